@@ -1,0 +1,919 @@
+"""CPU oracle: float64 NumPy/SciPy restatement of py_neuromodulation's per-hop hot path.
+
+TEST INFRASTRUCTURE, NOT PRODUCT (see oracle/__init__.py).  Every class mirrors the
+reference's plugin signature ``cls(settings, ch_names, sfreq).calc_feature(data) -> dict``
+so the parity tests read like the reference's own tests.  ``settings`` is duck-typed: the
+reference's ``NMSettings`` (build container only) and ``py_neuromodulation_amd.settings``
+both work.  Citations are into /root/reference/py_neuromodulation/.
+
+The restatement is written from the arithmetic in SURVEY.md Appendix A, not copied: it is
+vectorised over channels/bands where the reference loops in Python, computes the FIR bank
+with ONE forward FFT per channel (the reference tiles data and taps, filter/mne_filter.py:
+110-116) and replaces scipy.ndimage.label bookkeeping in Bursts by run-length arithmetic.
+Results agree with the reference to float64 rounding (tests/test_oracle_golden.py).
+"""
+
+from __future__ import annotations
+
+import math
+from collections.abc import Sequence
+
+import numpy as np
+from scipy import fft as sp_fft
+
+from . import mne_restated
+
+# --------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------
+
+
+def _enabled(selector) -> list[str]:
+    """BoolSelector.get_enabled() (utils/types.py:134-140) for either settings flavour."""
+    return list(selector.get_enabled())
+
+
+def _band_items(settings):
+    return [(name, (fr[0], fr[1])) for name, fr in settings.frequency_ranges_hz.items()]
+
+
+def window_schedule(n_samples: int, sfreq: float, feat_hz: float, seg_ms: float):
+    """stream/generator.py:34-53 + stream/stream.py:298,310.
+
+    Returns (start_idx[int64], end_idx[int64], time_ms[float64]) for every window the
+    generator yields.  Float stride/segment, ``int()`` truncation, stop when end > T.
+    time_ms = ceil(timestamps[-1] * 1000 + 1), timestamps = arange(start, end) / sfreq.
+    """
+    seg = seg_ms / 1000 * sfreq
+    stride = sfreq / feat_hz
+    starts, ends, times = [], [], []
+    k = 0
+    while True:
+        start = stride * k
+        end = start + seg
+        k += 1
+        if int(end) > n_samples:
+            break
+        ts = np.arange(start, end) / sfreq
+        starts.append(int(start))
+        ends.append(int(end))
+        times.append(math.ceil(ts[-1] * 1000 + 1))
+    return (np.asarray(starts, np.int64), np.asarray(ends, np.int64),
+            np.asarray(times, np.float64))
+
+
+def fir_bank_apply(data: np.ndarray, taps: np.ndarray) -> np.ndarray:
+    """filter/mne_filter.py:110-126: y[c,b,n] = sum_k h[b,k] x[c, n + (L-1)//2 - k].
+
+    data (C, W), taps (B, L) -> (C, B, W); zero outside [0, W) ("same" centred on the
+    full convolution, also when L > W).
+    """
+    data = np.atleast_2d(np.asarray(data, np.float64))
+    taps = np.atleast_2d(np.asarray(taps, np.float64))
+    W, L = data.shape[-1], taps.shape[-1]
+    n = sp_fft.next_fast_len(W + L - 1, real=True)
+    X = sp_fft.rfft(data, n=n, axis=-1)
+    H = sp_fft.rfft(taps, n=n, axis=-1)
+    full = sp_fft.irfft(X[:, None, :] * H[None, :, :], n=n, axis=-1)
+    s = (L - 1) // 2
+    return full[:, :, s : s + W]
+
+
+def _var(x, axis=-1):
+    return np.var(x, axis=axis)
+
+
+def hjorth_params(x: np.ndarray):
+    """features/hjorth_raw.py:24-34 (also bandpower.py:185-207) along the last axis."""
+    d1 = np.diff(x, axis=-1)
+    d2 = np.diff(d1, axis=-1)
+    v0, v1, v2 = _var(x), _var(d1), _var(d2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mobility = np.sqrt(v1 / v0)
+        complexity = np.sqrt(v2 / v1) / mobility
+    return v0, mobility, complexity
+
+
+_NAN_EST = {"mean": np.nanmean, "median": np.nanmedian, "std": np.nanstd, "max": np.nanmax}
+
+
+def find_peaks_distance(x: np.ndarray, distance: float) -> np.ndarray:
+    """scipy.signal.find_peaks(x, distance=distance)[0], restated.
+
+    Strict local maxima, plateaus -> midpoint (l + r) // 2, end points never peaks;
+    then visit peaks by decreasing height (stable: later index wins ties, as SciPy's
+    argsort order traversed from the end) and drop neighbours closer than ceil(distance).
+    """
+    n = len(x)
+    peaks = []
+    i = 1
+    i_max = n - 1
+    while i < i_max:
+        if x[i - 1] < x[i]:
+            ahead = i + 1
+            while ahead < i_max and x[ahead] == x[i]:
+                ahead += 1
+            if x[ahead] < x[i]:
+                left, right = i, ahead - 1
+                peaks.append((left + right) // 2)
+                i = ahead
+        i += 1
+    peaks = np.asarray(peaks, dtype=np.intp)
+    if peaks.size == 0 or distance is None:
+        return peaks
+    dist = math.ceil(distance)
+    keep = np.ones(peaks.size, dtype=bool)
+    order = np.argsort(x[peaks])  # SciPy uses the default (unstable) argsort: ties within
+    # `distance` resolve implementation-dependently there too
+    for i in range(peaks.size - 1, -1, -1):
+        j = order[i]
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and peaks[j] - peaks[k] < dist:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < peaks.size and peaks[k] - peaks[j] < dist:
+            keep[k] = False
+            k += 1
+    return peaks[keep]
+
+
+# --------------------------------------------------------------------------------------
+# time-domain features
+# --------------------------------------------------------------------------------------
+
+
+class Hjorth:
+    """features/hjorth_raw.py:18-42."""
+
+    def __init__(self, settings, ch_names: Sequence[str], sfreq: float) -> None:
+        self.ch_names = list(ch_names)
+
+    def calc_feature(self, data: np.ndarray) -> dict:
+        data = np.asarray(data, np.float64)
+        d1 = np.diff(data, axis=-1)
+        v0, v1, v2 = _var(data), _var(d1), _var(np.diff(d1, axis=-1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            act = np.nan_to_num(v0)
+            mob = np.nan_to_num(np.sqrt(v1 / v0))
+            # NB the reference divides by the nan_to_num'ed mobility (hjorth_raw.py:31-34)
+            comp = np.nan_to_num(np.sqrt(v2 / v1) / mob)
+        out = {}
+        for i, ch in enumerate(self.ch_names):
+            out[f"{ch}_RawHjorth_Activity"] = act[i]
+            out[f"{ch}_RawHjorth_Mobility"] = mob[i]
+            out[f"{ch}_RawHjorth_Complexity"] = comp[i]
+        return out
+
+
+class Raw:
+    """features/hjorth_raw.py:45-57."""
+
+    def __init__(self, settings, ch_names, sfreq) -> None:
+        self.ch_names = list(ch_names)
+
+    def calc_feature(self, data):
+        return {f"{ch}_raw": data[i, -1] for i, ch in enumerate(self.ch_names)}
+
+
+class LineLength:
+    """features/linelength.py:11-21: mean(|diff| / (W - 1)) = sum|dx| / (W - 1)^2."""
+
+    def __init__(self, settings, ch_names, sfreq) -> None:
+        self.ch_names = list(ch_names)
+
+    def calc_feature(self, data):
+        W = data.shape[1]
+        ll = np.mean(np.abs(np.diff(data, axis=-1)) / (W - 1), axis=-1)
+        return {f"{ch}_LineLength": ll[i] for i, ch in enumerate(self.ch_names)}
+
+
+# --------------------------------------------------------------------------------------
+# oscillatory features (features/oscillatory.py)
+# --------------------------------------------------------------------------------------
+
+
+class _Oscillatory:
+    name = ""
+
+    def _common(self, settings, ch_names, sfreq, osc_settings):
+        self.s = osc_settings
+        self.sfreq = int(sfreq)
+        self.ch_names = list(ch_names)
+        assert self.s.windowlength_ms <= settings.segment_length_features_ms
+        self.estimators = _enabled(self.s.features)
+
+    def _emit(self, Z, Zband_fn, freqs_for_psd, psd_fn):
+        out = {}
+        with np.errstate(all="ignore"):
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for band, idx in self.idx_range:
+                    Zb = Zband_fn(idx)
+                    for est in self.estimators:
+                        res = _NAN_EST[est](Zb, axis=self._est_axis)
+                        for i, ch in enumerate(self.ch_names):
+                            out[f"{ch}_{self.name}_{band}_{est}"] = res[i]
+        if self.s.return_spectrum:
+            for i, ch in enumerate(self.ch_names):
+                for k, f in enumerate(freqs_for_psd):
+                    out[f"{ch}_{self.name}_psd_{int(f)}"] = psd_fn(i, k)
+        return out
+
+
+class FFT(_Oscillatory):
+    """features/oscillatory.py:58-119: |rfft(x[:, -N:])| -> log10 -> band estimators, bins [lo, hi)."""
+
+    name = "fft"
+    _est_axis = 1
+
+    def __init__(self, settings, ch_names, sfreq) -> None:
+        self._common(settings, ch_names, sfreq, settings.fft_settings)
+        self.N = int(np.floor(self.s.windowlength_ms / 1000 * sfreq))
+        self.freqs = sp_fft.rfftfreq(self.N, 1 / np.floor(self.sfreq))
+        self.idx_range = [
+            (b, np.where((self.freqs >= lo) & (self.freqs < hi))[0])
+            for b, (lo, hi) in _band_items(settings)
+        ]
+
+    def spectrum(self, data):
+        Z = np.abs(sp_fft.rfft(np.asarray(data, np.float64)[:, -self.N:], axis=-1))
+        if self.s.log_transform:
+            with np.errstate(divide="ignore"):
+                Z = np.log10(Z)
+        return Z
+
+    def calc_feature(self, data):
+        Z = self.spectrum(data)
+        return self._emit(Z, lambda idx: Z[:, idx], self.freqs, lambda i, k: Z[i][k])
+
+
+def welch_psd(data: np.ndarray, fs: int, nperseg: int) -> np.ndarray:
+    """scipy.signal.welch(x, fs, "hann", nperseg, noverlap=None) restated.
+
+    hann (periodic), 50 % overlap, per-segment mean removal, density scaling
+    1 / (fs * sum(w^2)), one-sided doubling, mean over segments.
+    """
+    x = np.asarray(data, np.float64)
+    W = x.shape[-1]
+    nperseg = min(nperseg, W)
+    step = nperseg - nperseg // 2
+    n = np.arange(nperseg)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * n / nperseg)
+    scale = 1.0 / (fs * np.sum(w * w))
+    starts = range(0, W - nperseg + 1, step)
+    acc = 0.0
+    for s in starts:
+        seg = x[..., s : s + nperseg]
+        seg = seg - seg.mean(axis=-1, keepdims=True)
+        P = np.abs(sp_fft.rfft(seg * w, axis=-1)) ** 2 * scale
+        acc = acc + P
+    P = acc / len(starts)
+    if nperseg % 2 == 0:
+        P[..., 1:-1] *= 2
+    else:
+        P[..., 1:] *= 2
+    return P
+
+
+class Welch(_Oscillatory):
+    """features/oscillatory.py:122-182 (nperseg = sfreq samples, bins [lo, hi))."""
+
+    name = "welch"
+    _est_axis = 1
+
+    def __init__(self, settings, ch_names, sfreq) -> None:
+        self._common(settings, ch_names, sfreq, settings.welch_settings)
+        self.freqs = sp_fft.rfftfreq(self.sfreq, 1 / self.sfreq)
+        self.idx_range = [
+            (b, np.where((self.freqs >= lo) & (self.freqs < hi))[0])
+            for b, (lo, hi) in _band_items(settings)
+        ]
+
+    def spectrum(self, data):
+        Z = welch_psd(data, self.sfreq, self.sfreq)
+        if self.s.log_transform:
+            with np.errstate(divide="ignore"):
+                Z = np.log10(Z)
+        return Z
+
+    def calc_feature(self, data):
+        Z = self.spectrum(data)
+        return self._emit(Z, lambda idx: Z[:, idx], self.freqs, lambda i, k: Z[i][k])
+
+
+def stft_mag(data: np.ndarray, nperseg: int) -> np.ndarray:
+    """|scipy.signal.stft(x, window="hamming", nperseg, boundary="even")| restated.
+
+    noverlap = nperseg // 2, nfft = nperseg, padded=True, scaling="spectrum" (/ sum(w)),
+    even extension by nperseg // 2 on each side.  Returns (C, nperseg // 2 + 1, n_seg).
+    """
+    x = np.asarray(data, np.float64)
+    h = nperseg // 2
+    step = nperseg - h
+    left = x[..., h:0:-1]
+    right = x[..., -2 : -h - 2 : -1]
+    xe = np.concatenate([left, x, right], axis=-1)
+    nadd = (-(xe.shape[-1] - nperseg) % step) % nperseg
+    if nadd:
+        xe = np.concatenate([xe, np.zeros(xe.shape[:-1] + (nadd,))], axis=-1)
+    n = np.arange(nperseg)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * n / nperseg)  # periodic hamming
+    nseg = (xe.shape[-1] - nperseg) // step + 1
+    out = np.empty(x.shape[:-1] + (nperseg // 2 + 1, nseg))
+    for m in range(nseg):
+        seg = xe[..., m * step : m * step + nperseg] * w
+        out[..., m] = np.abs(sp_fft.rfft(seg, axis=-1)) / w.sum()
+    return out
+
+
+class STFT(_Oscillatory):
+    """features/oscillatory.py:185-250 (nperseg = windowlength_ms *samples*, bins [lo, hi])."""
+
+    name = "stft"
+    _est_axis = (1, 2)
+
+    def __init__(self, settings, ch_names, sfreq) -> None:
+        self._common(settings, ch_names, sfreq, settings.stft_settings)
+        self.nperseg = int(self.s.windowlength_ms)
+        self.freqs = sp_fft.rfftfreq(self.nperseg, 1 / self.sfreq)
+        self.idx_range = [
+            (b, np.where((self.freqs >= lo) & (self.freqs <= hi))[0])
+            for b, (lo, hi) in _band_items(settings)
+        ]
+
+    def spectrum(self, data):
+        Z = stft_mag(data, self.nperseg)
+        if self.s.log_transform:
+            with np.errstate(divide="ignore"):
+                Z = np.log10(Z)
+        return Z
+
+    def calc_feature(self, data):
+        Z = self.spectrum(data)
+        return self._emit(Z, lambda idx: Z[:, idx, :], self.freqs,
+                          lambda i, k: Z[i].mean(axis=1)[k])
+
+
+# --------------------------------------------------------------------------------------
+# FIR bank + BandPower (filter/mne_filter.py, features/bandpower.py)
+# --------------------------------------------------------------------------------------
+
+
+def design_bank(f_ranges, sfreq, filter_length=None, l_trans=4, h_trans=4) -> np.ndarray:
+    """filter/mne_filter.py:35-80: create_filter per band, auto-length fallback on ValueError."""
+    if filter_length is None:
+        filter_length = sfreq - 1
+    if isinstance(filter_length, float):
+        filter_length = int(filter_length)
+    bank = []
+    for lo, hi in f_ranges:
+        try:
+            h = mne_restated.create_filter(None, sfreq, lo, hi, filter_length=filter_length,
+                                           l_trans_bandwidth=l_trans, h_trans_bandwidth=h_trans)
+        except ValueError:
+            h = mne_restated.create_filter(None, sfreq, lo, hi)
+        bank.append(h)
+    return np.vstack(bank)
+
+
+class BandPower:
+    """features/bandpower.py:98-207 (Kalman smoothing is out of scope)."""
+
+    def __init__(self, settings, ch_names, sfreq, taps: np.ndarray | None = None) -> None:
+        self.s = settings.bandpass_filter_settings
+        if getattr(self.s, "kalman_filter", False):
+            raise NotImplementedError("kalman_filter is out of scope")
+        self.sfreq = sfreq
+        self.ch_names = list(ch_names)
+        bands = _band_items(settings)
+        self.band_names = [b for b, _ in bands]
+        self.taps = design_bank([r for _, r in bands], sfreq) if taps is None else taps
+        self.seglens = [
+            int(np.floor(sfreq / 1000 * self.s.segment_lengths_ms[b])) for b in self.band_names
+        ]
+        self.feats = _enabled(self.s.bandpower_features)
+
+    def calc_feature(self, data):
+        y = fir_bank_apply(data, self.taps)  # (C, B, W)
+        out = {}
+        vals = {}
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for bi, seglen in enumerate(self.seglens):
+                t = y[:, bi, -seglen:]
+                act, mob, comp = hjorth_params(t)
+                if self.s.log_transform:
+                    act = np.log10(act)
+                vals[bi] = {"activity": np.nan_to_num(act), "mobility": np.nan_to_num(mob),
+                            "complexity": np.nan_to_num(comp)}
+        for ci, ch in enumerate(self.ch_names):
+            for bi, band in enumerate(self.band_names):
+                for f in self.feats:
+                    out[f"{ch}_bandpass_{f}_{band}"] = vals[bi][f][ci]
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# Bursts (features/bursts.py)
+# --------------------------------------------------------------------------------------
+
+
+def analytic_envelope(y: np.ndarray) -> np.ndarray:
+    """|scipy.signal.hilbert(y)| along the last axis (exact length-W analytic signal)."""
+    W = y.shape[-1]
+    Y = sp_fft.fft(y, axis=-1)
+    h = np.zeros(W)
+    if W % 2 == 0:
+        h[0] = h[W // 2] = 1
+        h[1 : W // 2] = 2
+    else:
+        h[0] = 1
+        h[1 : (W + 1) // 2] = 2
+    return np.abs(sp_fft.ifft(Y * h, axis=-1))
+
+
+def burst_stats(env: np.ndarray, thr: np.ndarray, sfreq: float, seg_s: float) -> dict:
+    """features/bursts.py:175-258 for env (..., W) and thr (...,): run-length arithmetic.
+
+    Returns dict of arrays shaped like ``thr``.
+    """
+    shp = thr.shape
+    W = env.shape[-1]
+    e = env.reshape(-1, W)
+    t = thr.reshape(-1)
+    n = e.shape[0]
+    res = {k: np.zeros(n) for k in ("duration_mean", "duration_max", "amplitude_mean",
+                                   "amplitude_max", "burst_rate_per_s", "in_burst")}
+    for r in range(n):
+        b = e[r] >= t[r]
+        d = np.diff(np.concatenate(([False], b)).astype(np.int8))
+        starts = np.flatnonzero(d == 1)
+        ends = np.flatnonzero(d == -1)  # exclusive end index of each finished run
+        n_trans = np.count_nonzero(d)
+        num_bursts = n_trans // 2
+        if num_bursts:
+            res["duration_mean"][r] = b.sum() / num_bursts / sfreq
+        # valid runs = runs that do not include the last sample
+        nv = len(ends)
+        if nv:
+            lens = ends - starts[:nv]
+            res["duration_max"][r] = lens.max() / sfreq
+            means = np.array([e[r][s:en].mean() for s, en in zip(starts[:nv], ends)])
+            res["amplitude_mean"][r] = means.mean()
+        res["amplitude_max"][r] = (e[r] * b).max()
+        res["in_burst"][r] = float(b[-1])
+    res["burst_rate_per_s"] = res["duration_mean"] / seg_s
+    return {k: v.reshape(shp) for k, v in res.items()}
+
+
+class Bursts:
+    """features/bursts.py:60-298.  Stateful: ring buffer of envelopes per (channel, band)."""
+
+    def __init__(self, settings, ch_names, sfreq, taps: np.ndarray | None = None) -> None:
+        self.s = settings.bursts_settings
+        for fb in self.s.frequency_bands:
+            if fb not in settings.frequency_ranges_hz:
+                raise ValueError(f"bursting {fb} needs to be defined in settings['frequency_ranges_hz']")
+        self.sfreq = sfreq
+        self.ch_names = list(ch_names)
+        self.seg_s = settings.segment_length_features_ms / 1000
+        self.samples_overlap = int(sfreq * self.seg_s / settings.sampling_rate_features_hz)
+        self.band_names = list(self.s.frequency_bands)
+        ranges = [(settings.frequency_ranges_hz[b][0], settings.frequency_ranges_hz[b][1])
+                  for b in self.band_names]
+        self.taps = design_bank(ranges, sfreq) if taps is None else taps
+        self.n_ring = int(sfreq * self.s.time_duration_s)
+        self.buffer = np.empty((len(self.ch_names), len(self.band_names), 0))
+        self.batch = 0
+        self.feats = _enabled(self.s.burst_features)
+
+    def envelope(self, data):
+        return analytic_envelope(fir_bank_apply(data, self.taps))
+
+    def update_threshold(self, new: np.ndarray) -> np.ndarray:
+        """Append ``new`` (C, B, n_new) to the ring and return the percentile threshold.
+
+        REFERENCE QUIRK (features/bursts.py:3-6,156-173): the threshold is computed with
+        NumPy's *private* ``_quantile``, which ``partition``s its argument IN PLACE, and the
+        argument is ``self.data_buffer`` itself.  From the second call on the "ring" is
+        therefore no longer time-ordered: positions [0, lo] hold (in implementation-defined
+        order) elements <= the lower interpolation neighbour s[lo], lo = floor(q (n - 1)).
+        When the buffer overflows by t, ``[..., -n_ring:]`` drops the first t positions,
+        i.e. t elements that are all <= s[lo] -- never the oldest ones, never one of the
+        top n - 1 - lo.  WHICH of the small elements go is implementation-defined (NumPy's
+        introselect / AVX-512 quickselect), but irrelevant: every later threshold is an
+        order statistic at a fixed distance from the TOP of a multiset whose top part is
+        never removed, so it only depends on how many elements lie below it.  The
+        well-defined equivalent used here: on overflow drop the t smallest elements.
+        Consequence (reproduced, not fixed): once the ring is full the threshold is a
+        running order statistic over the WHOLE history and never decreases.
+        """
+        buf = np.concatenate((self.buffer, new), axis=2)
+        t = buf.shape[-1] - self.n_ring
+        if t > 0:
+            buf = np.partition(buf, t - 1, axis=-1)[:, :, t:]
+        self.buffer = buf
+        return np.quantile(buf, self.s.threshold / 100, axis=-1)
+
+    def calc_feature(self, data):
+        env = self.envelope(data)
+        n_new = env.shape[-1] if self.batch == 0 else self.samples_overlap
+        self.batch += 1
+        thr = self.update_threshold(env[:, :, -n_new:])
+        st = burst_stats(env, thr, self.sfreq, self.seg_s)
+        self.last_thr = thr
+        out = {}
+        for ci, ch in enumerate(self.ch_names):
+            for bi, fb in enumerate(self.band_names):
+                for f in self.feats:
+                    if f == "duration":
+                        out[f"{ch}_bursts_{fb}_duration_mean"] = st["duration_mean"][ci, bi]
+                        out[f"{ch}_bursts_{fb}_duration_max"] = st["duration_max"][ci, bi]
+                    elif f == "amplitude":
+                        out[f"{ch}_bursts_{fb}_amplitude_mean"] = st["amplitude_mean"][ci, bi]
+                        out[f"{ch}_bursts_{fb}_amplitude_max"] = st["amplitude_max"][ci, bi]
+                    elif f == "burst_rate_per_s":
+                        out[f"{ch}_bursts_{fb}_burst_rate_per_s"] = st["burst_rate_per_s"][ci, bi]
+                    elif f == "in_burst":
+                        out[f"{ch}_bursts_{fb}_in_burst"] = st["in_burst"][ci, bi]
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# Sharp waves (features/sharpwaves.py)
+# --------------------------------------------------------------------------------------
+
+_SW_FEATURE_ORDER = ["peak_left", "peak_right", "num_peaks", "trough", "width", "prominence",
+                     "interval", "decay_time", "rise_time", "sharpness", "rise_steepness",
+                     "decay_steepness", "slope_ratio"]
+_SW_EST_ORDER = ["mean", "median", "max", "min", "var"]
+_SW_EST = {
+    "mean": lambda a: np.add.reduce(np.asarray(a, np.float64)) / np.size(a),
+    "median": np.median, "max": np.max, "min": np.min, "var": np.var,
+}
+
+
+def sharpwave_design(settings, sfreq):
+    """features/sharpwaves.py:121-146: auto-length band-pass per filter range."""
+    names, taps = [], []
+    for fr in settings.sharpwave_analysis_settings.filter_ranges_hz:
+        assert fr[1] < sfreq
+        names.append(f"range_{fr[0]:.0f}_{fr[1]:.0f}")
+        taps.append(mne_restated.create_filter(None, sfreq, fr[0], fr[1]))
+    return names, taps
+
+
+def analyze_waveform(z: np.ndarray, sfreq: float, dist_peaks: float, dist_troughs: float,
+                     need: set[str]) -> dict:
+    """features/sharpwaves.py:330-465 for one 1-D series ``z`` (already sign-flipped)."""
+    W = len(z)
+    peaks = find_peaks_distance(z, dist_peaks)
+    troughs = find_peaks_distance(-z, dist_troughs)
+    ptr = first_valid = last_valid = 0
+    left, right = [], []
+    for i in range(len(troughs)):
+        while ptr < peaks.size and peaks[ptr] < troughs[i]:
+            ptr += 1
+        if ptr - 1 < 0:
+            first_valid = i + 1
+            continue
+        if ptr == peaks.size:
+            continue
+        last_valid = i
+        left.append(peaks[ptr - 1])
+        right.append(peaks[ptr])
+    troughs = troughs[first_valid : last_valid + 1]
+    left = np.asarray(left, dtype=int)
+    right = np.asarray(right, dtype=int)
+    ms = 1000 / sfreq
+    res: dict = {}
+    res["peak_left"], res["peak_right"], res["trough"] = z[left], z[right], z[troughs]
+    if "interval" in need:
+        res["interval"] = np.concatenate((np.zeros(1), np.diff(troughs))) * ms
+    if "sharpness" in need:
+        s = int(5 * ms)
+        tv = troughs[np.logical_and(troughs - s > 0, troughs + s < W)]
+        res["sharpness"] = z[tv] - 0.5 * (z[tv - s] + z[tv + s])
+    if "num_peaks" in need:
+        res["num_peaks"] = [troughs.shape[0]]
+    if need & {"rise_steepness", "decay_steepness", "slope_ratio"}:
+        st = np.concatenate((np.zeros(1), np.diff(z)))
+        n = troughs.shape[0]
+        rise = np.zeros(n)
+        decay = np.zeros(n)
+        for i in range(n):
+            rise[i] = np.max(np.abs(st[left[i] : troughs[i] + 1]))
+            decay[i] = np.max(np.abs(st[troughs[i] : right[i] + 1]))
+        res["rise_steepness"], res["decay_steepness"] = rise, decay
+        res["slope_ratio"] = rise - decay
+    if "prominence" in need:
+        res["prominence"] = np.abs((res["peak_right"] + res["peak_left"]) / 2 - res["trough"])
+    if "decay_time" in need:
+        res["decay_time"] = (left - troughs) * ms
+    if "rise_time" in need:
+        res["rise_time"] = (right - troughs) * ms
+    if "width" in need:
+        res["width"] = right - left
+    return res
+
+
+class SharpwaveAnalyzer:
+    """features/sharpwaves.py:100-328."""
+
+    def __init__(self, settings, ch_names, sfreq, taps: list | None = None) -> None:
+        self.s = settings.sharpwave_analysis_settings
+        self.sfreq = sfreq
+        self.ch_names = list(ch_names)
+        self.filter_names, designed = (sharpwave_design(settings, sfreq) if taps is None else
+                                       ([f"range_{fr[0]:.0f}_{fr[1]:.0f}"
+                                         for fr in self.s.filter_ranges_hz], taps))
+        self.taps = [np.asarray(t, np.float64) for t in designed]
+        self.used = [f for f in _SW_FEATURE_ORDER if getattr(self.s.sharpwave_features, f)]
+        est = self.s.estimator
+        self.est_of = {f: [e for e in _SW_EST_ORDER if f in getattr(est, e)] for f in self.used}
+        for f in self.used:
+            assert self.est_of[f], f"Add estimator key for {f}"
+        self.combos = [(f, e) for f in self.used for e in self.est_of[f]]
+
+    def filtered(self, data):
+        return np.stack([fir_bank_apply(data, t[None])[:, 0] for t in self.taps], axis=1)
+
+    def calc_feature(self, data):
+        y = self.filtered(data)
+        need = set(self.used)
+        per_key: dict[str, dict[str, float]] = {}
+        pol = []
+        if self.s.detect_peaks.estimate:
+            pol.append(("Peak", 1.0))
+        if self.s.detect_troughs.estimate:
+            pol.append(("Trough", -1.0))
+        dp = self.s.detect_troughs.distance_peaks_ms     # sharpwaves.py:339-344 always reads
+        dt = self.s.detect_troughs.distance_troughs_ms   # the detect_troughs block
+        for ci, ch in enumerate(self.ch_names):
+            for fi, fname in enumerate(self.filter_names):
+                for pname, sign in pol:
+                    r = analyze_waveform(sign * y[ci, fi], self.sfreq, dp, dt, need)
+                    for f, e in self.combos:
+                        if f == "num_peaks":
+                            per_key.setdefault(f"{ch}_Sharpwave_{f}_{fname}", {})[pname] = r[f][0]
+                            continue
+                        v = r[f]
+                        val = _SW_EST[e](v) if len(v) != 0 else 0
+                        per_key.setdefault(f"{ch}_Sharpwave_{e.title()}_{f}_{fname}", {})[pname] = val
+        out = {}
+        if self.s.apply_estimator_between_peaks_and_troughs:
+            for ch in self.ch_names:
+                for fname in self.filter_names:
+                    for f, e in self.combos:
+                        if f == "num_peaks":
+                            continue
+                        k = f"{ch}_Sharpwave_{e.title()}_{f}_{fname}"
+                        vals = list(per_key[k].values())
+                        out[k] = _SW_EST[e]([vals[0], vals[1]])
+            if "num_peaks" in self.used:
+                for ch in self.ch_names:
+                    for fname in self.filter_names:
+                        k = f"{ch}_Sharpwave_num_peaks_{fname}"
+                        out[k] = (per_key[k]["Peak"] + per_key[k]["Trough"]) / 2
+        else:
+            for k, sub in per_key.items():
+                for pname, v in sub.items():
+                    out[f"{k}_analyze_{pname}"] = v
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# preprocessing (filter/notch_filter.py, processing/rereference.py, processing/resample.py)
+# --------------------------------------------------------------------------------------
+
+
+def notch_design(sfreq: float, line_noise: float, notch_width: float = 3.0,
+                 trans_bandwidth: float = 6.8):
+    """filter/notch_filter.py:25-76: band-stop bank at k * line_noise, L = int(sfreq - 1)."""
+    freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
+    if freqs.size > 0 and freqs[-1] >= sfreq / 2:
+        freqs = freqs[:-1]
+    if freqs.size == 0:
+        return None
+    widths = notch_width * np.ones_like(freqs)
+    tb_half = trans_bandwidth / 2.0
+    lows = [f - w / 2.0 - tb_half for f, w in zip(freqs, widths)]
+    highs = [f + w / 2.0 + tb_half for f, w in zip(freqs, widths)]
+    return mne_restated.create_filter(None, sfreq, l_freq=highs, h_freq=lows,
+                                      filter_length=int(sfreq - 1),
+                                      l_trans_bandwidth=tb_half, h_trans_bandwidth=tb_half)
+
+
+class NotchFilter:
+    """filter/notch_filter.py:9-93."""
+
+    def __init__(self, sfreq, line_noise=None, taps=None) -> None:
+        if line_noise is None and taps is None:
+            raise ValueError("Either line_noise or freqs must be defined")
+        self.taps = notch_design(sfreq, line_noise) if taps is None else taps
+
+    def process(self, data):
+        if self.taps is None:
+            return data
+        return mne_restated._overlap_add_filter(data, self.taps)
+
+
+def reref_matrix(names, rereference, used, types, status) -> np.ndarray | None:
+    """processing/rereference.py:33-86 from plain column lists of the channel table."""
+    idx = [i for i, u in enumerate(used) if u == 1]
+    names = [names[i] for i in idx]
+    refs = [rereference[i] for i in idx]
+    types = [types[i] for i in idx]
+    status = [status[i] for i in idx]
+    n = len(names)
+    if n in (0, 1):
+        return None
+    R = np.zeros((n, n))
+    for i in range(n):
+        R[i, i] = 1
+        ref = refs[i]
+        if ref is None or (isinstance(ref, float) and np.isnan(ref)) or \
+                str(ref).lower() == "none" or status[i] != "good":
+            continue
+        if ref.lower() == "average":
+            ridx = [j for j in range(n) if types[j] == types[i] and status[j] == "good" and j != i]
+        else:
+            ridx = []
+            for rc in ref.split("&"):
+                if rc not in names:
+                    raise ValueError(f"One or more of the reference channels are not part of "
+                                     f"the recording channels. First missing channel: {rc}.")
+                if rc == names[i]:
+                    raise ValueError(f"You cannot rereference to the same channel. Channel: {rc}.")
+                ridx.append(names.index(rc))
+        R[i, ridx] = -1 / len(ridx)
+    good = [i for i in range(n) if status[i] == "good"]
+    return R[np.ix_(good, good)]
+
+
+class Resampler:
+    """processing/resample.py:19-60 (ratio 1 is a no-op; other ratios are parity-unpinned)."""
+
+    def __init__(self, sfreq, resample_freq_hz) -> None:
+        ratio = float(resample_freq_hz / sfreq)
+        self.up = 0.0 if ratio == 1.0 else ratio
+
+    def process(self, data):
+        if not self.up:
+            return data
+        return mne_restated.resample(np.asarray(data, np.float64), up=self.up, down=1.0)
+
+
+# --------------------------------------------------------------------------------------
+# post-processing (processing/normalization.py) -- SURVEY 8(f) "next" #1
+# --------------------------------------------------------------------------------------
+
+
+class FeatureNormalizer:
+    """processing/normalization.py:31-111 for mean / median / zscore / zscore-median."""
+
+    def __init__(self, settings) -> None:
+        s = settings.feature_normalization_settings
+        self.method = s.normalization_method
+        self.clip = s.clip
+        self.n = int(s.normalization_time_s * settings.sampling_rate_features_hz)
+        self.prev = np.empty((0, 0))
+
+    def process(self, cur: np.ndarray) -> np.ndarray:
+        if self.prev.size == 0:
+            self.prev = cur
+            return cur
+        self.prev = np.vstack((self.prev, cur))
+        has_nan = np.any(np.isnan(sum(self.prev)))
+        mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)
+        med = (np.nanmedian if has_nan else np.median)(self.prev, axis=0)
+        std = (np.nanstd if has_nan else np.std)(self.prev, axis=0)
+        std[std == 0] = 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if self.method == "mean":
+                out = (cur - mean) / mean
+            elif self.method == "median":
+                out = (cur - med) / med
+            elif self.method == "zscore":
+                out = (cur - mean) / std
+            elif self.method == "zscore-median":
+                out = (cur - med) / std
+            else:
+                raise NotImplementedError(self.method)
+        if self.clip:
+            out = out.clip(min=-self.clip, max=self.clip)
+        self.prev = self.prev[-self.n + 1:]
+        return np.nan_to_num(out)
+
+
+# --------------------------------------------------------------------------------------
+# orchestrator (stream/data_processor.py:238-311, features/feature_processor.py:45-84)
+# --------------------------------------------------------------------------------------
+
+FEATURE_ORDER = ["raw_hjorth", "return_raw", "bandpass_filter", "stft", "fft", "welch",
+                 "sharpwave_analysis", "fooof", "nolds", "coherence", "bursts", "linelength",
+                 "mne_connectivity", "bispectrum"]
+_FEATURE_CLS = {"raw_hjorth": Hjorth, "return_raw": Raw, "bandpass_filter": BandPower,
+                "stft": STFT, "fft": FFT, "welch": Welch, "sharpwave_analysis": SharpwaveAnalyzer,
+                "bursts": Bursts, "linelength": LineLength}
+_PREPROC_ORDER = ["preprocessing_filter", "notch_filter", "raw_resampling", "re_referencing",
+                  "raw_normalization"]
+
+
+class DataProcessor:
+    """stream/data_processor.py:19-311 restricted to the SURVEY section-8 scope.
+
+    ``channels`` is a mapping of column name -> list (name, rereference, used, target,
+    type, status, new_name), e.g. ``df.to_dict("list")``.
+    """
+
+    def __init__(self, sfreq, settings, channels: dict, line_noise=None) -> None:
+        self.settings = settings
+        self.sfreq = sfreq // 1
+        ch = channels
+        n = len(ch["name"])
+        self.ch_names_used = [ch["new_name"][i] for i in range(n)
+                              if ch["used"][i] == 1 and ch["status"][i] == "good"]
+        self.feature_idx = [i for i in range(n) if ch["used"][i] and not ch["target"][i]
+                            and ch["status"][i] == "good"]
+        self.pre = []
+        for name in _PREPROC_ORDER:
+            if name not in settings.preprocessing:
+                continue
+            if name == "notch_filter":
+                self.pre.append(NotchFilter(self.sfreq, line_noise))
+            elif name == "raw_resampling":
+                self.pre.append(Resampler(self.sfreq, settings.raw_resampling_settings.resample_freq_hz))
+            elif name == "re_referencing":
+                R = reref_matrix(ch["name"], ch["rereference"], ch["used"], ch["type"], ch["status"])
+                self.pre.append(_Reref(R))
+            else:
+                raise NotImplementedError(f"{name} is out of scope (SURVEY.md section 2)")
+        self.features = []
+        for f in _enabled(settings.features):
+            if f not in _FEATURE_CLS:
+                raise NotImplementedError(f"feature {f} is out of scope (SURVEY.md section 2)")
+            self.features.append(_FEATURE_CLS[f](settings, self.ch_names_used, self.sfreq))
+        self.normalizer = (FeatureNormalizer(settings)
+                           if settings.postprocessing.feature_normalization else None)
+        self.non_psd = None
+
+    def preprocess(self, data):
+        for p in self.pre:
+            data = p.process(data)
+        return data
+
+    def process(self, data: np.ndarray) -> dict:
+        nan_channels = np.isnan(data).any(axis=1)
+        data = np.nan_to_num(data)[self.feature_idx, :]
+        data = self.preprocess(data)
+        feats: dict = {}
+        for f in self.features:
+            feats.update(f.calc_feature(data))
+        if self.normalizer is not None:
+            keys = list(feats.keys())
+            vals = np.fromiter(feats.values(), dtype=np.float64)
+            if not self.settings.feature_normalization_settings.normalize_psd:
+                if self.non_psd is None:
+                    self.non_psd = [i for i, k in enumerate(keys) if "psd" not in k]
+                normed = vals.copy()
+                normed[self.non_psd] = self.normalizer.process(vals[self.non_psd])
+            else:
+                normed = self.normalizer.process(vals)
+            feats = dict(zip(keys, normed))
+        if nan_channels.sum() > 0:
+            for ch in list(np.array(self.ch_names_used)[nan_channels]):
+                for k in feats:
+                    if ch in k:
+                        feats[k] = np.nan
+        return feats
+
+
+class _Reref:
+    def __init__(self, R):
+        self.R = R
+
+    def process(self, data):
+        return data if self.R is None else self.R @ data
+
+
+def run_stream(data: np.ndarray, sfreq: float, settings, channels: dict, line_noise=50):
+    """stream/stream.py:198-345 restricted to feature computation: list of per-window dicts
+    (with ``time`` and target columns), in reference column order."""
+    dp = DataProcessor(sfreq, settings, channels, line_noise)
+    starts, ends, times = window_schedule(data.shape[1], sfreq, settings.sampling_rate_features_hz,
+                                          settings.segment_length_features_ms)
+    tidx = [i for i, t in enumerate(channels["target"]) if t == 1]
+    rows = []
+    for s, e, t in zip(starts, ends, times):
+        w = data[:, s:e]
+        d = dp.process(w)
+        d["time"] = t
+        for i in tidx:
+            d[channels["name"][i]] = w[i, -1]
+        rows.append({k: float(v) for k, v in d.items()})
+    return rows

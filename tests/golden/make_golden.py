@@ -1,0 +1,322 @@
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Build-container only: imports /root/reference through tests/golden/ref_shim.py (which
+cannot travel to the GPU box), runs the reference's own classes on seeded inputs and
+stores inputs, FIR taps and outputs.  Only data is stored -- no reference source.
+
+    python tests/golden/make_golden.py
+
+Every .npz holds: ``settings_json`` (the reference's ``NMSettings.model_dump()``),
+``sfreq``, ``data`` (float64), ``keys``/``values`` per feature class, and the taps the
+reference used (designed by oracle.mne_restated injected as mne.filter.create_filter; tap
+DESIGN is therefore parity-unpinned against MNE, everything downstream is reference code).
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+import tempfile
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import ref_shim  # noqa: E402
+
+nm = ref_shim.load_reference()
+import py_neuromodulation.features, py_neuromodulation.processing, py_neuromodulation.stream.generator  # noqa: E402
+warnings.filterwarnings("ignore")
+
+
+def synth(C, T, sfreq, seed, dc=True):
+    """SURVEY 8(d) synthetic generator: 50 N(0,1) + 10 sin(20 Hz) + 5 sin(70 Hz) + dc_c."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / sfreq
+    x = rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + 5 * np.sin(2 * np.pi * 70 * t)
+    if dc:
+        x = x + rng.uniform(-500, 500, size=(C, 1))
+    return x
+
+
+def dump(settings):
+    return json.dumps(settings.model_dump())
+
+
+def pack(d: dict, prefix: str, out: dict):
+    out[prefix + "_keys"] = np.array(list(d.keys()))
+    out[prefix + "_values"] = np.array([float(v) for v in d.values()], dtype=np.float64)
+
+
+def all_estimators(s):
+    for name in ("fft_settings", "welch_settings", "stft_settings"):
+        for e in ("mean", "median", "std", "max"):
+            setattr(s[name].features, e, True)
+
+
+def sharpwave_all(s):
+    sw = s.sharpwave_analysis_settings
+    sw.sharpwave_features.enable_all()
+    feats = list(type(sw.sharpwave_features).model_fields.keys())
+    sw.estimator.mean = list(feats)
+    sw.estimator.median = ["prominence", "interval"]
+    sw.estimator.max = ["prominence", "sharpness", "rise_steepness"]
+    sw.estimator.min = ["decay_time", "sharpness"]
+    sw.estimator.var = ["interval", "width"]
+
+
+def feature_case(name, sfreq, data, mutate):
+    s = nm.NMSettings.get_default()
+    s.features.enable_all()
+    for f in ("fooof", "nolds", "coherence", "mne_connectivity", "bispectrum"):
+        setattr(s.features, f, False)
+    mutate(s)
+    s = s.validate()
+    ch_names = [f"ch{i}" for i in range(data.shape[0])]
+    out = {"settings_json": dump(s), "sfreq": sfreq, "data": data, "ch_names": np.array(ch_names)}
+    pack(nm.features.Hjorth(s, ch_names, sfreq).calc_feature(data), "hjorth", out)
+    pack(nm.features.Raw(s, ch_names, sfreq).calc_feature(data), "raw", out)
+    pack(nm.features.LineLength(s, ch_names, sfreq).calc_feature(data), "linelength", out)
+    pack(nm.features.FFT(s, ch_names, sfreq).calc_feature(data), "fft", out)
+    pack(nm.features.Welch(s, ch_names, sfreq).calc_feature(data), "welch", out)
+    pack(nm.features.STFT(s, ch_names, sfreq).calc_feature(data), "stft", out)
+    bp = nm.features.BandPower(s, ch_names, sfreq)
+    out["bank_taps"] = bp.bandpass_filter.filter_bank
+    out["bank_filtered"] = bp.bandpass_filter.filter_data(data)[:2]
+    pack(bp.calc_feature(data), "bandpass", out)
+    sw = nm.features.SharpwaveAnalyzer(s, ch_names, sfreq)
+    for i, (_, taps) in enumerate(sw.list_filter):
+        out[f"sw_taps_{i}"] = taps
+    pack(sw.calc_feature(data), "sharpwave", out)
+    out["sw_filtered"] = sw.filtered_data[:2]
+    bu = nm.features.Bursts(s, ch_names, sfreq)
+    out["bursts_taps"] = bu.bandpass_filter.filter_bank
+    pack(bu.calc_feature(data), "bursts", out)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "values" in k})
+
+
+def case_feat_1k():
+    def mut(s):
+        all_estimators(s)
+        sharpwave_all(s)
+        for f in ("activity", "mobility", "complexity"):
+            setattr(s.bandpass_filter_settings.bandpower_features, f, True)
+    feature_case("feat_1k", 1000, synth(4, 1000, 1000, 11), mut)
+
+    def mut2(s):
+        mut(s)
+        for n in ("fft_settings", "welch_settings", "stft_settings"):
+            s[n].log_transform = False
+        s.bandpass_filter_settings.log_transform = False
+        s.sharpwave_analysis_settings.apply_estimator_between_peaks_and_troughs = False
+    feature_case("feat_1k_nolog", 1000, synth(3, 1000, 1000, 12, dc=False), mut2)
+
+
+def case_feat_2k():
+    def mut(s):
+        s.segment_length_features_ms = 1000
+        s.frequency_ranges_hz = {
+            "theta": [4, 8], "alpha": [8, 12], "low_beta": [13, 20], "high_beta": [20, 35],
+            "low_gamma": [60, 80], "high_gamma": [90, 200], "HFA": [200, 400],
+            "broadband": [4, 400]}
+        s.bandpass_filter_settings.segment_lengths_ms["broadband"] = 1000
+        s.stft_settings.windowlength_ms = 500
+        s.bursts_settings.frequency_bands = ["low_beta", "high_beta"]
+    feature_case("feat_2k", 2000, synth(2, 2000, 2000, 13), mut)
+
+
+def case_special_rows():
+    rng = np.random.default_rng(14)
+    data = np.vstack([np.zeros(1000), np.full(1000, 3.25), rng.random(1000),
+                      np.sin(2 * np.pi * 20 * np.arange(1000) / 1000) + rng.random(1000)])
+
+    def mut(s):
+        all_estimators(s)
+    feature_case("feat_special_rows", 1000, data, mut)
+
+
+def case_bursts_sequence():
+    sfreq, C, T = 1000, 2, 6000
+    s = nm.NMSettings.get_default()
+    s.bursts_settings.time_duration_s = 2
+    s.bursts_settings.frequency_bands = ["low_beta", "high_beta"]
+    s = s.validate()
+    rng = np.random.default_rng(15)
+    t = np.arange(T) / sfreq
+    amp = 1 + 0.8 * np.sin(2 * np.pi * 0.7 * t)
+    data = rng.standard_normal((C, T)) * 20 + 30 * amp * np.sin(2 * np.pi * 18 * t)
+    ch_names = [f"ch{i}" for i in range(C)]
+    bu = nm.features.Bursts(s, ch_names, sfreq)
+    gen = nm.stream.generator.RawDataGenerator(data, sfreq, s.sampling_rate_features_hz,
+                                               s.segment_length_features_ms)
+    rows, keys = [], None
+    for _, w in gen:
+        d = bu.calc_feature(w)
+        keys = list(d.keys())
+        rows.append([float(v) for v in d.values()])
+    out = {"settings_json": dump(s), "sfreq": sfreq, "data": data, "ch_names": np.array(ch_names),
+           "bursts_taps": bu.bandpass_filter.filter_bank, "keys": np.array(keys),
+           "values": np.array(rows)}
+    np.savez_compressed(HERE / "bursts_sequence.npz", **out)
+    print("bursts_sequence", out["values"].shape)
+
+
+def case_sharpwave_tests():
+    """Inputs of the reference's tests/test_sharpwave.py (impulses, sines)."""
+    sfreq = 1000
+    s = nm.NMSettings.get_default()
+    sharpwave_all(s)
+    s = s.validate()
+    W = 1000
+    rows = []
+    for height in (1, 2, 3, 4):
+        x = np.zeros(W)
+        x[100::200] = height
+        rows.append(x)
+    for spacing in (100, 200, 300, 400):
+        x = np.zeros(W)
+        x[50::spacing] = 1.0
+        rows.append(x)
+    t = np.arange(W) / sfreq
+    rng = np.random.default_rng(16)
+    rows.append(np.sin(2 * np.pi * 5 * t) + 0.1 * rng.standard_normal(W))
+    rows.append(np.sin(2 * np.pi * 15 * t) + 0.1 * rng.standard_normal(W))
+    rows.append(np.round(5 * np.sin(2 * np.pi * 9 * t)))  # plateaus
+    data = np.vstack(rows)
+    ch_names = [f"ch{i}" for i in range(data.shape[0])]
+    sw = nm.features.SharpwaveAnalyzer(s, ch_names, sfreq)
+    out = {"settings_json": dump(s), "sfreq": sfreq, "data": data, "ch_names": np.array(ch_names)}
+    for i, (_, taps) in enumerate(sw.list_filter):
+        out[f"sw_taps_{i}"] = taps
+    pack(sw.calc_feature(data), "sharpwave", out)
+    np.savez_compressed(HERE / "sharpwave_tests.npz", **out)
+    print("sharpwave_tests", out["sharpwave_values"].shape)
+
+
+def _run_stream(data, sfreq, s, channels=None, line_noise=50):
+    st = nm.Stream(sfreq=sfreq, data=data if channels is None else None, channels=channels,
+                   settings=s, line_noise=line_noise, verbose=False)
+    with tempfile.TemporaryDirectory() as td:
+        df = st.run(data=data, out_dir=td, save_csv=False)
+    return st, df
+
+
+def case_pipeline():
+    """README demo shape (README.rst:73-86): 5 ch x 10000 random, 3 Hz features."""
+    np.random.seed(0)
+    data = np.random.random([5, 10000])
+    out = {"sfreq": 1000, "data": data}
+    for tag, mutate in {
+        "default": lambda s: None,                      # notch+reref+zscore (notch taps unpinned)
+        "reref_nonorm": lambda s: (setattr(s, "preprocessing", ["re_referencing"]),
+                                   setattr(s.postprocessing, "feature_normalization", False)),
+        "nopre_norm": lambda s: setattr(s, "preprocessing", []),
+    }.items():
+        s = nm.NMSettings.get_default()
+        s.features.bandpass_filter = True
+        s.features.stft = True
+        s.sampling_rate_features_hz = 3
+        mutate(s)
+        st, df = _run_stream(data, 1000, s)
+        out[f"{tag}_settings_json"] = dump(st.settings)
+        out[f"{tag}_columns"] = np.array(list(df.columns))
+        out[f"{tag}_values"] = df.to_numpy(dtype=np.float64)
+        out[f"{tag}_channels_json"] = json.dumps(st.channels.to_dict("list"))
+        print("pipeline", tag, df.shape)
+    np.savez_compressed(HERE / "pipeline_readme.npz", **out)
+
+
+def _small_settings():
+    s = nm.NMSettings.get_default()
+    s.reset()
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.features.linelength = True
+    s.preprocessing = ["re_referencing"]
+    s.postprocessing.feature_normalization = False
+    return s
+
+
+def case_nan_and_channels():
+    """tests/test_nan_values.py (NaN policy) and bad/target/bipolar channel handling."""
+    import pandas as pd
+
+    rng = np.random.default_rng(17)
+    # (1) NaN policy with the default channel table (every channel used; the reference's NaN
+    # mask indexing requires that, data_processor.py:253,300)
+    data = rng.standard_normal((3, 3000)) * 10
+    data[1, 1500:1510] = np.nan
+    st, df = _run_stream(data, 1000, _small_settings())
+    out = {"settings_json": dump(st.settings), "sfreq": 1000, "nan_data": data,
+           "nan_columns": np.array(list(df.columns)), "nan_values": df.to_numpy(dtype=np.float64),
+           "nan_channels_json": json.dumps(st.channels.to_dict("list"))}
+    # (2) mixed channel table: bipolar refs, a bad channel, an unused target channel
+    data = rng.standard_normal((6, 3000)) * 10
+    ch = pd.DataFrame({
+        "name": ["LFP_0", "LFP_1", "ECOG_0", "ECOG_1", "ECOG_2", "MOV"],
+        "rereference": ["LFP_1", "LFP_0", "average", "average", "average", "None"],
+        "used": [1, 1, 1, 1, 1, 0],
+        "target": [0, 0, 0, 0, 0, 1],
+        "type": ["seeg", "seeg", "ecog", "ecog", "ecog", "misc"],
+        "status": ["good", "good", "good", "bad", "good", "good"],
+        "new_name": ["LFP_0-LFP_1", "LFP_1-LFP_0", "ECOG_0-avgref", "ECOG_1-avgref",
+                     "ECOG_2-avgref", "MOV"],
+    })
+    st, df = _run_stream(data, 1000, _small_settings(), channels=ch)
+    rr = nm.processing.ReReferencer(1000, ch)
+    out.update({"mix_data": data, "mix_columns": np.array(list(df.columns)),
+                "mix_values": df.to_numpy(dtype=np.float64),
+                "mix_channels_json": json.dumps(ch.to_dict("list")),
+                "mix_ref_matrix": rr.ref_matrix})
+    np.savez_compressed(HERE / "pipeline_nan_channels.npz", **out)
+    print("pipeline_nan_channels", out["nan_values"].shape, out["mix_values"].shape)
+
+
+def case_schedule():
+    out = {}
+    for tag, (T, sfreq, fh, seg) in {
+        "a": (10000, 1000, 3, 1000), "b": (10000, 1000, 10, 1000), "c": (3000, 1000, 200, 1000),
+        "d": (12000, 1111.111, 10, 1000), "e": (9000, 2000, 7.5, 500),
+    }.items():
+        data = np.zeros((1, T))
+        gen = nm.stream.generator.RawDataGenerator(data, sfreq, fh, seg)
+        starts, lens, times = [], [], []
+        base = data.ctypes.data
+        for ts, w in gen:
+            starts.append((w.ctypes.data - base) // 8)
+            lens.append(w.shape[1])
+            times.append(float(np.ceil(ts[-1] * 1000 + 1)))
+        out[f"{tag}_params"] = np.array([T, sfreq, fh, seg], dtype=np.float64)
+        out[f"{tag}_starts"] = np.array(starts)
+        out[f"{tag}_lens"] = np.array(lens)
+        out[f"{tag}_times"] = np.array(times)
+    np.savez_compressed(HERE / "schedule.npz", **out)
+    print("schedule", {k: len(v) for k, v in out.items() if k.endswith("starts")})
+
+
+def case_notch():
+    """NotchFilter.process = reference glue over the RESTATED _overlap_add_filter (unpinned)."""
+    out = {}
+    for sfreq in (1000, 2000):
+        nf = nm.processing.NotchFilter(sfreq, line_noise=50)
+        x = synth(2, sfreq, sfreq, 18)
+        out[f"taps_{sfreq}"] = nf.filter_bank
+        out[f"x_{sfreq}"] = x
+        out[f"y_{sfreq}"] = nf.process(x)
+    np.savez_compressed(HERE / "notch_unpinned.npz", **out)
+    print("notch", [k for k in out])
+
+
+if __name__ == "__main__":
+    case_schedule()
+    case_feat_1k()
+    case_feat_2k()
+    case_special_rows()
+    case_bursts_sequence()
+    case_sharpwave_tests()
+    case_pipeline()
+    case_nan_and_channels()
+    case_notch()
