@@ -1,0 +1,207 @@
+/*
+ * nmx.h -- C ABI of libnmx.so, the MI355X (gfx950) engine for py_neuromodulation's per-hop
+ * hot path  nm.Stream -> DataProcessor.process -> filter/ -> features/.
+ *
+ * The reference is pure Python and has NO FFI for this path; the plugin seam it offers is
+ *   NMFeature.__init__(settings, ch_names, sfreq) / calc_feature(data[C, W]) -> dict
+ *       (py_neuromodulation/utils/types.py:59-77)
+ *   NMPreprocessor.process(data[C, W]) -> data        (utils/types.py:80-81)
+ *   DataProcessor.process(data[C_all, W]) -> dict     (stream/data_processor.py:238-311)
+ * so the entry points below are what a ctypes binding inside those three call shapes needs
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative NMX_E_* code; nmx_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *   - the caller owns every buffer it passes in; the plan owns device scratch, FIR tap
+ *     spectra, FFT twiddles and the burst state; nmx_plan_destroy frees them.
+ *   - one plan = one logical stream on one GPU, not re-entrant (the reference calls
+ *     process() from a single thread, stream/stream.py:280-296); distinct plans are
+ *     independent (one per GPU for channel sharding).
+ *   - there is NO CPU fallback: without a HIP device nmx_plan_create fails with
+ *     NMX_E_NODEVICE.
+ */
+#ifndef NMX_H
+#define NMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMX_ABI_VERSION 1
+
+/* error codes */
+#define NMX_OK 0
+#define NMX_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define NMX_E_NODEVICE (-2)  /* no HIP device (the engine has no CPU path) */
+#define NMX_E_HIP (-3)       /* a HIP runtime call failed */
+#define NMX_E_NOMEM (-4)
+
+/* feature bits of nmx_plan_desc.features; order = FeatureSelector field order
+ * (stream/settings.py:41-55), which is the reference's execution and column order */
+#define NMX_F_HJORTH (1u << 0)     /* features/hjorth_raw.py:18-42   */
+#define NMX_F_RAW (1u << 1)        /* features/hjorth_raw.py:45-57   */
+#define NMX_F_BANDPOWER (1u << 2)  /* features/bandpower.py:98-207   */
+#define NMX_F_STFT (1u << 3)       /* features/oscillatory.py:185-250 */
+#define NMX_F_FFT (1u << 4)        /* features/oscillatory.py:58-119  */
+#define NMX_F_WELCH (1u << 5)      /* features/oscillatory.py:122-182 */
+#define NMX_F_SHARPWAVE (1u << 6)  /* features/sharpwaves.py:100-465  */
+#define NMX_F_BURSTS (1u << 7)     /* features/bursts.py:60-298       */
+#define NMX_F_LINELENGTH (1u << 8) /* features/linelength.py:11-21    */
+
+/* estimator bits (oscillatory: mean/median/std/max, features/oscillatory.py:29-34) */
+#define NMX_EST_MEAN 1u
+#define NMX_EST_MEDIAN 2u
+#define NMX_EST_STD 4u
+#define NMX_EST_MAX 8u
+
+/* sharp-wave per-trough quantities, SharpwaveFeatures field order (sharpwaves.py:43-56) */
+enum {
+  NMX_SW_PEAK_LEFT = 0, NMX_SW_PEAK_RIGHT, NMX_SW_NUM_PEAKS, NMX_SW_TROUGH, NMX_SW_WIDTH,
+  NMX_SW_PROMINENCE, NMX_SW_INTERVAL, NMX_SW_DECAY_TIME, NMX_SW_RISE_TIME, NMX_SW_SHARPNESS,
+  NMX_SW_RISE_STEEPNESS, NMX_SW_DECAY_STEEPNESS, NMX_SW_SLOPE_RATIO, NMX_SW_NFEAT
+};
+/* sharp-wave estimators, ESTIMATOR_DICT order (sharpwaves.py:26-32) */
+enum { NMX_SWE_MEAN = 0, NMX_SWE_MEDIAN, NMX_SWE_MAX, NMX_SWE_MIN, NMX_SWE_VAR, NMX_SWE_N };
+
+#define NMX_MAX_BANDS 16
+#define NMX_MAX_FILTERS 24
+#define NMX_MAX_SW_COMBOS 48
+
+/* Where one feature family writes inside an output row of n_outputs floats:
+ *   column = base + ch * ch_stride + a * a_stride + b * b_stride
+ * (a, b) are family specific, see each family below.  This reproduces the reference's key
+ * order without any host-side permutation. */
+typedef struct {
+  int32_t base, ch_stride, a_stride, b_stride;
+} nmx_cols;
+
+/* oscillatory family (FFT / Welch / STFT): band b uses bins [bin_lo[b], bin_hi[b]) of the
+ * family's frequency grid (the host resolves [lo,hi) vs [lo,hi] -- oscillatory.py:81,206).
+ * cols: a = band, b = estimator slot (enabled estimators in mean,median,std,max order).
+ * psd_cols (return_spectrum): a = frequency bin, used when return_spectrum != 0. */
+typedef struct {
+  int32_t n;               /* FFT: samples N = floor(ms/1000*sfreq); Welch: nperseg; STFT: nperseg */
+  int32_t log_transform;
+  uint32_t estimators;     /* NMX_EST_* */
+  int32_t return_spectrum;
+  int32_t bin_lo[NMX_MAX_BANDS], bin_hi[NMX_MAX_BANDS];
+  nmx_cols cols, psd_cols;
+} nmx_osc_desc;
+
+/* One FIR filter of the per-window bank (band-pass bank of BandPower/Bursts,
+ * filter/mne_filter.py:35-128, and the sharp-wave pre-filters, sharpwaves.py:121-154).
+ * Taps are DESIGNED ON THE HOST and passed in (odd length, float64). */
+typedef struct {
+  const double* taps;
+  int32_t n_taps;
+  /* BandPower epilogue (bandpower.py:130-207): tail length in samples, 0 = not used.
+   * cols: a = feature slot among enabled (activity, mobility, complexity). */
+  int32_t bp_seglen;
+  int32_t bp_band_index;    /* band position for the output column */
+  /* Bursts epilogue: index among burst bands or -1 */
+  int32_t burst_index;
+  /* Sharp-wave epilogue: index among sharp-wave filters or -1 */
+  int32_t sw_index;
+} nmx_filter_desc;
+
+typedef struct {
+  int32_t abi_version;      /* NMX_ABI_VERSION */
+  int32_t device;           /* HIP device ordinal */
+  int32_t n_channels;       /* C: channels the features are computed for */
+  int32_t window;           /* W: samples per window (int(seg_ms/1000*sfreq)) */
+  double sfreq;
+  double feat_hz;           /* sampling_rate_features_hz (burst ring: samples_overlap) */
+  uint32_t features;        /* NMX_F_* */
+  int32_t n_outputs;        /* floats per output row (all enabled families) */
+  int32_t n_bands;
+
+  nmx_cols hjorth_cols;     /* a = 0..2 (Activity, Mobility, Complexity) */
+  nmx_cols raw_cols;
+  nmx_cols linelength_cols;
+  nmx_osc_desc fft, welch, stft;
+
+  /* FIR bank */
+  int32_t n_filters;
+  nmx_filter_desc filters[NMX_MAX_FILTERS];
+  uint32_t bp_features;     /* bit0 activity, bit1 mobility, bit2 complexity */
+  int32_t bp_log_transform;
+  nmx_cols bp_cols;         /* a = band, b = feature slot */
+
+  /* Bursts (features/bursts.py): cols a = burst band, b = output slot in the order
+   * duration_mean, duration_max, amplitude_mean, amplitude_max, burst_rate_per_s, in_burst
+   * restricted to the enabled groups (burst_out_mask bit i = slot i present). */
+  int32_t n_burst_bands;
+  double burst_threshold;   /* percentile 0..100 */
+  double burst_time_duration_s;
+  uint32_t burst_out_mask;
+  nmx_cols burst_cols;
+
+  /* Sharp waves (features/sharpwaves.py) */
+  int32_t n_sw_filters;
+  int32_t sw_n_combos;                     /* (feature, estimator) pairs, reference order */
+  int32_t sw_combo_feature[NMX_MAX_SW_COMBOS];
+  int32_t sw_combo_estimator[NMX_MAX_SW_COMBOS];
+  double sw_distance_peaks, sw_distance_troughs;  /* samples (ms passed as samples, :339-344) */
+  int32_t sw_estimate_peaks, sw_estimate_troughs; /* detect_peaks/troughs.estimate */
+  int32_t sw_between;                      /* apply_estimator_between_peaks_and_troughs */
+  nmx_cols sw_cols;        /* a = filter, b = combo (x2 + polarity when !sw_between) */
+  nmx_cols sw_numpeaks_cols; /* a = filter; used when num_peaks is enabled and sw_between */
+
+  /* Pre-processing on the continuous stream / per window */
+  const double* notch_taps; /* NULL = no notch; filter/notch_filter.py:9-93 */
+  int32_t n_notch_taps;
+  const double* ref_matrix; /* NULL = identity; [C][C_in] row-major, processing/rereference.py:52-100 */
+  int32_t n_channels_in;    /* rows of the incoming data when ref_matrix is given */
+} nmx_plan_desc;
+
+typedef struct nmx_plan nmx_plan;
+
+int nmx_abi_version(void);
+int nmx_device_count(void);                 /* number of HIP devices (0 when none) */
+const char* nmx_last_error(void);           /* thread-local message of the last failure */
+
+int nmx_plan_create(const nmx_plan_desc* desc, nmx_plan** out);
+int nmx_plan_destroy(nmx_plan* plan);
+int nmx_plan_n_outputs(const nmx_plan* plan, int64_t* n_outputs);
+
+/* Batch of windows over a continuous recording x[C_in][T] (row-major, channel stride ldx),
+ * window i = samples [starts[i], starts[i] + W)  (stream/generator.py:41-53).
+ *   memspace 0: x / out are host pointers (copied through the plan's staging buffers)
+ *   memspace 1: x / out / nan_mask are device pointers on the plan's device
+ * out[n_windows][n_outputs] float32; nan_mask[n_windows][C_in] uint8 (may be NULL):
+ * 1 where the raw window of that channel held a NaN (stream/data_processor.py:253).
+ * hip_stream: hipStream_t to launch on (NULL = the plan's own stream).  The call is
+ * asynchronous for memspace 1 and synchronous for memspace 0.
+ * Bursts state (ring of envelopes) advances by n_windows. */
+int nmx_process_batch(nmx_plan* plan, const float* x, int64_t ldx, int64_t n_samples,
+                      const int64_t* starts, int64_t n_windows, float* out, uint8_t* nan_mask,
+                      int memspace, void* hip_stream);
+
+/* One window, the reference's call shape: x[C_in][W] float64 host -> out[n_outputs] host. */
+int nmx_process_window(nmx_plan* plan, const double* x, int64_t ldx, float* out,
+                       uint8_t* nan_mask);
+
+/* Pre-processing only (NMPreprocessor.process): x[C_in][W] float64 host -> y[C][W] float64. */
+int nmx_preprocess_window(nmx_plan* plan, const double* x, int64_t ldx, double* y, int64_t ldy);
+
+/* FIR bank only (MNEFilter.filter_data): x[C][W] -> y[C][n_filters][W] float64 host. */
+int nmx_filter_window(nmx_plan* plan, const double* x, int64_t ldx, double* y);
+
+/* Burst ring state (the only state carried across windows, features/bursts.py:105-115). */
+int nmx_state_reset(nmx_plan* plan);
+int nmx_state_size(const nmx_plan* plan, int64_t* n_bytes);
+int nmx_state_export(nmx_plan* plan, void* dst, int64_t n_bytes);
+int nmx_state_import(nmx_plan* plan, const void* src, int64_t n_bytes);
+
+/* Timing of the last nmx_process_batch, measured with HIP events on the launch stream:
+ * which = 0 whole batch, 1 pre-processing, 2 time/oscillatory kernel, 3 FIR-bank kernel,
+ * 4 bursts kernels, 5 sharp-wave kernel.  Blocks until the events have completed. */
+int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMX_H */

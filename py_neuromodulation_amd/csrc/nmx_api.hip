@@ -1,0 +1,164 @@
+// nmx_api.hip -- libnmx.so: HIP (gfx950) backend + C ABI.  Build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC nmx_api.hip -o ../libnmx.so
+// There is no CPU path in this library: every entry point that computes launches kernels.
+#include <hip/hip_runtime.h>
+
+#include "nmx_k_bank.h"
+#include "nmx_k_bursts.h"
+#include "nmx_k_prep.h"
+#include "nmx_k_sharpwave.h"
+#include "nmx_k_timeosc.h"
+
+#include <string>
+
+// ---- kernels: one workgroup per item, dynamic LDS carved by the host plan -----------------
+extern __shared__ __attribute__((aligned(16))) float nmx_smem[];
+
+__global__ void __launch_bounds__(256) nmx_kern_timeosc(const NmxTimeOscArgs A) {
+  const int item = blockIdx.x;
+  nmx_time_osc_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
+}
+__global__ void __launch_bounds__(256) nmx_kern_bank(const NmxBankArgs A) {
+  const int item = blockIdx.x;
+  nmx_bank_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
+}
+__global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs A) {
+  const int item = blockIdx.x;
+  nmx_burst_thr_item(A, item / A.n_bands, item % A.n_bands, nmx_smem);
+}
+__global__ void __launch_bounds__(64) nmx_kern_burst_stat(const NmxBurstStatArgs A) {
+  const int item = blockIdx.x;
+  const int bi = item % A.n_bands, r = item / A.n_bands;
+  nmx_burst_stat_item(A, r / A.n_channels, r % A.n_channels, bi, nmx_smem);
+}
+__global__ void __launch_bounds__(64) nmx_kern_sharp(const NmxSharpArgs A) {
+  const int item = blockIdx.x;
+  const int fi = item % A.n_filters, r = item / A.n_filters;
+  nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem);
+}
+__global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
+  nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
+}
+__global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
+  const int item = blockIdx.x;
+  nmx_nanmask_item(A, item / A.C_in, item % A.C_in, nmx_smem);
+}
+
+// ---- backend ------------------------------------------------------------------------------
+typedef hipStream_t be_stream_t;
+struct be_timer_t {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool used = false;
+};
+
+static thread_local std::string g_be_err;
+static int g_be_rc = 0;
+static int nmx_fail(int code, const std::string& msg);
+static int be_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  return nmx_fail(NMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define BE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess && !g_be_rc) g_be_rc = be_hip(e_, #call); } while (0)
+
+static int be_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+static int be_set_device(int dev) { return be_hip(hipSetDevice(dev), "hipSetDevice"); }
+static void* be_alloc(size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n) != hipSuccess) return nullptr;
+  return p;
+}
+static void be_free(void* p) { (void)hipFree(p); }
+static void be_h2d_sync(void* d, const void* s, size_t n) { BE_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); }
+static void be_d2h_sync(void* d, const void* s, size_t n) { BE_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); }
+static void be_memset_sync(void* d, int v, size_t n) { BE_TRY(hipMemset(d, v, n)); }
+static void be_h2d_async(void* d, const void* s, size_t n, be_stream_t st) {
+  BE_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st));
+}
+static void be_d2h_async(void* d, const void* s, size_t n, be_stream_t st) {
+  BE_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st));
+}
+static void be_h2d_2d_async(void* d, size_t dpitch, const void* s, size_t spitch, size_t width,
+                            size_t height, be_stream_t st) {
+  BE_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, st));
+}
+static void be_memset_async(void* d, int v, size_t n, be_stream_t st) { BE_TRY(hipMemsetAsync(d, v, n, st)); }
+static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
+static be_stream_t be_stream_create() {
+  hipStream_t s = nullptr;
+  BE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+static void be_stream_destroy(be_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+static void be_timer_create(be_timer_t& t) {
+  BE_TRY(hipEventCreate(&t.a));
+  BE_TRY(hipEventCreate(&t.b));
+}
+static void be_timer_destroy(be_timer_t& t) {
+  if (t.a) (void)hipEventDestroy(t.a);
+  if (t.b) (void)hipEventDestroy(t.b);
+}
+static void be_timer_start(be_timer_t& t, be_stream_t s) { BE_TRY(hipEventRecord(t.a, s)); t.used = false; }
+static void be_timer_stop(be_timer_t& t, be_stream_t s) { BE_TRY(hipEventRecord(t.b, s)); t.used = true; }
+static float be_timer_elapsed(be_timer_t& t) {
+  if (!t.used) return 0.f;
+  float ms = 0.f;
+  if (hipEventSynchronize(t.b) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) return -1.f;
+  return ms;
+}
+static int be_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return be_hip(e, "kernel launch");
+  int rc = g_be_rc;
+  g_be_rc = 0;
+  return rc;
+}
+
+template <typename K>
+static void be_allow_lds(K kern) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+static void be_init_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  be_allow_lds(nmx_kern_timeosc);
+  be_allow_lds(nmx_kern_bank);
+  be_allow_lds(nmx_kern_burst_thr);
+  be_allow_lds(nmx_kern_burst_stat);
+  be_allow_lds(nmx_kern_sharp);
+}
+
+static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_timeosc, dim3(n_items), dim3(nt), lds, s, A);
+}
+static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_bank, dim3(n_items), dim3(nt), lds, s, A);
+}
+static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_burst_thr, dim3(n_items), dim3(nt), lds, s, A);
+}
+static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_burst_stat, dim3(n_items), dim3(64), lds, s, A);
+}
+static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_sharp, dim3(n_items), dim3(64), lds, s, A);
+}
+static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
+  dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
+  hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+}
+static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);
+}
+
+#include "nmx_engine.inc"

@@ -1,0 +1,111 @@
+// nmx_common.h -- shared host/device definitions of the nmx engine (gfx950 / CDNA4).
+//
+// Device code is written in "phase" style: every cooperative step is a loop
+//     for (int j = NMX_TID; j < m; j += NMX_NT) { ... }   followed by NMX_SYNC()
+// plus block reductions.  One workgroup processes one item ((channel, window) or
+// (channel, band)); all staging happens in LDS.  Compiling with -DNMX_HOST_EMU maps
+// NMX_TID/NMX_NT to 0/1 and NMX_SYNC to a no-op so the SAME source runs single-threaded
+// under g++; that build exists only for tests/ (kernel-logic checks in a container that
+// has no GPU) and is never part of libnmx.so -- the product has no CPU path.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#ifdef NMX_HOST_EMU
+struct float2 {
+  float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+#define NMX_DEV static inline
+#define NMX_TID 0
+#define NMX_NT 1
+#define NMX_SYNC() ((void)0)
+#define NMX_RESTRICT
+#else
+#include <hip/hip_runtime.h>
+#define NMX_DEV __device__ __forceinline__
+#define NMX_TID ((int)threadIdx.x)
+#define NMX_NT ((int)blockDim.x)
+#define NMX_SYNC() __syncthreads()
+#define NMX_RESTRICT __restrict__
+#endif
+
+#define NMX_MAX_STAGES 12
+#define NMX_MAX_BANDS_DEV 16
+#define NMX_MAX_FILTERS_DEV 24
+#define NMX_MAX_SW_COMBOS_DEV 48
+
+// ---- FFT plan (complex length n, mixed radix Stockham) --------------------------------
+struct NmxFftStage {
+  int radix;       // 2, 3, 4, 5 or any prime (generic O(p^2) butterfly)
+  int ns;          // product of the radices of the previous stages
+  int m;           // n / radix  (butterflies in this stage)
+  unsigned magic;  // floor(2^32 / ns) + 1 : q = umulhi(j, magic) == j / ns for j < 2^16
+  int tw_step;     // n / (ns * radix)
+};
+
+struct NmxFft {
+  int n;
+  int nstages;
+  NmxFftStage st[NMX_MAX_STAGES];
+  const float2* tw;   // [n]      exp(-2 pi i k / n)
+  const float2* twr;  // [n + 1]  exp(-2 pi i k / (2 n)), real <-> half-length complex split
+};
+
+struct NmxCols {
+  int base, ch_stride, a_stride, b_stride;
+};
+
+// One oscillatory family (FFT / Welch / STFT) as the kernel sees it
+struct NmxOsc {
+  int enabled;
+  int n;         // real transform length (FFT: N, Welch/STFT: nperseg)
+  int nfreq;     // n / 2 + 1
+  int nseg;      // segments (FFT: 1)
+  int step;      // hop between segments
+  int half;      // STFT: even-extension length nperseg / 2
+  int complex_full;  // 1: n odd -> full-length complex transform of (x, 0)
+  int log_transform;
+  unsigned estimators;
+  int n_est;
+  int return_spectrum;
+  float scale;   // Welch: 1 / (fs * sum w^2); STFT: 1 / sum w
+  int bin_lo[NMX_MAX_BANDS_DEV], bin_hi[NMX_MAX_BANDS_DEV];
+  NmxCols cols, psd_cols;
+  NmxFft fft;    // complex length n/2 (or n when complex_full)
+  const float* win;  // [n] window (Welch: hann, STFT: hamming), NULL for FFT
+};
+
+struct NmxTimeOscArgs {
+  const float* x;        // input samples
+  long long ch_stride;   // elements between channels
+  long long win_stride;  // elements between windows (0 for a strided stream view)
+  const long long* starts;  // per-window start sample or NULL
+  float* out;            // [n_windows][n_outputs]
+  int n_outputs;
+  int n_channels;
+  int W;
+  int n_bands;
+  int clean_on_load;     // apply nan_to_num while loading
+  unsigned features;     // NMX_F_* (HJORTH, RAW, LINELENGTH handled here)
+  NmxCols hjorth_cols, raw_cols, ll_cols;
+  NmxOsc fft, welch, stft;
+  // LDS carve (float offsets)
+  int off_x, off_a, off_b, off_spec, off_red, lds_floats;
+};
+
+#define NMXD_F_HJORTH (1u << 0)
+#define NMXD_F_RAW (1u << 1)
+#define NMXD_F_BANDPOWER (1u << 2)
+#define NMXD_F_STFT (1u << 3)
+#define NMXD_F_FFT (1u << 4)
+#define NMXD_F_WELCH (1u << 5)
+#define NMXD_F_SHARPWAVE (1u << 6)
+#define NMXD_F_BURSTS (1u << 7)
+#define NMXD_F_LINELENGTH (1u << 8)
+
+#define NMXD_EST_MEAN 1u
+#define NMXD_EST_MEDIAN 2u
+#define NMXD_EST_STD 4u
+#define NMXD_EST_MAX 8u

@@ -1,0 +1,257 @@
+// nmx_device.h -- device building blocks: block reductions, LDS Stockham FFT (mixed radix
+// 2/3/4/5 + generic prime), real<->complex split, estimator helpers.
+// Hardware mapping (gfx950): one workgroup = one item, data staged in LDS (160 KiB/CU),
+// 64-lane wave reductions through __shfl_xor (DPP / ds_swizzle), cross-wave via LDS.
+#pragma once
+
+#include "nmx_common.h"
+
+#ifdef NMX_HOST_EMU
+static inline unsigned nmx_umulhi(unsigned a, unsigned b) {
+  return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
+}
+#else
+NMX_DEV unsigned nmx_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
+#endif
+
+// ---------------------------------------------------------------------------------------
+// block reductions (every thread gets the result).  `red` = LDS scratch of >= 32 floats.
+// ---------------------------------------------------------------------------------------
+#ifdef NMX_HOST_EMU
+NMX_DEV float nmx_block_sum(float v, float*) { return v; }
+NMX_DEV float nmx_block_max(float v, float*) { return v; }
+NMX_DEV float nmx_block_min(float v, float*) { return v; }
+NMX_DEV int nmx_block_sum_i(int v, float*) { return v; }
+NMX_DEV int nmx_block_or(int v, float*) { return v; }
+#else
+template <typename T, typename Op>
+NMX_DEV T nmx_block_reduce(T v, float* red, Op op) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+  const int nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) ((T*)red)[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T t = ((T*)red)[0];
+  for (int i = 1; i < nw; ++i) t = op(t, ((T*)red)[i]);
+  return t;
+}
+NMX_DEV float nmx_block_sum(float v, float* red) {
+  return nmx_block_reduce(v, red, [](float a, float b) { return a + b; });
+}
+// NaN-propagating max/min (np.max semantics): fmaxf would drop NaNs
+NMX_DEV float nmx_block_max(float v, float* red) {
+  return nmx_block_reduce(v, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); });
+}
+NMX_DEV float nmx_block_min(float v, float* red) {
+  return nmx_block_reduce(v, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); });
+}
+NMX_DEV int nmx_block_sum_i(int v, float* red) {
+  return nmx_block_reduce(v, red, [](int a, int b) { return a + b; });
+}
+NMX_DEV int nmx_block_or(int v, float* red) {
+  return nmx_block_reduce(v, red, [](int a, int b) { return a | b; });
+}
+#endif
+
+NMX_DEV float nmx_nanmax(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+NMX_DEV float nmx_nanmin(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+
+// np.nan_to_num for float32 data: NaN -> 0, +-inf -> +-FLT_MAX
+NMX_DEV float nmx_clean(float v) {
+  if (v != v) return 0.0f;
+  if (v > 3.402823466e+38f) return 3.402823466e+38f;
+  if (v < -3.402823466e+38f) return -3.402823466e+38f;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// complex helpers
+// ---------------------------------------------------------------------------------------
+NMX_DEV float2 nmx_cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+NMX_DEV float2 nmx_cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+NMX_DEV float2 nmx_csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <int DIR>
+NMX_DEV float2 nmx_tw(const float2* NMX_RESTRICT tw, int idx) {
+  float2 t = tw[idx];
+  if (DIR > 0) t.y = -t.y;
+  return t;
+}
+// multiply by DIR * i  (DIR = -1 forward: (x, y) -> (y, -x); DIR = +1: (x, y) -> (-y, x))
+template <int DIR>
+NMX_DEV float2 nmx_mul_i(float2 a) {
+  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// Stockham autosort FFT in LDS.  DIR = -1 forward, +1 inverse (unnormalised).
+// Stage (radix R, Ns = product of earlier radices): butterfly j reads in[j + r * n/R],
+// multiplies by exp(DIR 2 pi i r k / (Ns R)), k = j % Ns, and writes
+// out[(j / Ns) * Ns * R + k + r * Ns].  Reads are unit-stride across lanes.
+// Returns the buffer that holds the result (a or b); `in0` is never written.
+// ---------------------------------------------------------------------------------------
+template <int DIR>
+NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b) {
+  const float2* in = in0;
+  float2* out = a;
+  const float2* NMX_RESTRICT tw = p.tw;
+  for (int s = 0; s < p.nstages; ++s) {
+    const int R = p.st[s].radix, m = p.st[s].m, ns = p.st[s].ns, tstep = p.st[s].tw_step;
+    const unsigned magic = p.st[s].magic;
+    for (int j = NMX_TID; j < m; j += NMX_NT) {
+      const int q = (ns == 1) ? j : (int)nmx_umulhi((unsigned)j, magic);
+      const int k = j - q * ns;
+      const int o = q * ns * R + k;
+      const int tb = k * tstep;
+      if (R == 4) {
+        float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m];
+        if (ns > 1) {
+          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
+          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
+          a3 = nmx_cmul(a3, nmx_tw<DIR>(tw, 3 * tb));
+        }
+        const float2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+        const float2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
+        out[o] = nmx_cadd(t0, t2);
+        out[o + ns] = nmx_cadd(t1, t3);
+        out[o + 2 * ns] = nmx_csub(t0, t2);
+        out[o + 3 * ns] = nmx_csub(t1, t3);
+      } else if (R == 2) {
+        float2 a0 = in[j], a1 = in[j + m];
+        if (ns > 1) a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
+        out[o] = nmx_cadd(a0, a1);
+        out[o + ns] = nmx_csub(a0, a1);
+      } else if (R == 5) {
+        float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m], a4 = in[j + 4 * m];
+        if (ns > 1) {
+          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
+          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
+          a3 = nmx_cmul(a3, nmx_tw<DIR>(tw, 3 * tb));
+          a4 = nmx_cmul(a4, nmx_tw<DIR>(tw, 4 * tb));
+        }
+        const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;
+        const float s1 = DIR * 0.95105651629515353f, s2 = DIR * 0.58778525229247314f;
+        const float2 t1 = nmx_cadd(a1, a4), t2 = nmx_cadd(a2, a3);
+        const float2 d1 = nmx_csub(a1, a4), d2 = nmx_csub(a2, a3);
+        const float2 m1 = make_float2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+        const float2 m2 = make_float2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+        // i * n1, i * n2 with n1 = s1 d1 + s2 d2, n2 = s2 d1 - s1 d2
+        const float2 n1 = make_float2(-(s1 * d1.y + s2 * d2.y), s1 * d1.x + s2 * d2.x);
+        const float2 n2 = make_float2(-(s2 * d1.y - s1 * d2.y), s2 * d1.x - s1 * d2.x);
+        out[o] = make_float2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+        out[o + ns] = nmx_cadd(m1, n1);
+        out[o + 2 * ns] = nmx_cadd(m2, n2);
+        out[o + 3 * ns] = nmx_csub(m2, n2);
+        out[o + 4 * ns] = nmx_csub(m1, n1);
+      } else if (R == 3) {
+        float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m];
+        if (ns > 1) {
+          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
+          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
+        }
+        const float s = DIR * 0.86602540378443865f;
+        const float2 t = nmx_cadd(a1, a2), d = nmx_csub(a1, a2);
+        const float2 u = make_float2(a0.x - 0.5f * t.x, a0.y - 0.5f * t.y);
+        const float2 v = make_float2(-s * d.y, s * d.x);
+        out[o] = nmx_cadd(a0, t);
+        out[o + ns] = nmx_cadd(u, v);
+        out[o + 2 * ns] = nmx_csub(u, v);
+      } else {
+        // generic prime radix: O(R^2), inputs re-read from LDS (no register array)
+        const int pstep = p.n / R;
+        for (int qq = 0; qq < R; ++qq) {
+          float2 acc = in[j];
+          int e = 0;  // (qq * r) mod R
+          for (int r = 1; r < R; ++r) {
+            e += qq;
+            if (e >= R) e -= R;
+            float2 v = in[j + r * m];
+            if (ns > 1) v = nmx_cmul(v, nmx_tw<DIR>(tw, r * tb));
+            acc = nmx_cadd(acc, nmx_cmul(v, nmx_tw<DIR>(tw, e * pstep)));
+          }
+          out[o + qq * ns] = acc;
+        }
+      }
+    }
+    NMX_SYNC();
+    in = out;
+    out = (out == a) ? b : a;
+  }
+  return (float2*)in;
+}
+
+// Forward real FFT of even length N = 2 n from the half-length transform Z of
+// z[k] = x[2k] + i x[2k+1]:  X[k] = E[k] + exp(-2 pi i k / N) O[k],  k = 0..n.
+NMX_DEV float2 nmx_rfft_bin(const float2* Z, const float2* NMX_RESTRICT twr, int n, int k) {
+  const float2 zk = Z[k == n ? 0 : k];
+  const float2 zc = Z[k == 0 ? 0 : n - k];
+  const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+  // O = -i (zk - conj(zc)) / 2
+  const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+  const float2 o = make_float2(d.y, -d.x);
+  const float2 w = twr[k];
+  return nmx_cadd(e, nmx_cmul(w, o));
+}
+
+// Inverse: half-length spectrum Z'[k] (k = 0..n-1) whose unnormalised inverse transform is
+// N * (x[2j] + i x[2j+1]) given the Hermitian half X[0..n]:
+//   Z'[k] = (X[k] + conj(X[n-k])) + i exp(+2 pi i k / N) (X[k] - conj(X[n-k]))
+NMX_DEV float2 nmx_irfft_pre(float2 xk, float2 xnk, float2 twr_k) {
+  const float2 s = make_float2(xk.x + xnk.x, xk.y - xnk.y);
+  const float2 d = make_float2(xk.x - xnk.x, xk.y + xnk.y);
+  const float2 w = make_float2(twr_k.x, -twr_k.y);  // conj -> exp(+...)
+  const float2 wd = nmx_cmul(w, d);
+  return make_float2(s.x - wd.y, s.y + wd.x);  // s + i * wd
+}
+
+// ---------------------------------------------------------------------------------------
+// estimators over v[0..cnt) in LDS (features/oscillatory.py:29-34: nanmean, nanmedian,
+// nanstd (ddof 0), nanmax; the values are never NaN here, -inf follows IEEE arithmetic)
+// ---------------------------------------------------------------------------------------
+NMX_DEV float nmx_est_mean(const float* v, int cnt, float* red) {
+  float s = 0.f;
+  for (int i = NMX_TID; i < cnt; i += NMX_NT) s += v[i];
+  return nmx_block_sum(s, red) / (float)cnt;
+}
+NMX_DEV float nmx_est_std(const float* v, int cnt, float mean, float* red) {
+  float s = 0.f;
+  for (int i = NMX_TID; i < cnt; i += NMX_NT) {
+    const float d = v[i] - mean;
+    s += d * d;
+  }
+  return sqrtf(nmx_block_sum(s, red) / (float)cnt);
+}
+NMX_DEV float nmx_est_max(const float* v, int cnt, float* red) {
+  float s = -INFINITY;
+  for (int i = NMX_TID; i < cnt; i += NMX_NT) s = nmx_nanmax(s, v[i]);
+  return nmx_block_max(s, red);
+}
+NMX_DEV float nmx_est_min(const float* v, int cnt, float* red) {
+  float s = INFINITY;
+  for (int i = NMX_TID; i < cnt; i += NMX_NT) s = nmx_nanmin(s, v[i]);
+  return nmx_block_min(s, red);
+}
+// element of rank r (0-based) by counting; O(cnt^2 / threads)
+NMX_DEV float nmx_rank_select(const float* v, int cnt, int r, float* red) {
+  float found = -INFINITY;
+  for (int i = NMX_TID; i < cnt; i += NMX_NT) {
+    const float vi = v[i];
+    int less = 0, eq = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const float vj = v[j];
+      less += (vj < vi);
+      eq += (vj == vi);
+    }
+    if (less <= r && r < less + eq) found = vi;
+  }
+  return nmx_block_max(found, red);
+}
+NMX_DEV float nmx_est_median(const float* v, int cnt, float* red) {
+  if (cnt & 1) return nmx_rank_select(v, cnt, cnt >> 1, red);
+  const float a = nmx_rank_select(v, cnt, (cnt >> 1) - 1, red);
+  const float b = nmx_rank_select(v, cnt, cnt >> 1, red);
+  return 0.5f * (a + b);
+}

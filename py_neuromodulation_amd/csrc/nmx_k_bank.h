@@ -1,0 +1,189 @@
+// nmx_k_bank.h -- kernel B: per-(window, channel) FIR bank by FFT convolution in LDS.
+//
+// One forward real FFT of the (zero-padded or odd-reflected) window is shared by every
+// filter; per filter: multiply by the REAL spectrum of the centred taps (zero-phase,
+// symmetric, odd length -> real even spectrum, so no complex multiply and half the table),
+// inverse real FFT, then the consumers run on the filtered series while it is still in LDS:
+//   * BandPower tail statistics              features/bandpower.py:165-207
+//   * Hilbert envelope -> HBM (Bursts)        features/bursts.py:153
+//   * filtered series -> HBM (sharp waves, notch)  features/sharpwaves.py:242-251,
+//                                                 filter/notch_filter.py:78-93
+// "same" semantics of filter/mne_filter.py:110-126: y[n] = sum_k h[k] x[n + (L-1)/2 - k],
+// x = 0 outside the window.  With circularly centred taps the wanted samples are outputs
+// [0, W) of a length-M circular convolution, alias-free when M >= W + (L-1)/2.
+// Notch (MNE _overlap_add_filter, phase="zero", pad="reflect_limited"): the same on the
+// odd-reflected window; only (L-1)/2 reflected samples per side can reach the kept outputs,
+// so the staged signal is W + (L-1) long and outputs are read at offset (L-1)/2.
+//
+// The intermediate (C, B, W) tensor of the reference never exists in HBM.
+#pragma once
+
+#include "nmx_k_timeosc.h"
+
+struct NmxFilterDev {
+  const float* H;  // [M/2 + 1] real spectrum of centred taps, pre-scaled by 1/M
+  int half;        // (L - 1) / 2
+  int bp_seglen;   // 0 = no BandPower epilogue
+  int bp_band;
+  int burst_index;  // -1 = none
+  int sw_index;     // -1 = none
+  int store_raw;    // notch: write y to yout[w][c][W]
+};
+
+struct NmxBankArgs {
+  const float* x;
+  long long ch_stride, win_stride;
+  const long long* starts;
+  float* out;
+  int n_outputs, n_channels, W, clean_on_load;
+  int M;            // circular convolution length (even)
+  int pad_mode;     // 0 zero-pad ("same"), 1 odd reflection (notch)
+  int n_edge;       // reflect_limited: samples available for reflection (min(L, W) - 1)
+  int pad_half;     // pad_mode 1: (L - 1) / 2 staged on each side
+  NmxFft fft;       // complex length M / 2
+  int n_filters;
+  NmxFilterDev f[NMX_MAX_FILTERS_DEV];
+  unsigned bp_features;  // bit0 activity, bit1 mobility, bit2 complexity
+  int bp_log;
+  NmxCols bp_cols;
+  // Hilbert envelope (Bursts)
+  int n_burst_bands;
+  float* env_out;   // [n_windows][C][n_burst_bands][W]
+  NmxFft hil_r;     // complex length W/2 (W even) or W (W odd): forward real transform
+  NmxFft hil_c;     // complex length W: inverse of the one-sided spectrum
+  int hil_full;     // W odd
+  // filtered series to HBM
+  int n_sw_filters;
+  float* sw_out;    // [n_windows][C][n_sw_filters][W]
+  float* y_out;     // notch: [n_windows][C][W]
+  // LDS carve (float offsets)
+  int off_X, off_a, off_b, off_red, lds_floats;
+};
+
+NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
+  float2* X = (float2*)(smem + A.off_X);
+  float2* bufA = (float2*)(smem + A.off_a);
+  float2* bufB = (float2*)(smem + A.off_b);
+  float* red = smem + A.off_red;
+  const int W = A.W, M = A.M, Mh = M >> 1;
+  float* out_row = A.out ? A.out + (long long)w * A.n_outputs : nullptr;
+  const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
+                     (A.starts ? A.starts[w] : 0ll);
+
+  // ---- stage the (padded) window as M/2 packed complex samples in bufB -----------------
+  if (A.pad_mode == 0) {
+    for (int i = NMX_TID; i < Mh; i += NMX_NT) {
+      const int n0 = 2 * i;
+      float v0 = n0 < W ? src[n0] : 0.f, v1 = (n0 + 1) < W ? src[n0 + 1] : 0.f;
+      if (A.clean_on_load) {
+        v0 = nmx_clean(v0);
+        v1 = nmx_clean(v1);
+      }
+      bufB[i] = make_float2(v0, v1);
+    }
+  } else {
+    float* xs = (float*)X;  // the spectrum region doubles as window staging
+    for (int i = NMX_TID; i < W; i += NMX_NT) {
+      float v = src[i];
+      if (A.clean_on_load) v = nmx_clean(v);
+      xs[i] = v;
+    }
+    NMX_SYNC();
+    const int h = A.pad_half, ne = A.n_edge;
+    const float x0 = xs[0], xl = xs[W - 1];
+    auto ext = [&](int jp) -> float {  // jp in [0, W + 2h): sample of the reflected signal
+      const int j = jp - h;
+      if (j < 0) return (-j <= ne) ? 2.f * x0 - xs[-j] : 0.f;
+      if (j < W) return xs[j];
+      const int r = j - (W - 1);
+      return (r <= ne && j < W + h) ? 2.f * xl - xs[W - 1 - r] : 0.f;
+    };
+    for (int i = NMX_TID; i < Mh; i += NMX_NT) {
+      const int n0 = 2 * i;
+      bufB[i] = make_float2(n0 < W + 2 * h ? ext(n0) : 0.f, (n0 + 1) < W + 2 * h ? ext(n0 + 1) : 0.f);
+    }
+  }
+  NMX_SYNC();
+
+  // ---- forward transform, Hermitian half X[0..M/2] kept in LDS ------------------------
+  {
+    const float2* Z = nmx_fft<-1>(A.fft, bufB, bufA, bufB);
+    for (int k = NMX_TID; k <= Mh; k += NMX_NT) X[k] = nmx_rfft_bin(Z, A.fft.twr, Mh, k);
+    NMX_SYNC();
+  }
+
+  const int yoff = (A.pad_mode == 1) ? A.pad_half : 0;
+  for (int fi = 0; fi < A.n_filters; ++fi) {
+    const NmxFilterDev& F = A.f[fi];
+    const float* NMX_RESTRICT H = F.H;
+    // Z'[k] from X[k] H[k] and X[M/2 - k] H[M/2 - k]
+    for (int k = NMX_TID; k < Mh; k += NMX_NT) {
+      const float hk = H[k], hn = H[Mh - k];
+      const float2 xk = X[k], xn = X[Mh - k];
+      bufB[k] = nmx_irfft_pre(make_float2(xk.x * hk, xk.y * hk), make_float2(xn.x * hn, xn.y * hn),
+                              A.fft.twr[k]);
+    }
+    NMX_SYNC();
+    float2* yz = nmx_fft<+1>(A.fft, bufB, bufA, bufB);
+    float2* other = (yz == bufA) ? bufB : bufA;
+    const float* y = (const float*)yz + yoff;  // y[n], n in [0, W), natural order
+
+    if (F.bp_seglen > 0) {  // ---- BandPower (bandpower.py:185-207) ----
+      const bool need_mc = (A.bp_features & 6u) != 0;
+      float act, mob, comp;
+      nmx_hjorth(y + (W - F.bp_seglen), F.bp_seglen, red, 1, need_mc, act, mob, comp);
+      if (NMX_TID == 0) {
+        int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
+        if (A.bp_features & 1u) {
+          out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act);
+          col += A.bp_cols.b_stride;
+        }
+        if (A.bp_features & 2u) {
+          out_row[col] = nmx_nan_to_num(mob);
+          col += A.bp_cols.b_stride;
+        }
+        if (A.bp_features & 4u) out_row[col] = nmx_nan_to_num(comp);
+      }
+    }
+    if (F.sw_index >= 0) {
+      float* dst = A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W;
+      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = y[i];
+    }
+    if (F.store_raw) {
+      float* dst = A.y_out + ((long long)w * A.n_channels + c) * W;
+      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = y[i];
+    }
+    if (F.burst_index >= 0) {  // ---- |hilbert(y)| (bursts.py:153), exact length-W transform ----
+      const int Wh = W >> 1;
+      const float2* Zy;
+      if (A.hil_full) {
+        for (int i = NMX_TID; i < W; i += NMX_NT) other[i] = make_float2(y[i], 0.f);
+        NMX_SYNC();
+        Zy = nmx_fft<-1>(A.hil_r, other, yz, other);
+      } else {
+        // y is contiguous floats: reinterpret as W/2 packed complex samples (read-only input)
+        Zy = nmx_fft<-1>(A.hil_r, (const float2*)y, other, yz);
+      }
+      float2* Ab = (Zy == bufA) ? bufB : bufA;
+      // one-sided spectrum: X[0], 2 X[k] (0 < k < W/2), X[W/2] (W even), 0 for negative k
+      const float invW = 1.f / (float)W;
+      for (int k = NMX_TID; k < W; k += NMX_NT) {
+        float2 v = make_float2(0.f, 0.f);
+        if (A.hil_full) {
+          if (k == 0) v = Zy[0];
+          else if (k <= (W - 1) / 2) v = make_float2(2.f * Zy[k].x, 2.f * Zy[k].y);
+        } else if (k <= Wh) {
+          v = nmx_rfft_bin(Zy, A.hil_r.twr, Wh, k);
+          if (k != 0 && k != Wh) v = make_float2(2.f * v.x, 2.f * v.y);
+        }
+        Ab[k] = make_float2(v.x * invW, v.y * invW);
+      }
+      NMX_SYNC();
+      float2* Zbuf = (Ab == bufA) ? bufB : bufA;
+      const float2* an = nmx_fft<+1>(A.hil_c, Ab, Zbuf, Ab);
+      float* dst = A.env_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W;
+      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
+    }
+    NMX_SYNC();
+  }
+}

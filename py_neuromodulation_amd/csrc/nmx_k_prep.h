@@ -1,0 +1,61 @@
+// nmx_k_prep.h -- stream-level pre-processing kernels.
+//
+//  nmx_reref_tile : y[c][t] = sum_j R[c][j] * nan_to_num(x[j][t])  on the CONTINUOUS stream
+//     (processing/rereference.py:99-100 after stream/data_processor.py:255).  The reference
+//     re-references every window after notch/resample; all three are linear and the notch is
+//     per channel, so the channel-space map commutes and is applied once per sample here
+//     instead of once per (window, sample) (10x less work at 90 % overlap).  The row
+//     selection data[feature_idx] is folded into R by the host.
+//  nmx_nanmask_item: mask[w][j] = any(isnan(x[j][start_w : start_w + W]))
+//     (stream/data_processor.py:253), one wave per (window, input row).
+#pragma once
+
+#include "nmx_device.h"
+
+#define NMX_REREF_ROWS 16
+
+struct NmxRerefArgs {
+  const float* x;     // [C_in][ldx]
+  long long ldx;
+  float* y;           // [C][ldy]
+  long long ldy;
+  const float* R;     // [C][C_in]
+  int C, C_in;
+  long long T;
+};
+
+// block = 256 threads <-> 256 consecutive samples; blockIdx.y <-> NMX_REREF_ROWS output rows
+NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
+  if (t >= A.T) return;
+  float acc[NMX_REREF_ROWS];
+  for (int i = 0; i < NMX_REREF_ROWS; ++i) acc[i] = 0.f;
+  const int nrow = (A.C - c0) < NMX_REREF_ROWS ? (A.C - c0) : NMX_REREF_ROWS;
+  for (int j = 0; j < A.C_in; ++j) {
+    const float v = nmx_clean(A.x[(long long)j * A.ldx + t]);
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+    for (int i = 0; i < NMX_REREF_ROWS; ++i)
+      if (i < nrow) acc[i] += A.R[(long long)(c0 + i) * A.C_in + j] * v;
+  }
+  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = acc[i];
+}
+
+struct NmxNanMaskArgs {
+  const float* x;
+  long long ldx;
+  const long long* starts;
+  unsigned char* mask;   // [n_windows][C_in]
+  int C_in, W;
+};
+
+NMX_DEV void nmx_nanmask_item(const NmxNanMaskArgs& A, int w, int j, float* smem) {
+  const float* src = A.x + (long long)j * A.ldx + A.starts[w];
+  int any = 0;
+  for (int i = NMX_TID; i < A.W; i += NMX_NT) {
+    const float v = src[i];
+    any |= (v != v);
+  }
+  any = nmx_block_or(any, smem);
+  if (NMX_TID == 0) A.mask[(long long)w * A.C_in + j] = (unsigned char)(any ? 1 : 0);
+}

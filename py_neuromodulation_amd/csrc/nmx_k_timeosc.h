@@ -1,0 +1,244 @@
+// nmx_k_timeosc.h -- kernel A: time-domain scan + FFT / Welch / STFT band power for one
+// (window, channel) item per workgroup.
+//
+// Reference arithmetic reproduced (citations into /root/reference/py_neuromodulation):
+//   features/hjorth_raw.py:24-42,51-57   Hjorth activity / mobility / complexity, Raw
+//   features/linelength.py:11-21         sum|dx| / (W-1)^2
+//   features/oscillatory.py:90-119       FFT: |rfft(x[-N:])| -> log10 -> estimators, bins [lo,hi)
+//   features/oscillatory.py:150-182      Welch: hann, constant detrend, density, 50 % overlap
+//   features/oscillatory.py:215-250      STFT: hamming, even boundary, spectrum scaling
+// Data flow: window HBM -> LDS once (coalesced), everything else LDS/registers, ~35 floats
+// written back per item.  Variances are two-pass (mean-shifted) in fp32.
+#pragma once
+
+#include "nmx_device.h"
+
+// variance (ddof 0) of f(i), i in [0, n), where f reads LDS; two block reductions
+template <typename F>
+NMX_DEV float nmx_var(int n, float* red, F f) {
+  float s = 0.f;
+  for (int i = NMX_TID; i < n; i += NMX_NT) s += f(i);
+  const float mean = nmx_block_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (int i = NMX_TID; i < n; i += NMX_NT) {
+    const float d = f(i) - mean;
+    q += d * d;
+  }
+  return nmx_block_sum(q, red) / (float)n;
+}
+
+NMX_DEV float nmx_nan_to_num(float v) { return nmx_clean(v); }
+
+// Hjorth triple of a series y[0..n) in LDS, with the reference's nan_to_num placement.
+// mode 0 = hjorth_raw.py (complexity divides by the nan_to_num'ed mobility),
+// mode 1 = bandpower.py:185-207 (nan_to_num only on the final values).
+NMX_DEV void nmx_hjorth(const float* y, int n, float* red, int mode, bool need_mc,
+                        float& activity, float& mobility, float& complexity) {
+  const float v0 = nmx_var(n, red, [&](int i) { return y[i]; });
+  activity = v0;
+  mobility = complexity = 0.f;
+  if (!need_mc) return;
+  const float v1 = nmx_var(n - 1, red, [&](int i) { return y[i + 1] - y[i]; });
+  const float v2 = nmx_var(n - 2, red, [&](int i) { return (y[i + 2] - y[i + 1]) - (y[i + 1] - y[i]); });
+  const float mob = sqrtf(v1 / v0);
+  const float dmob = sqrtf(v2 / v1);
+  if (mode == 0) {
+    mobility = nmx_nan_to_num(mob);
+    complexity = nmx_nan_to_num(dmob / mobility);
+  } else {
+    mobility = mob;
+    complexity = dmob / mob;
+  }
+}
+
+NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin, int n_bands,
+                            float* out_row, int c, float* red) {
+  for (int b = 0; b < n_bands; ++b) {
+    const int lo = O.bin_lo[b], hi = O.bin_hi[b];
+    const int cnt = (hi - lo) * vals_per_bin;
+    const float* v = spec + lo * vals_per_bin;
+    int slot = 0;
+    float mean = NAN;
+    const bool need_mean = O.estimators & (NMXD_EST_MEAN | NMXD_EST_STD);
+    if (need_mean && cnt > 0) mean = nmx_est_mean(v, cnt, red);
+    const int col0 = O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride;
+    if (O.estimators & NMXD_EST_MEAN) {
+      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = mean;
+      ++slot;
+    }
+    if (O.estimators & NMXD_EST_MEDIAN) {
+      const float r = cnt > 0 ? nmx_est_median(v, cnt, red) : NAN;
+      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = r;
+      ++slot;
+    }
+    if (O.estimators & NMXD_EST_STD) {
+      const float r = cnt > 0 ? nmx_est_std(v, cnt, mean, red) : NAN;
+      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = r;
+      ++slot;
+    }
+    if (O.estimators & NMXD_EST_MAX) {
+      const float r = cnt > 0 ? nmx_est_max(v, cnt, red) : NAN;
+      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = r;
+      ++slot;
+    }
+  }
+}
+
+// real transform of the packed / windowed segment already sitting in `bufB` (as n/2 complex,
+// or n complex with zero imaginary part when O.complex_full); returns pointer to Z
+NMX_DEV float2* nmx_osc_fft(const NmxOsc& O, float2* bufA, float2* bufB) {
+  return nmx_fft<-1>(O.fft, bufB, bufA, bufB);
+}
+
+NMX_DEV float2 nmx_osc_bin(const NmxOsc& O, const float2* Z, int k) {
+  if (O.complex_full) return Z[k];
+  return nmx_rfft_bin(Z, O.fft.twr, O.fft.n, k);
+}
+
+NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* smem) {
+  float* xs = smem + A.off_x;
+  float2* bufA = (float2*)(smem + A.off_a);
+  float2* bufB = (float2*)(smem + A.off_b);
+  float* spec = smem + A.off_spec;
+  float* red = smem + A.off_red;
+  const int W = A.W;
+  float* out_row = A.out + (long long)w * A.n_outputs;
+
+  // ---- stage the window in LDS (lane-consecutive, coalesced) ---------------------------
+  const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
+                     (A.starts ? A.starts[w] : 0ll);
+  for (int i = NMX_TID; i < W; i += NMX_NT) {
+    float v = src[i];
+    if (A.clean_on_load) v = nmx_clean(v);
+    xs[i] = v;
+  }
+  NMX_SYNC();
+
+  // ---- time-domain features -----------------------------------------------------------
+  if (A.features & NMXD_F_HJORTH) {
+    float act, mob, comp;
+    nmx_hjorth(xs, W, red, 0, true, act, mob, comp);
+    if (NMX_TID == 0) {
+      const int col = A.hjorth_cols.base + c * A.hjorth_cols.ch_stride;
+      out_row[col] = nmx_nan_to_num(act);
+      out_row[col + A.hjorth_cols.a_stride] = mob;
+      out_row[col + 2 * A.hjorth_cols.a_stride] = comp;
+    }
+  }
+  if ((A.features & NMXD_F_RAW) && NMX_TID == 0)
+    out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = xs[W - 1];
+  if (A.features & NMXD_F_LINELENGTH) {
+    float s = 0.f;
+    for (int i = NMX_TID; i < W - 1; i += NMX_NT) s += fabsf(xs[i + 1] - xs[i]);
+    s = nmx_block_sum(s, red);
+    const float wm1 = (float)(W - 1);
+    if (NMX_TID == 0) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = s / wm1 / wm1;
+  }
+
+  // ---- FFT band power -------------------------------------------------------------------
+  if (A.fft.enabled) {
+    const NmxOsc& O = A.fft;
+    const int N = O.n, off = W - N;
+    NMX_SYNC();
+    if (O.complex_full) {
+      for (int i = NMX_TID; i < N; i += NMX_NT) bufB[i] = make_float2(xs[off + i], 0.f);
+    } else {
+      for (int i = NMX_TID; i < N / 2; i += NMX_NT)
+        bufB[i] = make_float2(xs[off + 2 * i], xs[off + 2 * i + 1]);
+    }
+    NMX_SYNC();
+    const float2* Z = nmx_osc_fft(O, bufA, bufB);
+    for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+      const float2 X = nmx_osc_bin(O, Z, k);
+      float v = sqrtf(X.x * X.x + X.y * X.y);
+      if (O.log_transform) v = log10f(v);
+      spec[k] = v;
+    }
+    NMX_SYNC();
+    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red);
+    if (O.return_spectrum)
+      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT)
+        out_row[O.psd_cols.base + c * O.psd_cols.ch_stride + k * O.psd_cols.a_stride] = spec[k];
+  }
+
+  // ---- Welch ------------------------------------------------------------------------------
+  if (A.welch.enabled) {
+    const NmxOsc& O = A.welch;
+    const int N = O.n;
+    for (int sgi = 0; sgi < O.nseg; ++sgi) {
+      const int s0 = sgi * O.step;
+      float sm = 0.f;
+      for (int i = NMX_TID; i < N; i += NMX_NT) sm += xs[s0 + i];
+      const float mean = nmx_block_sum(sm, red) / (float)N;
+      NMX_SYNC();
+      if (O.complex_full) {
+        for (int i = NMX_TID; i < N; i += NMX_NT)
+          bufB[i] = make_float2((xs[s0 + i] - mean) * O.win[i], 0.f);
+      } else {
+        for (int i = NMX_TID; i < N / 2; i += NMX_NT)
+          bufB[i] = make_float2((xs[s0 + 2 * i] - mean) * O.win[2 * i],
+                                (xs[s0 + 2 * i + 1] - mean) * O.win[2 * i + 1]);
+      }
+      NMX_SYNC();
+      const float2* Z = nmx_osc_fft(O, bufA, bufB);
+      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+        const float2 X = nmx_osc_bin(O, Z, k);
+        float p = (X.x * X.x + X.y * X.y) * O.scale;
+        const bool edge = (k == 0) || ((N % 2 == 0) && k == N / 2);
+        if (!edge) p *= 2.f;
+        spec[k] = (sgi == 0) ? p : spec[k] + p;
+      }
+      NMX_SYNC();
+    }
+    const float inv = 1.f / (float)O.nseg;
+    for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+      float v = spec[k] * inv;
+      if (O.log_transform) v = log10f(v);
+      spec[k] = v;
+    }
+    NMX_SYNC();
+    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red);
+    if (O.return_spectrum)
+      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT)
+        out_row[O.psd_cols.base + c * O.psd_cols.ch_stride + k * O.psd_cols.a_stride] = spec[k];
+  }
+
+  // ---- STFT -----------------------------------------------------------------------------
+  if (A.stft.enabled) {
+    const NmxOsc& O = A.stft;
+    const int N = O.n, h = O.half;
+    auto xe = [&](int e) -> float {  // even extension by h, zero padding beyond
+      if (e < h) return xs[h - e];
+      if (e < h + W) return xs[e - h];
+      if (e < 2 * h + W) return xs[W - 2 - (e - h - W)];
+      return 0.f;
+    };
+    for (int sgi = 0; sgi < O.nseg; ++sgi) {
+      const int s0 = sgi * O.step;
+      NMX_SYNC();
+      if (O.complex_full) {
+        for (int i = NMX_TID; i < N; i += NMX_NT) bufB[i] = make_float2(xe(s0 + i) * O.win[i], 0.f);
+      } else {
+        for (int i = NMX_TID; i < N / 2; i += NMX_NT)
+          bufB[i] = make_float2(xe(s0 + 2 * i) * O.win[2 * i], xe(s0 + 2 * i + 1) * O.win[2 * i + 1]);
+      }
+      NMX_SYNC();
+      const float2* Z = nmx_osc_fft(O, bufA, bufB);
+      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+        const float2 X = nmx_osc_bin(O, Z, k);
+        float v = sqrtf(X.x * X.x + X.y * X.y) * O.scale;
+        if (O.log_transform) v = log10f(v);
+        spec[k * O.nseg + sgi] = v;
+      }
+    }
+    NMX_SYNC();
+    nmx_emit_bands(O, spec, O.nseg, A.n_bands, out_row, c, red);
+    if (O.return_spectrum)
+      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+        float s = 0.f;
+        for (int m = 0; m < O.nseg; ++m) s += spec[k * O.nseg + m];
+        out_row[O.psd_cols.base + c * O.psd_cols.ch_stride + k * O.psd_cols.a_stride] =
+            s / (float)O.nseg;
+      }
+  }
+}

@@ -1,0 +1,396 @@
+"""Host side of the hot path: settings -> flat C plan -> HIP kernels (via libnmx.so).
+
+``HotPathEngine`` turns a (duck-typed) ``NMSettings`` + channel names into an
+``nmx_plan_desc`` -- band -> FFT-bin tables, FIR taps designed on the host, the output column
+of every (feature, channel) in the reference's key order -- and drives the C ABI:
+
+    process_window(data[C_in, W] float64) -> float32[F]      one hop, the reference call shape
+    process_batch(data[C_in, T], starts)   -> float32[n, F]   many hops resident on the GPU
+
+Key order reproduced: features in ``FeatureSelector`` field order
+(stream/settings.py:41-55 via utils/types.py:135-140), and inside each feature the nesting of
+the reference class (hjorth_raw.py:37-40, bandpower.py:131-145, oscillatory.py:102-117,
+sharpwaves.py:169-197,302-326, bursts.py:119-125,262-298, linelength.py:17-19).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections.abc import Sequence
+
+import numpy as np
+
+from . import _lib, fir_design
+from ._lib import Cols, PlanDesc
+
+_FEATURE_BITS = {"raw_hjorth": _lib.F_HJORTH, "return_raw": _lib.F_RAW,
+                 "bandpass_filter": _lib.F_BANDPOWER, "stft": _lib.F_STFT, "fft": _lib.F_FFT,
+                 "welch": _lib.F_WELCH, "sharpwave_analysis": _lib.F_SHARPWAVE,
+                 "bursts": _lib.F_BURSTS, "linelength": _lib.F_LINELENGTH}
+_OUT_OF_SCOPE = {"fooof", "nolds", "coherence", "mne_connectivity", "bispectrum"}
+_BURST_SLOTS = [("duration", ["duration_mean", "duration_max"]),
+                ("amplitude", ["amplitude_mean", "amplitude_max"]),
+                ("burst_rate_per_s", ["burst_rate_per_s"]), ("in_burst", ["in_burst"])]
+
+
+def _enabled(sel) -> list[str]:
+    return list(sel.get_enabled())
+
+
+def _cols(base=0, ch=0, a=0, b=0) -> Cols:
+    return Cols(int(base), int(ch), int(a), int(b))
+
+
+class HotPathEngine:
+    """One plan on one GPU for ``len(ch_names)`` channels."""
+
+    def __init__(self, settings, ch_names: Sequence[str], sfreq: float, *,
+                 features: Sequence[str] | None = None, ref_matrix: np.ndarray | None = None,
+                 notch_taps: np.ndarray | None = None, device: int = 0,
+                 lib: _lib.NmxLibrary | None = None, bank_taps: np.ndarray | None = None,
+                 sharpwave_taps: Sequence[np.ndarray] | None = None) -> None:
+        self.lib = lib if lib is not None else _lib.get_library()
+        self.settings = settings
+        self.ch_names = list(ch_names)
+        self.sfreq = float(sfreq)
+        self.C = len(self.ch_names)
+        enabled = _enabled(settings.features) if features is None else list(features)
+        bad = [f for f in enabled if f in _OUT_OF_SCOPE or f not in _FEATURE_BITS]
+        if bad:
+            raise NotImplementedError(
+                f"features {bad} are outside the accelerated hot path (SURVEY.md section 2)")
+        self.enabled = enabled
+        self.W = int(settings.segment_length_features_ms / 1000 * sfreq)
+        self._keep: list = []   # arrays referenced by the C struct
+        self.keys: list[str] = []
+        self.desc = self._build(ref_matrix, notch_taps, device, bank_taps, sharpwave_taps)
+        self.n_outputs = len(self.keys)
+        self.C_in = int(self.desc.n_channels_in)
+        self._plan = C.c_void_p()
+        self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
+
+    # ------------------------------------------------------------------------------------
+    def _dptr(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._keep.append(arr)
+        return arr.ctypes.data_as(C.POINTER(C.c_double))
+
+    def _osc(self, osc_settings, name: str, n: int, freqs: np.ndarray, inclusive: bool,
+             bands, base: int) -> tuple[_lib.OscDesc, int]:
+        s = osc_settings
+        if not s.windowlength_ms <= self.settings.segment_length_features_ms:
+            raise AssertionError(
+                f"oscillatory feature windowlength_ms = ({s.windowlength_ms}) needs to be smaller "
+                f"than settings['segment_length_features_ms'] = "
+                f"{self.settings.segment_length_features_ms}")
+        o = _lib.OscDesc()
+        o.n = int(n)
+        o.log_transform = int(bool(s.log_transform))
+        ests = _enabled(s.features)
+        o.estimators = sum(_lib.EST_BITS[e] for e in ests)
+        o.return_spectrum = int(bool(s.return_spectrum))
+        for b, (_, (lo, hi)) in enumerate(bands):
+            idx = np.where((freqs >= lo) & ((freqs <= hi) if inclusive else (freqs < hi)))[0]
+            if idx.size and not np.array_equal(idx, np.arange(idx[0], idx[-1] + 1)):
+                raise ValueError("non-contiguous band bins")
+            o.bin_lo[b] = int(idx[0]) if idx.size else 0
+            o.bin_hi[b] = int(idx[-1]) + 1 if idx.size else 0
+        # keys: band, estimator, channel  (oscillatory.py:102-112)
+        o.cols = _cols(base, 1, len(ests) * self.C, self.C)
+        for bname, _ in bands:
+            for e in ests:
+                self.keys += [f"{ch}_{name}_{bname}_{e}" for ch in self.ch_names]
+        used = len(bands) * len(ests) * self.C
+        if o.return_spectrum:
+            ints = [int(f) for f in freqs]
+            if len(set(ints)) != len(ints):
+                raise NotImplementedError(
+                    f"{name}: return_spectrum with a bin spacing below 1 Hz yields colliding "
+                    "'psd_<int(f)>' keys in the reference; not supported")
+            o.psd_cols = _cols(base + used, len(freqs), 1, 0)
+            for ch in self.ch_names:
+                self.keys += [f"{ch}_{name}_psd_{i}" for i in ints]
+            used += self.C * len(freqs)
+        return o, used
+
+    def _build(self, ref_matrix, notch_taps, device, bank_taps, sharpwave_taps) -> PlanDesc:
+        st, C_, W, sfreq = self.settings, self.C, self.W, self.sfreq
+        d = PlanDesc()
+        d.abi_version = _lib.NMX_ABI_VERSION
+        d.device = int(device)
+        d.n_channels = C_
+        d.window = W
+        d.sfreq = sfreq
+        d.feat_hz = float(st.sampling_rate_features_hz)
+        bands = [(name, (float(fr[0]), float(fr[1]))) for name, fr in st.frequency_ranges_hz.items()]
+        if len(bands) > _lib.NMX_MAX_BANDS:
+            raise ValueError(f"at most {_lib.NMX_MAX_BANDS} frequency bands are supported")
+        d.n_bands = len(bands)
+        band_index = {name: i for i, (name, _) in enumerate(bands)}
+        filters: list[dict] = []
+        band_filter: dict[str, int] = {}
+
+        def bank_filter(name: str) -> dict:
+            """FIR of band `name` (shared by BandPower and Bursts: same MNEFilter arguments)."""
+            if name not in band_filter:
+                if bank_taps is not None:
+                    taps = np.asarray(bank_taps)[band_index[name]]
+                else:
+                    taps = fir_design.band_pass_bank([bands[band_index[name]][1]], sfreq)[0]
+                band_filter[name] = len(filters)
+                filters.append({"taps": taps, "bp_seglen": 0, "bp_band": 0, "burst": -1, "sw": -1})
+            return filters[band_filter[name]]
+
+        feats = 0
+        col = 0
+        for f in self.enabled:
+            feats |= _FEATURE_BITS[f]
+            if f == "raw_hjorth":
+                d.hjorth_cols = _cols(col, 3, 1, 0)
+                for ch in self.ch_names:
+                    self.keys += [f"{ch}_RawHjorth_Activity", f"{ch}_RawHjorth_Mobility",
+                                  f"{ch}_RawHjorth_Complexity"]
+                col += 3 * C_
+            elif f == "return_raw":
+                d.raw_cols = _cols(col, 1)
+                self.keys += [f"{ch}_raw" for ch in self.ch_names]
+                col += C_
+            elif f == "linelength":
+                d.linelength_cols = _cols(col, 1)
+                self.keys += [f"{ch}_LineLength" for ch in self.ch_names]
+                col += C_
+            elif f == "fft":
+                n = int(np.floor(st.fft_settings.windowlength_ms / 1000 * sfreq))
+                freqs = np.fft.rfftfreq(n, 1 / np.floor(int(sfreq)))
+                d.fft, used = self._osc(st.fft_settings, "fft", n, freqs, False, bands, col)
+                col += used
+            elif f == "welch":
+                n = int(sfreq)
+                freqs = np.fft.rfftfreq(n, 1 / n)
+                d.welch, used = self._osc(st.welch_settings, "welch", n, freqs, False, bands, col)
+                col += used
+            elif f == "stft":
+                n = int(st.stft_settings.windowlength_ms)   # ms used as samples (oscillatory.py:199)
+                freqs = np.fft.rfftfreq(n, 1 / int(sfreq))
+                d.stft, used = self._osc(st.stft_settings, "stft", n, freqs, True, bands, col)
+                col += used
+            elif f == "bandpass_filter":
+                bp = st.bandpass_filter_settings
+                if getattr(bp, "kalman_filter", False):
+                    raise NotImplementedError("kalman_filter is outside the accelerated hot path")
+                bfeats = _enabled(bp.bandpower_features)
+                d.bp_features = sum(1 << ["activity", "mobility", "complexity"].index(x) for x in bfeats)
+                d.bp_log_transform = int(bool(bp.log_transform))
+                nf = len(bfeats)
+                d.bp_cols = _cols(col, len(bands) * nf, nf, 1)
+                for name, _ in bands:
+                    fd = bank_filter(name)
+                    fd["bp_seglen"] = int(np.floor(sfreq / 1000 * bp.segment_lengths_ms[name]))
+                    fd["bp_band"] = band_index[name]
+                for ch in self.ch_names:
+                    for name, _ in bands:
+                        self.keys += [f"{ch}_bandpass_{x}_{name}" for x in bfeats]
+                col += C_ * len(bands) * nf
+            elif f == "bursts":
+                bs = st.bursts_settings
+                names = list(bs.frequency_bands)
+                for nme in names:
+                    if nme not in band_index:
+                        raise ValueError(f"bursting {nme} needs to be defined in "
+                                         "settings['frequency_ranges_hz']")
+                groups = _enabled(bs.burst_features)
+                slots, mask, bit = [], 0, 0
+                for g, outs in _BURST_SLOTS:
+                    for o in outs:
+                        if g in groups:
+                            mask |= 1 << bit
+                        bit += 1
+                # the reference emits the groups in burst_features order, which is _BURST_SLOTS order
+                for g in groups:
+                    slots += dict(_BURST_SLOTS)[g]
+                d.n_burst_bands = len(names)
+                d.burst_threshold = float(bs.threshold)
+                d.burst_time_duration_s = float(bs.time_duration_s)
+                d.burst_out_mask = mask
+                d.burst_cols = _cols(col, len(names) * len(slots), len(slots), 1)
+                for i, nme in enumerate(names):
+                    bank_filter(nme)["burst"] = i
+                for ch in self.ch_names:
+                    for nme in names:
+                        self.keys += [f"{ch}_bursts_{nme}_{s}" for s in slots]
+                col += C_ * len(names) * len(slots)
+            elif f == "sharpwave_analysis":
+                col = self._sharpwave(d, filters, col, sharpwave_taps)
+        d.features = feats
+        d.n_outputs = col
+        if len(filters) > _lib.NMX_MAX_FILTERS:
+            raise ValueError(f"at most {_lib.NMX_MAX_FILTERS} FIR filters per plan are supported")
+        d.n_filters = len(filters)
+        for i, fd in enumerate(filters):
+            taps = np.asarray(fd["taps"], np.float64)
+            d.filters[i].taps = self._dptr(taps)
+            d.filters[i].n_taps = len(taps)
+            d.filters[i].bp_seglen = fd["bp_seglen"]
+            d.filters[i].bp_band_index = fd["bp_band"]
+            d.filters[i].burst_index = fd["burst"]
+            d.filters[i].sw_index = fd["sw"]
+        self.filter_taps = [np.asarray(fd["taps"], np.float64) for fd in filters]
+        if notch_taps is not None:
+            nt = np.asarray(notch_taps, np.float64)
+            d.notch_taps = self._dptr(nt)
+            d.n_notch_taps = len(nt)
+        if ref_matrix is not None:
+            R = np.ascontiguousarray(ref_matrix, np.float64)
+            if R.ndim != 2 or R.shape[0] != C_:
+                raise ValueError("ref_matrix must be [n_channels, n_channels_in]")
+            d.ref_matrix = self._dptr(R)
+            d.n_channels_in = R.shape[1]
+        else:
+            d.n_channels_in = C_
+        assert len(self.keys) == col
+        return d
+
+    def _sharpwave(self, d: PlanDesc, filters: list, col: int, sharpwave_taps) -> int:
+        st, sfreq, C_ = self.settings, self.sfreq, self.C
+        sw = st.sharpwave_analysis_settings
+        used = [f for f in _lib.SW_FEATURES if getattr(sw.sharpwave_features, f)]
+        est_of = {f: [e for e in _lib.SW_ESTIMATORS if f in sw.estimator[e]] for f in used}
+        for f in used:
+            assert est_of[f], f"Add estimator key for {f}"
+        combos = [(f, e) for f in used for e in est_of[f]]
+        if len(combos) > _lib.NMX_MAX_SW_COMBOS:
+            raise ValueError("too many sharp-wave (feature, estimator) pairs")
+        names = []
+        for i, fr in enumerate(sw.filter_ranges_hz):
+            assert fr[1] < sfreq, ("Filter range has to be smaller than sfreq, "
+                                   f"got sfreq {sfreq} and filter range {fr}")
+            names.append(f"range_{fr[0]:.0f}_{fr[1]:.0f}")
+            taps = (np.asarray(sharpwave_taps[i]) if sharpwave_taps is not None
+                    else fir_design.band_pass(sfreq, fr[0], fr[1]))
+            filters.append({"taps": taps, "bp_seglen": 0, "bp_band": 0, "burst": -1, "sw": i})
+        d.n_sw_filters = len(names)
+        d.sw_n_combos = len(combos)
+        for i, (f, e) in enumerate(combos):
+            d.sw_combo_feature[i] = _lib.SW_FEATURES.index(f)
+            d.sw_combo_estimator[i] = _lib.SW_ESTIMATORS.index(e)
+        d.sw_distance_peaks = float(sw.detect_troughs.distance_peaks_ms)      # sharpwaves.py:339-344
+        d.sw_distance_troughs = float(sw.detect_troughs.distance_troughs_ms)
+        d.sw_estimate_peaks = int(bool(sw.detect_peaks.estimate))
+        d.sw_estimate_troughs = int(bool(sw.detect_troughs.estimate))
+        between = bool(sw.apply_estimator_between_peaks_and_troughs)
+        d.sw_between = int(between)
+        NF = len(names)
+        if between:
+            reg = [(f, e) for f, e in combos if f != "num_peaks"]
+            d.sw_cols = _cols(col, NF * len(reg), len(reg), 1)
+            for ch in self.ch_names:
+                for fn in names:
+                    self.keys += [f"{ch}_Sharpwave_{e.title()}_{f}_{fn}" for f, e in reg]
+            col += C_ * NF * len(reg)
+            if "num_peaks" in used:
+                d.sw_numpeaks_cols = _cols(col, NF, 1, 0)
+                for ch in self.ch_names:
+                    self.keys += [f"{ch}_Sharpwave_num_peaks_{fn}" for fn in names]
+                col += C_ * NF
+        else:
+            pols = ([("Peak")] if d.sw_estimate_peaks else []) + (["Trough"] if d.sw_estimate_troughs else [])
+            slots, seen_np = [], False
+            for f, e in combos:
+                if f == "num_peaks":
+                    if seen_np:
+                        continue
+                    seen_np = True
+                    slots.append("{ch}_Sharpwave_num_peaks_{fn}")
+                else:
+                    slots.append("{ch}_Sharpwave_" + e.title() + "_" + f + "_{fn}")
+            npol = len(pols)
+            d.sw_cols = _cols(col, NF * len(slots) * npol, len(slots) * npol, npol)
+            for ch in self.ch_names:
+                for fn in names:
+                    for s in slots:
+                        self.keys += [s.format(ch=ch, fn=fn) + "_analyze_" + p for p in pols]
+            col += C_ * NF * len(slots) * npol
+        return col
+
+    # ------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_plan", None) is not None and self._plan.value:
+            self.lib.lib.nmx_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_state(self) -> None:
+        self.lib.check(self.lib.lib.nmx_state_reset(self._plan))
+
+    def export_state(self) -> bytes:
+        n = C.c_int64()
+        self.lib.check(self.lib.lib.nmx_state_size(self._plan, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self.lib.check(self.lib.lib.nmx_state_export(self._plan, buf, n.value))
+        return buf.raw
+
+    def import_state(self, blob: bytes) -> None:
+        self.lib.check(self.lib.lib.nmx_state_import(self._plan, blob, len(blob)))
+
+    def process_window(self, data: np.ndarray, want_nan_mask: bool = False):
+        """data[C_in, W] (float64, may be a non-contiguous view) -> float32[n_outputs]."""
+        data = np.asarray(data, dtype=np.float64)
+        if data.ndim != 2 or data.shape[0] != self.C_in or data.shape[1] != self.W:
+            raise ValueError(f"expected data of shape ({self.C_in}, {self.W}), got {data.shape}")
+        if data.strides[1] != 8:
+            data = np.ascontiguousarray(data)
+        out = np.empty(self.n_outputs, np.float32)
+        mask = np.zeros(self.C_in, np.uint8) if want_nan_mask else None
+        self.lib.check(self.lib.lib.nmx_process_window(
+            self._plan, data.ctypes.data, data.strides[0] // 8, out.ctypes.data,
+            mask.ctypes.data if mask is not None else None))
+        return (out, mask.astype(bool)) if want_nan_mask else out
+
+    def process_batch(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False):
+        """data[C_in, T] host array, starts[n] window start samples -> float32[n, n_outputs]."""
+        data = np.asarray(data)
+        if data.dtype != np.float32 or data.strides[1] != 4:
+            data = np.ascontiguousarray(data, dtype=np.float32)
+        if data.ndim != 2 or data.shape[0] != self.C_in:
+            raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        n = len(starts)
+        out = np.empty((n, self.n_outputs), np.float32)
+        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        self.lib.check(self.lib.lib.nmx_process_batch(
+            self._plan, data.ctypes.data, data.strides[0] // 4, data.shape[1], starts.ctypes.data, n,
+            out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
+        return (out, mask.astype(bool)) if want_nan_mask else out
+
+    def process_batch_device(self, x_ptr: int, ldx: int, n_samples: int, starts: np.ndarray,
+                             out_ptr: int, mask_ptr: int | None = None, stream: int | None = None) -> None:
+        """Device-resident variant: raw pointers on the plan's device (e.g. torch ``data_ptr()``)."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        self.lib.check(self.lib.lib.nmx_process_batch(
+            self._plan, x_ptr, ldx, n_samples, starts.ctypes.data, len(starts), out_ptr, mask_ptr,
+            1, stream))
+
+    def preprocess_window(self, data: np.ndarray) -> np.ndarray:
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        y = np.empty((self.C, self.W), np.float64)
+        self.lib.check(self.lib.lib.nmx_preprocess_window(self._plan, data.ctypes.data, data.shape[1],
+                                                         y.ctypes.data, self.W))
+        return y
+
+    def filter_window(self, data: np.ndarray) -> np.ndarray:
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        y = np.empty((self.C, int(self.desc.n_filters), self.W), np.float64)
+        self.lib.check(self.lib.lib.nmx_filter_window(self._plan, data.ctypes.data, data.shape[1],
+                                                     y.ctypes.data))
+        return y
+
+    def timing_ms(self, which: int = 0) -> float:
+        ms = C.c_float()
+        self.lib.check(self.lib.lib.nmx_last_timing_ms(self._plan, which, C.byref(ms)))
+        return float(ms.value)

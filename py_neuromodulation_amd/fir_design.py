@@ -1,0 +1,140 @@
+"""Host-side FIR tap design (run once per stream; the taps are an input of the HIP kernels).
+
+The reference delegates design to MNE-Python, which is neither vendored nor installable
+here ("parity unpinned" for the design step).  This module implements the
+published MNE algorithm with NumPy only -- windowed-sinc low-pass sections (hamming,
+length 3.3 / transition), added/subtracted per gain change -- for the three call shapes on
+the hot path:
+
+  band_pass_bank   filter/mne_filter.py:35-80    (filter_length = int(sfreq - 1), 4 Hz
+                                                   transitions, auto-length fallback)
+  auto_band_pass   features/sharpwaves.py:127-143 (auto transitions and length)
+  notch_bank       filter/notch_filter.py:25-76   (band-stops at k * line_noise)
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+_HAMMING_LENGTH_FACTOR = 3.3
+
+
+def _hamming_lowpass(numtaps: int, cutoff: float) -> np.ndarray:
+    """Windowed-sinc low-pass, cutoff as a fraction of Nyquist, unit DC gain
+    (== scipy.signal.firwin(numtaps, cutoff, window="hamming", fs=2))."""
+    m = np.arange(numtaps) - 0.5 * (numtaps - 1)
+    h = cutoff * np.sinc(cutoff * m)
+    if numtaps > 1:
+        h = h * (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(numtaps) / (numtaps - 1)))
+    return h / h.sum()
+
+
+def _sections(n_taps: int, edges: np.ndarray, gains: np.ndarray) -> np.ndarray:
+    """Sum of low-pass sections for a piecewise 0/1 gain profile (edges normalised to Nyquist)."""
+    if n_taps % 2 == 0:
+        raise RuntimeError("zero-phase FIR needs an odd number of taps")
+    h = np.zeros(n_taps)
+    if gains[-1] == 1:
+        h[n_taps // 2] = 1.0
+    hi_f, hi_g = edges[-1], gains[-1]
+    for lo_f, lo_g in zip(edges[-2::-1], gains[-2::-1]):
+        if lo_g != hi_g:
+            width = (hi_f - lo_f) / 2.0
+            n = int(round(_HAMMING_LENGTH_FACTOR / width))
+            n += 1 - n % 2
+            if n > n_taps:
+                raise ValueError(f"filter length {n_taps} too short for the transition band "
+                                 f"(needs {n} taps)")
+            sec = _hamming_lowpass(n, (hi_f + lo_f) / 2.0)
+            pad = (n_taps - n) // 2
+            if lo_g == 0:
+                h[pad:n_taps - pad] -= sec
+            else:
+                h[pad:n_taps - pad] += sec
+        hi_f, hi_g = lo_f, lo_g
+    return h
+
+
+def _odd(n: int) -> int:
+    return n + (n - 1) % 2
+
+
+def _auto_length(sfreq: float, *transitions: float) -> int:
+    seconds = _HAMMING_LENGTH_FACTOR / min(transitions)
+    # MNE formats the duration as "%ss" and parses it back before ceil()
+    return _odd(max(int(math.ceil(float("%s" % (seconds,)) * sfreq)), 1))
+
+
+def band_pass(sfreq: float, l_freq: float, h_freq: float, filter_length: int | None = None,
+              l_trans: float | None = None, h_trans: float | None = None) -> np.ndarray:
+    """Band-pass taps; ``None`` transitions / length mean MNE's "auto"."""
+    sfreq = float(sfreq)
+    nyq = sfreq / 2.0
+    if h_freq > nyq:
+        raise ValueError(f"h_freq ({h_freq}) must be below the Nyquist frequency {nyq}")
+    if not l_freq < h_freq:
+        raise ValueError("band-pass needs l_freq < h_freq")
+    lt = min(max(0.25 * l_freq, 2.0), l_freq) if l_trans is None else float(l_trans)
+    ht = min(max(0.25 * h_freq, 2.0), nyq - h_freq) if h_trans is None else float(h_trans)
+    if lt <= 0 or ht <= 0:
+        raise ValueError("transition bandwidths must be positive")
+    s1, s2 = l_freq - lt, h_freq + ht
+    if s1 < 0:
+        raise ValueError("Filter specification invalid: lower stop frequency negative")
+    if s2 > nyq:
+        raise ValueError("Effective band-stop frequency is too high")
+    n = _auto_length(sfreq, lt, ht) if filter_length is None else _odd(int(filter_length))
+    edges, gains = [s1, l_freq, h_freq, s2], [0, 1, 1, 0]
+    if s2 != nyq:
+        edges.append(nyq)
+        gains.append(0)
+    if s1 != 0:
+        edges.insert(0, 0.0)
+        gains.insert(0, 0)
+    return _sections(n, np.asarray(edges) / nyq, np.asarray(gains))
+
+
+def band_pass_bank(f_ranges, sfreq: float, filter_length: float | None = None,
+                   l_trans: float = 4, h_trans: float = 4) -> np.ndarray:
+    """MNEFilter.__init__: one row per band, auto-length fallback when the fixed length is too
+    short for the transition band.  Rows must share a length (np.vstack in the reference)."""
+    if filter_length is None:
+        filter_length = sfreq - 1
+    rows = []
+    for lo, hi in f_ranges:
+        try:
+            rows.append(band_pass(sfreq, lo, hi, int(filter_length), l_trans, h_trans))
+        except ValueError:
+            rows.append(band_pass(sfreq, lo, hi))
+    return np.vstack(rows)
+
+
+def notch_bank(sfreq: float, line_noise: float, notch_width: float = 3.0,
+               trans_bandwidth: float = 6.8) -> np.ndarray | None:
+    """NotchFilter.__init__: multi band-stop at k * line_noise, length int(sfreq - 1)."""
+    freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
+    if freqs.size > 0 and freqs[-1] >= sfreq / 2:
+        freqs = freqs[:-1]
+    if freqs.size == 0:
+        return None
+    nyq = float(sfreq) / 2.0
+    tb = trans_bandwidth / 2.0
+    lows = freqs - notch_width / 2.0 - tb     # pass-band edges below each notch
+    highs = freqs + notch_width / 2.0 + tb    # pass-band edges above each notch
+    if np.any(lows < 0):
+        raise ValueError("Filter specification invalid: lower stop frequency negative")
+    if np.any(highs > nyq):
+        raise ValueError("Effective band-stop frequency is too high")
+    edges = np.r_[lows, lows + tb, highs - tb, highs]
+    gains = np.r_[np.ones_like(lows), np.zeros_like(lows), np.zeros_like(lows), np.ones_like(lows)]
+    order = np.argsort(edges)
+    edges, gains = edges[order], gains[order]
+    if edges[0] != 0:
+        edges, gains = np.r_[0.0, edges], np.r_[1.0, gains]
+    if edges[-1] != nyq:
+        edges, gains = np.r_[edges, nyq], np.r_[gains, 1.0]
+    if np.any(np.abs(np.diff(gains, 2)) > 1):
+        raise ValueError("Stop bands are not sufficiently separated.")
+    return _sections(_odd(int(sfreq - 1)), edges / nyq, gains)

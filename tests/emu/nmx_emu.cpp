@@ -1,0 +1,84 @@
+// nmx_emu.cpp -- TEST-ONLY single-thread logic emulator of the nmx kernels.
+//
+// Compiles the SAME device source (py_neuromodulation_amd/csrc/nmx_k_*.h) with
+// -DNMX_HOST_EMU (one "thread" per workgroup, barriers are no-ops) behind the same C ABI,
+// so the CPU-only test suite can check kernel *logic* (index math, FFT staging, epilogues)
+// against the oracle in a container without a GPU.  It is NOT part of the product: the
+// package loader only ever opens libnmx.so (HIP); nothing under py_neuromodulation_amd/
+// references this file, and wave-level behaviour (races, barriers, shuffles) is only
+// exercised by the -m gpu tests on the MI355X.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define NMX_HOST_EMU 1
+#include "../../py_neuromodulation_amd/csrc/nmx_k_bank.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_bursts.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_timeosc.h"
+
+typedef void* be_stream_t;
+struct be_timer_t { bool used = false; };
+static int nmx_fail(int code, const std::string& msg);
+
+static int be_device_count() { return 1; }
+static int be_set_device(int) { return 0; }
+static void* be_alloc(size_t n) { return calloc(1, n ? n : 4); }
+static void be_free(void* p) { free(p); }
+static void be_h2d_sync(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static void be_d2h_sync(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static void be_memset_sync(void* d, int v, size_t n) { memset(d, v, n); }
+static void be_h2d_async(void* d, const void* s, size_t n, be_stream_t) { memcpy(d, s, n); }
+static void be_d2h_async(void* d, const void* s, size_t n, be_stream_t) { memcpy(d, s, n); }
+static void be_h2d_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, be_stream_t) {
+  for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+}
+static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v, n); }
+static int be_sync(be_stream_t) { return 0; }
+static be_stream_t be_stream_create() { return nullptr; }
+static void be_stream_destroy(be_stream_t) {}
+static void be_timer_create(be_timer_t&) {}
+static void be_timer_destroy(be_timer_t&) {}
+static void be_timer_start(be_timer_t&, be_stream_t) {}
+static void be_timer_stop(be_timer_t& t, be_stream_t) { t.used = true; }
+static float be_timer_elapsed(be_timer_t&) { return 0.f; }
+static int be_check_launch() { return 0; }
+
+static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) nmx_time_osc_item(A, it / A.n_channels, it % A.n_channels, sm.data());
+}
+static void be_launch_bank(const NmxBankArgs& A, int n_items, int, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) nmx_bank_item(A, it / A.n_channels, it % A.n_channels, sm.data());
+}
+static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) nmx_burst_thr_item(A, it / A.n_bands, it % A.n_bands, sm.data());
+}
+static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) {
+    const int bi = it % A.n_bands, r = it / A.n_bands;
+    nmx_burst_stat_item(A, r / A.n_channels, r % A.n_channels, bi, sm.data());
+  }
+}
+static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) {
+    const int fi = it % A.n_filters, r = it / A.n_filters;
+    nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, sm.data());
+  }
+}
+static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
+  for (int c0 = 0; c0 < A.C; c0 += NMX_REREF_ROWS)
+    for (long long t = 0; t < A.T; ++t) nmx_reref_tile(A, t, c0);
+}
+static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
+  float sm[64];
+  for (int it = 0; it < n_items; ++it) nmx_nanmask_item(A, it / A.C_in, it % A.C_in, sm);
+}
+
+#include "../../py_neuromodulation_amd/csrc/nmx_engine.inc"

@@ -1,0 +1,133 @@
+"""Parity test bodies shared by tests/test_kernel_logic_emu.py (CPU, logic emulator) and
+tests/test_gpu_parity.py (-m gpu, the real libnmx.so on the MI355X).  Each takes the loaded
+library binding; see tests/parity.py for the tolerance policy."""
+
+import numpy as np
+
+from tests import parity
+
+FEATURE_CASES = ["feat_1k", "feat_1k_nolog", "feat_2k", "feat_special_rows"]
+
+
+def case_feature_cases_match_reference_goldens(lib, case):
+    n_bad, report, worst = parity.run_feature_case(lib, case)
+    assert n_bad == 0, f"{case}: {n_bad} features outside tolerance\n{report}"
+
+
+def case_sharpwave_reference_test_inputs(lib):
+    """Impulse / sine / plateau inputs of the reference's tests/test_sharpwave.py."""
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import golden_dict, load_golden, settings_from_json
+
+    g = load_golden("sharpwave_tests")
+    s = settings_from_json(g["settings_json"])
+    ch = [str(c) for c in g["ch_names"]]
+    eng = HotPathEngine(s, ch, 1000.0, lib=lib, features=["sharpwave_analysis"],
+                        sharpwave_taps=[g["sw_taps_0"], g["sw_taps_1"]])
+    out = eng.process_window(g["data"])
+    want = golden_dict(g, "sharpwave")
+    assert list(want) == eng.keys
+    n_bad, report, _ = parity.compare(eng.keys, out, list(want.values()), s, 1000.0, 5.0, eng.W)
+    assert n_bad == 0, report
+
+
+def case_bursts_sequence_state_across_batches(lib):
+    """51 consecutive windows, ring of 2 s: the threshold state (top-K of the history) carries
+    across calls and across the ring-overflow regime exactly like the reference's buffer."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("bursts_sequence")
+    s = settings_from_json(g["settings_json"])
+    ch = [str(c) for c in g["ch_names"]]
+    sfreq = float(g["sfreq"])
+    data = g["data"]
+    starts, _, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz,
+                                       s.segment_length_features_ms)
+    keys = [str(k) for k in g["keys"]]
+    want = g["values"]
+    amp = float(np.abs(data).max())
+    for split in (len(starts), 7):   # one batch, then several batches + single windows
+        eng = HotPathEngine(s, ch, sfreq, lib=lib, features=["bursts"], bank_taps=None)
+        assert eng.keys == keys
+        rows = []
+        i = 0
+        while i < len(starts):
+            n = min(split, len(starts) - i)
+            if n == 1 or (split == 7 and i >= 28):
+                rows.append(eng.process_window(data[:, starts[i]:starts[i] + eng.W])[None])
+                n = 1
+            else:
+                rows.append(eng.process_batch(data, starts[i:i + n]))
+            i += n
+        got = np.concatenate(rows)
+        n_bad = 0
+        for r in range(len(starts)):
+            b, rep, _ = parity.compare(keys, got[r], want[r], s, sfreq, amp, eng.W, burst_slack=True)
+            n_bad += b
+            assert b == 0, f"window {r}\n{rep}"
+        # and tight agreement for the overwhelming majority of entries
+        close = np.isclose(got, want, rtol=1e-4, atol=1e-6)
+        assert close.mean() > 0.98
+        eng.close()
+
+
+def case_preprocessing_notch_and_reref(lib):
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings, fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import load_golden
+
+    g = load_golden("notch_unpinned")
+    s = NMSettings.get_default()
+    for sfreq in (1000, 2000):
+        x, y = g[f"x_{sfreq}"], g[f"y_{sfreq}"]
+        s.segment_length_features_ms = 1000
+        taps = fir_design.notch_bank(sfreq, 50)
+        np.testing.assert_allclose(taps, g[f"taps_{sfreq}"], rtol=0, atol=1e-14)
+        R = np.array([[1.0, -1.0], [-0.5, 1.0]])
+        eng = HotPathEngine(s, ["a", "b"], float(sfreq), lib=lib, features=["raw_hjorth"],
+                            notch_taps=taps, ref_matrix=R)
+        got = eng.preprocess_window(x)
+        want = orc.NotchFilter(sfreq, taps=taps).process(R @ x)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max())
+        # notch only == reference glue output stored in the golden
+        eng2 = HotPathEngine(s, ["a", "b"], float(sfreq), lib=lib, features=["raw_hjorth"], notch_taps=taps)
+        np.testing.assert_allclose(eng2.preprocess_window(x), y, rtol=0, atol=2e-5 * np.abs(y).max())
+        eng.close()
+        eng2.close()
+
+
+def case_filter_window_matches_mnefilter_shape_and_values(lib):
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("feat_1k")
+    s = settings_from_json(g["settings_json"])
+    ch = [str(c) for c in g["ch_names"]]
+    eng = HotPathEngine(s, ch, 1000.0, lib=lib, features=["bandpass_filter"], bank_taps=g["bank_taps"])
+    y = eng.filter_window(g["data"])
+    assert y.shape == (4, 4, 1000)
+    np.testing.assert_allclose(y[:2], g["bank_filtered"], rtol=0, atol=2e-5 * np.abs(g["bank_filtered"]).max())
+    eng.close()
+
+
+def case_nan_mask_and_clean_on_load(lib):
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 1000)) * 10
+    x[1, 10:20] = np.nan
+    eng = HotPathEngine(s, ["a", "b", "c"], 1000.0, lib=lib, features=["raw_hjorth", "linelength"])
+    out, mask = eng.process_window(x, want_nan_mask=True)
+    assert mask.tolist() == [False, True, False]
+    want = {}
+    xc = np.nan_to_num(x)
+    want.update(orc.Hjorth(s, ["a", "b", "c"], 1000.0).calc_feature(xc))
+    want.update(orc.LineLength(s, ["a", "b", "c"], 1000.0).calc_feature(xc))
+    np.testing.assert_allclose(out, np.array(list(want.values())), rtol=1e-5)
+    eng.close()

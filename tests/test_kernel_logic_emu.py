@@ -1,0 +1,54 @@
+"""CPU-only check of the KERNEL LOGIC: the HIP kernel source compiled single-threaded with g++
+(tests/emu/nmx_emu.cpp, test-only) behind the same C ABI, driven through the same Python host
+code, compared with the reference-generated goldens at fp32 tolerances (tests/parity.py).
+
+What this does NOT cover (only the -m gpu tests do): wave/barrier behaviour, LDS races,
+shuffles, occupancy -- and it is not a product code path: the package never loads this library.
+"""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from tests import parity  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import __graft_entry__ as ge
+    from py_neuromodulation_amd import _lib
+
+    return _lib.NmxLibrary(ge.build_emu())
+
+
+from tests import parity_cases as pc  # noqa: E402
+
+
+@pytest.mark.parametrize("case", pc.FEATURE_CASES)
+def test_feature_cases_match_reference_goldens(emu_lib, case):
+    pc.case_feature_cases_match_reference_goldens(emu_lib, case)
+
+
+def test_sharpwave_reference_test_inputs(emu_lib):
+    pc.case_sharpwave_reference_test_inputs(emu_lib)
+
+
+def test_bursts_sequence_state_across_batches(emu_lib):
+    pc.case_bursts_sequence_state_across_batches(emu_lib)
+
+
+def test_preprocessing_notch_and_reref(emu_lib):
+    pc.case_preprocessing_notch_and_reref(emu_lib)
+
+
+def test_filter_window_matches_mnefilter_shape_and_values(emu_lib):
+    pc.case_filter_window_matches_mnefilter_shape_and_values(emu_lib)
+
+
+def test_nan_mask_and_clean_on_load(emu_lib):
+    pc.case_nan_mask_and_clean_on_load(emu_lib)
