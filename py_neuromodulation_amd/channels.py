@@ -1,0 +1,89 @@
+"""Channel table handling (subset of utils/channels.py and stream/data_processor.py:141-160).
+
+The table is a pandas DataFrame with the reference's columns
+``name, rereference, used, target, type, status, new_name``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+COLUMNS = ["name", "rereference", "used", "target", "type", "status", "new_name"]
+
+
+def get_default_channels_from_data(data, car_rereferencing: bool = True):
+    """utils/channels.py:257-309: all channels 'ecog', good, used, common-average referenced;
+    ``new_name`` is ``ch{i}_avgref`` in both modes (the reference overwrites it, :291)."""
+    import pandas as pd
+
+    n = data.shape[0]
+    names = [f"ch{i}" for i in range(n)]
+    return pd.DataFrame({
+        "name": names,
+        "rereference": ["average" if car_rereferencing else "None"] * n,
+        "used": np.ones(n, dtype=int),
+        "target": np.zeros(n, dtype=int),
+        "type": ["ecog"] * n,
+        "status": ["good"] * n,
+        "new_name": [f"{c}_avgref" for c in names],
+    })
+
+
+def load_channels(channels):
+    """DataFrame, mapping of columns, or path to a channels.csv (utils/io.py load_channels)."""
+    import pandas as pd
+
+    if isinstance(channels, pd.DataFrame):
+        df = channels
+    elif isinstance(channels, dict):
+        df = pd.DataFrame(channels)
+    else:
+        df = pd.read_csv(channels)
+    missing = [c for c in COLUMNS if c not in df.columns]
+    if missing:
+        raise ValueError(f"channels table lacks columns {missing}")
+    return df.reset_index(drop=True)
+
+
+def channel_info(df):
+    """stream/data_processor.py:141-160 -> (ch_names_used, feature_idx, target_idx)."""
+    sel = (df["used"] == 1) & (df["status"] == "good")
+    ch_names_used = df.loc[sel, "new_name"].tolist()
+    feature_idx = [i for i in np.where(df["used"].astype(bool) & ~df["target"].astype(bool))[0].tolist()
+                   if df.loc[i, "status"] == "good"]
+    target_idx = np.where(df["target"] == 1)[0].tolist()
+    return ch_names_used, feature_idx, target_idx
+
+
+def reref_matrix(df) -> np.ndarray | None:
+    """processing/rereference.py:33-86: dense re-reference matrix over the good used channels
+    (None when fewer than two channels are used)."""
+    sub = df[df["used"] == 1].reset_index(drop=True)
+    n = len(sub)
+    if n in (0, 1):
+        return None
+    names = sub["name"].tolist()
+    types = sub["type"].tolist()
+    status = sub["status"].tolist()
+    refs = sub["rereference"].tolist()
+    R = np.zeros((n, n))
+    for i in range(n):
+        R[i, i] = 1.0
+        ref = refs[i]
+        if ref is None or (isinstance(ref, float) and np.isnan(ref)) or str(ref).lower() == "none" \
+                or status[i] != "good":
+            continue
+        if ref.lower() == "average":
+            idx = [j for j in range(n) if types[j] == types[i] and status[j] == "good" and j != i]
+        else:
+            idx = []
+            for rc in ref.split("&"):
+                if rc not in names:
+                    raise ValueError("One or more of the reference channels are not part of the "
+                                     f"recording channels. First missing channel: {rc}.")
+                if rc == names[i]:
+                    raise ValueError(f"You cannot rereference to the same channel. Channel: {rc}.")
+                idx.append(names.index(rc))
+        R[i, idx] = -1.0 / len(idx)
+    good = [i for i in range(n) if status[i] == "good"]
+    return R[np.ix_(good, good)]

@@ -1,0 +1,142 @@
+"""Per-window orchestrator: drop-in for ``DataProcessor`` (stream/data_processor.py:19-311)
+plus a batch-of-windows entry point.
+
+process(data[C_all, W]) reproduces, in order: NaN mask over all incoming rows (:253),
+nan_to_num + channel pick (:255), pre-processors in PREPROCESSOR_DICT order filtered by
+membership in settings.preprocessing (processing/data_preprocessor.py:9-15,45-51), all enabled
+features in FeatureSelector order (features/feature_processor.py:45-84), feature normalisation
+of the non-"psd" keys (:263-290), and the NaN policy: every key that CONTAINS the new_name of
+a NaN channel becomes NaN (:297-306, substring match, reproduced as is).
+
+Everything up to the features is ONE launch sequence on the GPU: the channel pick and the
+re-reference matrix are folded into one [C, C_all] matrix applied on the device, notch runs per
+window on the device, features read the result from HBM/LDS.
+"""
+
+from __future__ import annotations
+
+from time import time
+
+import numpy as np
+
+from . import channels as chmod
+from . import fir_design
+from .engine import HotPathEngine
+from .processing import FeatureNormalizer
+from .settings import NMSettings
+
+PREPROCESSOR_ORDER = ["preprocessing_filter", "notch_filter", "raw_resampling", "re_referencing",
+                      "raw_normalization"]
+
+
+class DataProcessor:
+    def __init__(self, sfreq: float, settings, channels, coord_names=None, coord_list=None,
+                 line_noise: float | None = None, path_grids=None, verbose: bool = True,
+                 device: int = 0, window: int | None = None, lib=None,
+                 channel_subset=None, dry_run: bool = False) -> None:
+        self.settings = NMSettings.load(settings)
+        self.channels = chmod.load_channels(channels)
+        self.sfreq_features = self.settings.sampling_rate_features_hz
+        self._sfreq_raw_orig = sfreq
+        self.sfreq_raw = sfreq // 1
+        self.line_noise = line_noise
+        self.verbose = verbose
+        st = self.settings
+        if st.postprocessing.project_cortex or st.postprocessing.project_subcortex:
+            raise NotImplementedError("grid projection is outside the accelerated hot path")
+        self.ch_names_used, self.feature_idx, self.target_idx = chmod.channel_info(self.channels)
+        n_all = len(self.channels)
+
+        notch_taps = None
+        R = None
+        for name in st.preprocessing:
+            if name not in PREPROCESSOR_ORDER:
+                raise ValueError(f"Invalid preprocessing method '{name}'. Must be one of {PREPROCESSOR_ORDER}")
+        for name in PREPROCESSOR_ORDER:
+            if name not in st.preprocessing:
+                continue
+            if name == "notch_filter":
+                if line_noise is None:
+                    raise ValueError("Either line_noise or freqs must be defined if notch_filter is activated.")
+                notch_taps = fir_design.notch_bank(self.sfreq_raw, line_noise)
+            elif name == "raw_resampling":
+                if float(st.raw_resampling_settings.resample_freq_hz / self.sfreq_raw) != 1.0:
+                    raise NotImplementedError(
+                        "raw_resampling at a ratio != 1 is outside the accelerated path (parity "
+                        "unpinned vs MNE); set raw_resampling_settings.resample_freq_hz == sfreq. "
+                        "Note the reference keeps building features with the RAW rate "
+                        "(stream/data_processor.py:55,68,80).")
+            elif name == "re_referencing":
+                R = chmod.reref_matrix(self.channels)
+            else:
+                raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY 8f)")
+        C = len(self.feature_idx)
+        if R is not None and R.shape[0] != C:
+            raise ValueError(f"re-reference matrix is {R.shape} but {C} channels are picked for features")
+        # fold data[feature_idx] (and R) into one [C, C_all] matrix applied on the device
+        need_matrix = R is not None or self.feature_idx != list(range(n_all))
+        full = None
+        if need_matrix:
+            S = np.zeros((C, n_all))
+            S[np.arange(C), self.feature_idx] = 1.0
+            full = (R @ S) if R is not None else S
+        self.ref_matrix = R
+        # channel sharding over GPUs: this processor computes the features of a subset of the
+        # picked channels but its re-reference rows still read ALL input rows
+        self.all_ch_names_used = list(self.ch_names_used)
+        names = self.ch_names_used
+        if channel_subset is not None:
+            subset = list(channel_subset)
+            if full is None:
+                full = np.eye(n_all)
+            full = full[subset]
+            names = [self.ch_names_used[i] for i in subset]
+        self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
+                                    device=device, window=window, lib=lib, dry_run=dry_run)
+        self.keys = self.engine.keys
+        self.feature_normalizer = (FeatureNormalizer(st) if st.postprocessing.feature_normalization
+                                   else None)
+        if self.feature_normalizer is not None and not st.feature_normalization_settings.normalize_psd:
+            self.non_psd_indices = np.array([i for i, k in enumerate(self.keys) if "psd" not in k], dtype=int)
+        else:
+            self.non_psd_indices = None
+        # NaN policy: columns whose key contains the channel's new_name (substring, as the reference)
+        self._nan_cols = [np.array([i for i, k in enumerate(self.keys) if ch in k], dtype=int)
+                          for ch in self.ch_names_used]
+        self.cnt_samples = 0
+
+    # ------------------------------------------------------------------------------------
+    def _postprocess_row(self, row: np.ndarray, nan_rows: np.ndarray) -> np.ndarray:
+        if self.feature_normalizer is not None:
+            if self.non_psd_indices is not None:
+                row = row.copy()
+                row[self.non_psd_indices] = self.feature_normalizer.process(row[self.non_psd_indices])
+            else:
+                row = self.feature_normalizer.process(row)
+        if nan_rows.any():
+            if len(nan_rows) != len(self.ch_names_used):
+                # the reference indexes ch_names_used with the mask over ALL rows (:300)
+                raise IndexError("boolean index did not match: NaN handling needs every channel used")
+            row = row.copy()
+            for ci in np.where(nan_rows)[0]:
+                row[self._nan_cols[ci]] = np.nan
+        return row
+
+    def process(self, data: np.ndarray) -> dict:
+        start_time = time()
+        out, mask = self.engine.process_window(data, want_nan_mask=True)
+        row = self._postprocess_row(out.astype(np.float64), mask)
+        if self.verbose:
+            from . import logger
+
+            logger.info("Last batch took: %.3f seconds to process", time() - start_time)
+        return dict(zip(self.keys, row.tolist()))
+
+    def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
+        """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
+        applied hop by hop because the normaliser is sequential)."""
+        out, mask = self.engine.process_batch(data, starts, want_nan_mask=True)
+        out = out.astype(np.float64)
+        if self.feature_normalizer is None and not mask.any():
+            return out
+        return np.stack([self._postprocess_row(out[i], mask[i]) for i in range(len(out))])

@@ -49,8 +49,11 @@ class HotPathEngine:
                  features: Sequence[str] | None = None, ref_matrix: np.ndarray | None = None,
                  notch_taps: np.ndarray | None = None, device: int = 0,
                  lib: _lib.NmxLibrary | None = None, bank_taps: np.ndarray | None = None,
-                 sharpwave_taps: Sequence[np.ndarray] | None = None) -> None:
-        self.lib = lib if lib is not None else _lib.get_library()
+                 sharpwave_taps: Sequence[np.ndarray] | None = None,
+                 window: int | None = None, dry_run: bool = False) -> None:
+        """``dry_run=True`` only derives the plan description and the key list (no library, no
+        GPU) -- used to lay out the global column order when channels are sharded over GPUs."""
+        self.lib = None if dry_run else (lib if lib is not None else _lib.get_library())
         self.settings = settings
         self.ch_names = list(ch_names)
         self.sfreq = float(sfreq)
@@ -61,14 +64,16 @@ class HotPathEngine:
             raise NotImplementedError(
                 f"features {bad} are outside the accelerated hot path (SURVEY.md section 2)")
         self.enabled = enabled
-        self.W = int(settings.segment_length_features_ms / 1000 * sfreq)
+        # window samples as the generator cuts them (stream/generator.py:34-53)
+        self.W = int(window) if window is not None else int(settings.segment_length_features_ms / 1000 * sfreq)
         self._keep: list = []   # arrays referenced by the C struct
         self.keys: list[str] = []
         self.desc = self._build(ref_matrix, notch_taps, device, bank_taps, sharpwave_taps)
         self.n_outputs = len(self.keys)
         self.C_in = int(self.desc.n_channels_in)
         self._plan = C.c_void_p()
-        self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
+        if not dry_run:
+            self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
 
     # ------------------------------------------------------------------------------------
     def _dptr(self, arr: np.ndarray):

@@ -1,0 +1,129 @@
+"""Offline stream driver: drop-in for ``nm.Stream`` (stream/stream.py:22-345).
+
+``Stream(...).run(data) -> pd.DataFrame`` with the reference's columns (features in reference
+order, then ``time`` (:310), then target channels (:145-170)).  Where the reference loops over
+hops on one CPU thread, the whole recording is put on the GPU once and all hops are computed in
+one batch (windows are strided views of the resident array); only the sequential, tiny
+post-processing (normaliser) runs per hop on the host.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from . import channels as chmod
+from .data_processor import DataProcessor
+from .generator import window_schedule
+from .settings import NMSettings
+
+_FREQ_FEATURES = ["bandpass_filter", "stft", "fft", "welch", "bursts", "coherence", "nolds", "bispectrum"]
+
+
+class Stream:
+    def __init__(self, sfreq: float, channels=None, data=None, settings=None,
+                 line_noise: float | None = 50, sampling_rate_features_hz: float | None = None,
+                 path_grids=None, coord_names=None, coord_list=None, verbose: bool = False,
+                 device: int = 0, lib=None) -> None:
+        self.settings = NMSettings.load(settings)
+        if channels is None and data is not None:
+            channels = chmod.get_default_channels_from_data(data)
+        if channels is None and data is None:
+            raise ValueError("Either `channels` or `data` must be passed to `Stream`.")
+        self.channels = chmod.load_channels(channels)
+        if self.channels.query("used == 1 and target == 0").shape[0] == 0:
+            raise ValueError("No channels selected for analysis that have column 'used' = 1 and "
+                             "'target' = 0. Please check your channels")
+        if any(f in _FREQ_FEATURES for f in self.settings.features.get_enabled()):
+            assert all(fb[1] < sfreq / 2 for fb in self.settings.frequency_ranges_hz.values()), (
+                "If a feature that uses frequency ranges is selected, the frequency band ranges "
+                f"need to be smaller than the nyquist frequency.\nGot sfreq = {sfreq} and fband "
+                f"ranges:\n {self.settings.frequency_ranges_hz}")
+        if sampling_rate_features_hz is not None:
+            self.settings.sampling_rate_features_hz = sampling_rate_features_hz
+        self.sfreq = sfreq
+        self.line_noise = line_noise
+        self.verbose = verbose
+        self.device = device
+        self._lib = lib  # None = the product library (libnmx.so); tests may inject a binding
+        self.data = data
+        self.is_running = False
+        # fail early like the reference (it builds a DataProcessor in __init__, :130)
+        self.data_processor = self._make_processor(None)
+
+    def _make_processor(self, window):
+        return DataProcessor(sfreq=self.sfreq, settings=self.settings, channels=self.channels,
+                             line_noise=self.line_noise, verbose=self.verbose, device=self.device,
+                             window=window, lib=self._lib)
+
+    def _handle_data(self, data) -> np.ndarray:
+        names_expected = self.channels["name"].to_list()
+        if isinstance(data, np.ndarray):
+            if len(names_expected) != data.shape[0]:
+                raise ValueError("If data is passed as an array, the first dimension must match the "
+                                 f"number of channel names in `channels`.\n Number of data channels "
+                                 f"(data.shape[0]): {data.shape[0]}\n Length of channels[\"name\"]: "
+                                 f"{len(names_expected)}.")
+            return data
+        names_data = data.columns.to_list()
+        if not (len(names_expected) == len(names_data) and sorted(names_expected) == sorted(names_data)):
+            raise ValueError("If data is passed as a DataFrame, the column names must match the channel "
+                             f"names in `channels`.\nInput dataframe column names: {names_data}\n"
+                             f"Expected (from channels[\"name\"]): : {names_expected}.")
+        return data.to_numpy().transpose()
+
+    def run(self, data=None, out_dir="", experiment_name: str = "sub", save_csv: bool = True,
+            return_df: bool = True, **unused):
+        """Compute every hop of ``data`` and return the feature DataFrame."""
+        import pandas as pd
+
+        if data is not None:
+            data = self._handle_data(data)
+        elif self.data is not None:
+            data = self._handle_data(self.data)
+        else:
+            raise ValueError("No data passed to run function.")
+        self.is_running = True
+        st = self.settings
+        starts, lens, times = window_schedule(data.shape[1], self.sfreq, st.sampling_rate_features_hz,
+                                              st.segment_length_features_ms)
+        rows = np.empty((len(starts), 0))
+        keys: list[str] = []
+        if len(starts):
+            groups = sorted(set(int(x) for x in lens))
+            if len(groups) > 1 and "bursts" in st.features.get_enabled():
+                raise NotImplementedError("bursts with a non-integer hop (ragged windows) is not supported")
+            # a fresh DataProcessor per run, like the reference (:233-242), one per window length
+            procs = {w: self._make_processor(w) for w in groups}
+            self.data_processor = procs[groups[0]]
+            keys = list(self.data_processor.keys)
+            if len(groups) == 1:
+                rows = self.data_processor.process_batch(data, starts)
+            else:
+                # ragged windows (float sampling rate): the normaliser is sequential over ALL hops
+                norm = self.data_processor.feature_normalizer
+                for p in procs.values():
+                    p.feature_normalizer = None
+                raw = np.empty((len(starts), len(keys)))
+                masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
+                for w, p in procs.items():
+                    sel = np.where(lens == w)[0]
+                    o, m = p.engine.process_batch(data, starts[sel], want_nan_mask=True)
+                    raw[sel], masks[sel] = o, m
+                self.data_processor.feature_normalizer = norm
+                rows = np.stack([self.data_processor._postprocess_row(raw[i], masks[i])
+                                 for i in range(len(starts))])
+        df = pd.DataFrame(rows, columns=keys)
+        df["time"] = times
+        tgt = self.channels[self.channels["target"] == 1]
+        for idx, name in zip(tgt.index, tgt["name"].to_list()):
+            df[name] = [float(data[idx, s + n - 1]) for s, n in zip(starts, lens)]
+        self.is_running = False
+        if save_csv:
+            out = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
+            out.mkdir(parents=True, exist_ok=True)
+            df.to_csv(out / f"{experiment_name}_FEATURES.csv", index=False)
+            self.settings.save(out_dir or Path.cwd(), experiment_name)
+            self.channels.to_csv(out / f"{experiment_name}_channels.csv", index=False)
+        return df if return_df else {}

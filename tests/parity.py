@@ -7,7 +7,7 @@ in fp32, the reference in float64:
   * log10-valued features (FFT/Welch/STFT with log_transform, band-pass activity with
     log_transform): atol = 1e-5 in log10 units (a 1e-5 relative error of the underlying power
     is 4.3e-6 in log10; a pure relative test is meaningless where log10(.) crosses 0)
-  * raw: 1e-6 relative (fp32 rounding of the input sample itself)
+  * raw: 1e-6 relative + 1e-6 * data amplitude (fp32 rounding of the re-referenced sample)
   * sharp waves: values are gathers/differences of the filtered series -> atol = 1e-5 * max|y|
     (amplitudes) or 1e-5 * window length in ms (times); "var" estimators and the
     between-polarity variance square a difference of nearly equal numbers -> rtol 2e-3
@@ -50,7 +50,7 @@ def tolerances(key: str, settings, sfreq: float, amp_scale: float, W: int):
     """-> (rtol, atol) for one feature key."""
     fam = family_of(key)
     if fam == "raw":
-        return 1e-6, 1e-30
+        return 1e-6, 1e-6 * amp_scale  # re-referenced samples are differences of O(amp) values
     if fam in ("fft", "welch", "stft"):
         log = getattr(settings, f"{fam}_settings").log_transform
         return 1e-5, (1e-5 if log else 1e-5 * amp_scale * 1e-3)

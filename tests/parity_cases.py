@@ -131,3 +131,69 @@ def case_nan_mask_and_clean_on_load(lib):
     want.update(orc.LineLength(s, ["a", "b", "c"], 1000.0).calc_feature(xc))
     np.testing.assert_allclose(out, np.array(list(want.values())), rtol=1e-5)
     eng.close()
+
+
+def _pipeline_case(lib, tag, rtol_norm=False):
+    """README demo shape through the Stream mirror vs the reference DataFrame."""
+    import json
+
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("pipeline_readme")
+    s = settings_from_json(g[f"{tag}_settings_json"])
+    st = Stream(sfreq=float(g["sfreq"]), data=g["data"], settings=s, line_noise=50, lib=lib)
+    df = st.run(save_csv=False)
+    cols = [str(c) for c in g[f"{tag}_columns"]]
+    assert list(df.columns) == cols, "DataFrame columns / order differ from the reference"
+    want = g[f"{tag}_values"]
+    got = df.to_numpy(dtype=np.float64)
+    assert got.shape == want.shape
+    return s, cols, got, want
+
+
+def case_pipeline_readme_no_normalisation(lib):
+    s, cols, got, want = _pipeline_case(lib, "reref_nonorm")
+    worst = 0
+    for r in range(len(got)):
+        n_bad, rep, _ = parity.compare(cols[:-1], got[r, :-1], want[r, :-1], s, 1000.0, 1.0, 1000,
+                                       burst_slack=True)
+        assert n_bad == 0, f"row {r}\n{rep}"
+    np.testing.assert_array_equal(got[:, -1], want[:, -1])  # time column
+
+
+def case_pipeline_readme_default_zscore(lib):
+    """notch + CAR + z-score normalisation: z-scores divide by the spread of the last 30 s, so
+    fp32 feature noise is amplified by value/std; compare with an absolute tolerance in z units
+    and require near-total agreement."""
+    for tag in ("default", "nopre_norm"):
+        s, cols, got, want = _pipeline_case(lib, tag)
+        np.testing.assert_array_equal(got[:, -1], want[:, -1])
+        err = np.abs(got[:, :-1] - want[:, :-1])
+        keys = np.array(cols[:-1])
+        smooth = np.array([parity.family_of(k) not in ("bursts", "sharpwave") for k in keys])
+        # first row is returned un-normalised (normalization.py:93-97)
+        assert np.nanmax(err[1:, smooth]) < 0.05, keys[smooth][np.nanargmax(err[1:, smooth].max(axis=0))]
+        assert np.mean(err[1:, smooth] < 2e-3) > 0.99
+        assert np.mean(err[1:, ~smooth] < 2e-2) > 0.97
+
+
+def case_pipeline_nan_and_channel_table(lib):
+    import json
+
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("pipeline_nan_channels")
+    s = settings_from_json(g["settings_json"])
+    for tag in ("nan", "mix"):
+        ch = json.loads(str(g[f"{tag}_channels_json"]))
+        st = Stream(sfreq=1000.0, channels=ch, settings=s, line_noise=50, lib=lib)
+        df = st.run(g[f"{tag}_data"], save_csv=False)
+        cols = [str(c) for c in g[f"{tag}_columns"]]
+        assert list(df.columns) == cols
+        got, want = df.to_numpy(dtype=np.float64), g[f"{tag}_values"]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        for r in range(len(got)):
+            n_bad, rep, _ = parity.compare(cols, got[r], want[r], s, 1000.0, 30.0, 1000)
+            assert n_bad == 0, f"{tag} row {r}\n{rep}"

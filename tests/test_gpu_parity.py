@@ -77,3 +77,15 @@ def test_batch_equals_window_by_window_and_oracle_64ch(gpu_lib):
         n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, 1000)
         assert n_bad == 0, rep
     eng.close()
+
+
+def test_pipeline_readme_no_normalisation(gpu_lib):
+    pc.case_pipeline_readme_no_normalisation(gpu_lib)
+
+
+def test_pipeline_readme_default_zscore(gpu_lib):
+    pc.case_pipeline_readme_default_zscore(gpu_lib)
+
+
+def test_pipeline_nan_and_channel_table(gpu_lib):
+    pc.case_pipeline_nan_and_channel_table(gpu_lib)

@@ -52,3 +52,15 @@ def test_filter_window_matches_mnefilter_shape_and_values(emu_lib):
 
 def test_nan_mask_and_clean_on_load(emu_lib):
     pc.case_nan_mask_and_clean_on_load(emu_lib)
+
+
+def test_pipeline_readme_no_normalisation(emu_lib):
+    pc.case_pipeline_readme_no_normalisation(emu_lib)
+
+
+def test_pipeline_readme_default_zscore(emu_lib):
+    pc.case_pipeline_readme_default_zscore(emu_lib)
+
+
+def test_pipeline_nan_and_channel_table(emu_lib):
+    pc.case_pipeline_nan_and_channel_table(emu_lib)
