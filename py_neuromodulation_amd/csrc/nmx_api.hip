@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include "nmx_k_bank.h"
+#include "nmx_k_bank_w64.h"
 #include "nmx_k_bursts.h"
 #include "nmx_k_prep.h"
 #include "nmx_k_sharpwave.h"
 #include "nmx_k_timeosc.h"
 
+#include <cstdlib>
 #include <string>
 
 // ---- kernels: one workgroup per item, dynamic LDS carved by the host plan -----------------
@@ -22,9 +24,13 @@ __global__ void __launch_bounds__(256) nmx_kern_bank(const NmxBankArgs A) {
   const int item = blockIdx.x;
   nmx_bank_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
 }
+__global__ void __launch_bounds__(256) nmx_kern_hilbert(const NmxHilbertArgs A) {
+  nmx_hilbert_item(A, (long long)blockIdx.x, nmx_smem);
+}
+template <int CH>
 __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs A) {
   const int item = blockIdx.x;
-  nmx_burst_thr_item(A, item / A.n_bands, item % A.n_bands, nmx_smem);
+  nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
 }
 __global__ void __launch_bounds__(64) nmx_kern_burst_stat(const NmxBurstStatArgs A) {
   const int item = blockIdx.x;
@@ -93,6 +99,21 @@ static be_stream_t be_stream_create() {
   return s;
 }
 static void be_stream_destroy(be_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+// side stream for the latency-bound bursts chain: highest priority so its few waves are issued
+// ahead of the throughput kernels it overlaps with
+static be_stream_t be_stream_create_high() {
+  int lo = 0, hi = 0;
+  hipStream_t s = nullptr;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)
+    return s;
+  return be_stream_create();
+}
+typedef hipEvent_t be_event_t;
+static void be_event_create(be_event_t& e) { BE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+static void be_event_destroy(be_event_t& e) { if (e) (void)hipEventDestroy(e); }
+static void be_event_record(be_event_t& e, be_stream_t s) { BE_TRY(hipEventRecord(e, s)); }
+static void be_stream_wait(be_stream_t s, be_event_t& e) { BE_TRY(hipStreamWaitEvent(s, e, 0)); }
 static void be_timer_create(be_timer_t& t) {
   BE_TRY(hipEventCreate(&t.a));
   BE_TRY(hipEventCreate(&t.b));
@@ -128,7 +149,10 @@ static void be_init_once() {
   done = true;
   be_allow_lds(nmx_kern_timeosc);
   be_allow_lds(nmx_kern_bank);
-  be_allow_lds(nmx_kern_burst_thr);
+  be_allow_lds(nmx_kern_hilbert);
+  be_allow_lds(nmx_kern_burst_thr<32>);
+  be_allow_lds(nmx_kern_burst_thr<64>);
+  be_allow_lds(nmx_kern_burst_thr<128>);
   be_allow_lds(nmx_kern_burst_stat);
   be_allow_lds(nmx_kern_sharp);
 }
@@ -141,9 +165,27 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds
   be_init_once();
   hipLaunchKernelGGL(nmx_kern_bank, dim3(n_items), dim3(nt), lds, s, A);
 }
+extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
+extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
+static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s) {
+  static int variant = -1;
+  if (variant < 0) {
+    const char* v = getenv("NMX_W64_VARIANT");
+    variant = (v && v[0] == 's' && v[1] == 'l') ? 1 : 0;  // "slp" | "scalar" (default)
+  }
+  if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
+  else nmx_w64_launch_scalar(&A, n_items, lds, s);
+}
+static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
+}
 static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
-  hipLaunchKernelGGL(nmx_kern_burst_thr, dim3(n_items), dim3(nt), lds, s, A);
+  const int chunk = (A.K + nt - 1) / nt;
+  if (chunk <= 32) hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A);
+  else if (chunk <= 64) hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A);
+  else hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A);
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t s) {
   be_init_once();

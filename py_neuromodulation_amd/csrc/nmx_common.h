@@ -27,7 +27,16 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #define NMX_DEV __device__ __forceinline__
 #define NMX_TID ((int)threadIdx.x)
 #define NMX_NT ((int)blockDim.x)
-#define NMX_SYNC() __syncthreads()
+// Workgroup barrier.  A single-wave workgroup needs no s_barrier: its LDS operations execute
+// in order, so a compiler fence + lgkmcnt(0) is enough -- and, unlike __syncthreads(), it does
+// not drain vmcnt, i.e. it does not stall on outstanding global loads/stores (table prefetches,
+// result stores) at every phase boundary.
+#define NMX_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define NMX_SYNC()                                   \
+  do {                                               \
+    if (blockDim.x <= 64) { NMX_WAVE_FENCE(); }      \
+    else { __syncthreads(); }                        \
+  } while (0)
 #define NMX_RESTRICT __restrict__
 #endif
 

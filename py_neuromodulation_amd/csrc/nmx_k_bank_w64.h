@@ -1,0 +1,450 @@
+// nmx_k_bank_w64.h -- kernel B', the fast FIR-bank path: ONE WAVE per (window, channel),
+// circular-convolution length M = 2048 (half-length complex transform n = 1024 = 64 lanes x 16).
+//
+// CDNA4 mapping
+//   * every lane owns 16 complex points in VGPRs; a 1024-point transform is three register
+//     passes (radix 16, 16, 4) separated by TWO LDS exchanges instead of five LDS round trips,
+//     all twiddles live in VGPRs (loaded once per workgroup, reused for 1 forward + n_filters
+//     inverse transforms), no barriers across waves (single-wave workgroup).
+//   * LDS reads are always lane-consecutive ds_read_b64 (Stockham addressing); the only strided
+//     write (first pass, 16 consecutive points per lane) goes to a buffer padded by one point
+//     per 16 -> conflict-free ds_write_b64.  The exchange buffer is reused in place (a wave
+//     reads all 16 points before it writes any).
+//   * forward transform: window HBM -> registers (float2, lane-consecutive) -> pass A directly;
+//     its result Z (8 KiB) stays in LDS for all filters.
+//   * per filter the forward "split", the multiplication by the REAL tap spectrum H and the
+//     inverse "unsplit" of the half-length real-FFT trick collapse algebraically to
+//         Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),   A_k = (a+b) - (a-b) sin(2 pi k / M),
+//                                                   B_k = (a-b) cos(2 pi k / M),  a = H[k], b = H[n-k]
+//     i.e. 4 flops per point with two real tables; the Hermitian spectrum X is never formed.
+//   * epilogues from registers: band-pass activity = two-pass variance over the tail samples
+//     with wave reductions (nothing written to LDS); filtered series for sharp waves / bursts /
+//     notch are stored lane-consecutively to HBM.
+// The forward transform Z stays in VGPRs (the conjugate partner Z[n-k] is one cross-lane read from
+// lane 64 - l), so the only LDS tile is the 8.5 KiB exchange buffer -> up to 16 waves per CU.
+#pragma once
+
+#include "nmx_k_bank.h"
+
+#ifdef NMX_HOST_EMU
+#define NMX_UNROLL
+#else
+#define NMX_UNROLL _Pragma("unroll")
+#endif
+
+#ifdef NMX_HOST_EMU
+#define NMX_SCHED_FENCE() ((void)0)
+#else
+// keep the scheduler from hoisting all 16 points' loads above the first use (register pressure)
+#define NMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#define NMX_W64_N 1024
+#define NMX_W64_E 16
+// register index of point l + 64 j after pass C (v[4 t + r] = y[l + 64 t + 256 r], j = t + 4 r)
+#define NMX_J2I(j) (4 * ((j) & 3) + ((j) >> 2))
+
+struct NmxBankW64Args {
+  NmxBankArgs b;          // shared description (x, strides, filters, cols, outputs ...)
+  // per filter, k < n = M/2, th_k = 2 pi k / M, a = H[k], b = H[n-k] (real spectrum of the taps):
+  const float* Hs[NMX_MAX_FILTERS_DEV];   // A_k = (a + b) - (a - b) sin(th_k)
+  const float* Hd[NMX_MAX_FILTERS_DEV];   // B_k = (a - b) cos(th_k)
+  float* yb_out;          // burst bands: filtered series [n_windows][C][Bb][W] (Hilbert kernel input)
+  int off_Z, off_X, off_red, lds_floats;
+};
+
+#ifdef NMX_HOST_EMU
+#define NMX_LANES 64
+#define NMX_LANE_LOOP for (int l = 0; l < 64; ++l)
+#define NMX_LI l
+#define NMX_WSYNC() ((void)0)
+#else
+#define NMX_LANES 1
+#define NMX_LANE_LOOP for (int l = (int)threadIdx.x, l_once_ = 0; l_once_ < 1; ++l_once_)
+#define NMX_LI 0
+#define NMX_WSYNC() NMX_WAVE_FENCE()
+#endif
+
+// 4-point DFT, DIR = -1 forward / +1 inverse
+template <int DIR>
+NMX_DEV void nmx_dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+  const float2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+  const float2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
+  a0 = nmx_cadd(t0, t2);
+  a1 = nmx_cadd(t1, t3);
+  a2 = nmx_csub(t0, t2);
+  a3 = nmx_csub(t1, t3);
+}
+
+// in-register 16-point DFT: y_q = sum_r a_r w^(q r), w = exp(DIR 2 pi i / 16); in/out v[0..15]
+template <int DIR>
+NMX_DEV void nmx_dft16(float2* v) {
+  // step 1: for each r0, DFT4 over r1 of a[r0 + 4 r1]  -> inner[r0][q1] stored at v[r0 + 4 q1]
+NMX_UNROLL
+  for (int r0 = 0; r0 < 4; ++r0) nmx_dft4<DIR>(v[r0], v[r0 + 4], v[r0 + 8], v[r0 + 12]);
+  // step 2: twiddle inner[r0][q1] by w^(q1 r0)
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  const float sg = (float)DIR;
+  // w^1 = (c1, sg s1), w^2 = (h, sg h), w^3 = (s1, sg c1), w^4 = (0, sg), w^6 = (-h, sg h), w^9 = (-c1, -sg s1)
+  v[1 + 4] = nmx_cmul(v[1 + 4], make_float2(c1, sg * s1));   // q1=1, r0=1 : w^1
+  v[2 + 4] = nmx_cmul(v[2 + 4], make_float2(h, sg * h));     // q1=1, r0=2 : w^2
+  v[3 + 4] = nmx_cmul(v[3 + 4], make_float2(s1, sg * c1));   // q1=1, r0=3 : w^3
+  v[1 + 8] = nmx_cmul(v[1 + 8], make_float2(h, sg * h));     // q1=2, r0=1 : w^2
+  v[2 + 8] = nmx_mul_i<DIR>(v[2 + 8]);                       // q1=2, r0=2 : w^4
+  v[3 + 8] = nmx_cmul(v[3 + 8], make_float2(-h, sg * h));    // q1=2, r0=3 : w^6
+  v[1 + 12] = nmx_cmul(v[1 + 12], make_float2(s1, sg * c1));  // q1=3, r0=1 : w^3
+  v[2 + 12] = nmx_cmul(v[2 + 12], make_float2(-h, sg * h));   // q1=3, r0=2 : w^6
+  v[3 + 12] = nmx_cmul(v[3 + 12], make_float2(-c1, -sg * s1)); // q1=3, r0=3 : w^9
+  // step 3: for each q1, DFT4 over r0 -> y[q1 + 4 q0] ; store so that v[q] = y_q
+NMX_UNROLL
+  for (int q1 = 0; q1 < 4; ++q1) nmx_dft4<DIR>(v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+  // now v[4 q1 + q0] = y[q1 + 4 q0]: transpose the 4x4 index in registers
+  float2 t;
+#define NMX_SWAP(i, j) t = v[i]; v[i] = v[j]; v[j] = t;
+  NMX_SWAP(1, 4) NMX_SWAP(2, 8) NMX_SWAP(3, 12) NMX_SWAP(6, 9) NMX_SWAP(7, 13) NMX_SWAP(11, 14)
+#undef NMX_SWAP
+}
+
+// per-lane twiddle registers (forward sign; the inverse conjugates on the fly).  Only a few
+// exact table values are kept; the rest are products with compile-time constants or of at most
+// three table values (<= 3 ulp), which keeps the kernel at ~2 waves/SIMD worth of VGPRs.
+struct NmxW64Tw {
+  float2 b1, b2, b4, b8;  // pass B: exp(-2 pi i r k / 256), k = lane % 16, r = 1, 2, 4, 8
+  float2 c1, c2, c3;      // pass C: exp(-2 pi i r lane / 1024), r = 1, 2, 3
+};
+
+NMX_DEV void nmx_w64_load_tw(NmxW64Tw& T, const NmxFft& f, int lane) {
+  const int k = lane & 15;
+  T.b1 = f.tw[4 * k]; T.b2 = f.tw[8 * k]; T.b4 = f.tw[16 * k]; T.b8 = f.tw[(32 * k) & 1023];
+  T.c1 = f.tw[lane]; T.c2 = f.tw[2 * lane]; T.c3 = f.tw[3 * lane];
+}
+
+template <int DIR>
+NMX_DEV float2 nmx_twd(float2 t) { return DIR > 0 ? make_float2(t.x, -t.y) : t; }
+
+// exp(-2 pi i m / 32), m = 0..15 (split twiddle of point lane + 64 r is s0 * this[r])
+#define NMX_C32(m) make_float2(nmx_c32_re[m], nmx_c32_im[m])
+static constexpr float nmx_c32_re[16] = {
+    1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+    0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f, -0.19509032201612825f,
+    -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
+    -0.92387953251128674f, -0.98078528040323043f};
+static constexpr float nmx_c32_im[16] = {
+    -0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f,
+    -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f, -1.0f, -0.98078528040323043f,
+    -0.92387953251128674f, -0.83146961230254524f, -0.70710678118654752f, -0.55557023301960218f,
+    -0.38268343236508977f, -0.19509032201612825f};
+
+// padded physical index of the pass-A output buffer
+NMX_DEV int nmx_w64_pad(int idx) { return idx + (idx >> 4); }
+
+// Passes A (from registers) .. C (to registers).  v: 16 points per lane, in: v[r] = x[lane + 64 r]
+// out: v[4 t + r] = y[lane + 64 t + 256 r].  X = exchange buffer (>= 1024 + 64 float2).
+// Phase functions are split so the host emulator can run them lane by lane.
+template <int DIR>
+NMX_DEV void nmx_w64_passA(float2* v, float2* X, int lane) {
+  nmx_dft16<DIR>(v);
+  float2* Xo = X + 17 * lane;  // == pad(16 lane + r) for r < 16: base + constant offsets
+  NMX_UNROLL
+  for (int r = 0; r < 16; ++r) Xo[r] = v[r];
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passB_load(float2* v, const float2* X, const NmxW64Tw& T, int lane) {
+  const float2* Xi = X + lane + (lane >> 4);  // pad(lane + 64 r) = lane + lane/16 + 68 r
+  NMX_UNROLL
+  for (int r = 0; r < 16; ++r) v[r] = Xi[68 * r];
+  {
+    const float2 w1 = nmx_twd<DIR>(T.b1), w2 = nmx_twd<DIR>(T.b2), w4 = nmx_twd<DIR>(T.b4), w8 = nmx_twd<DIR>(T.b8);
+    const float2 w3 = nmx_cmul(w1, w2), w5 = nmx_cmul(w1, w4), w6 = nmx_cmul(w2, w4), w9 = nmx_cmul(w1, w8);
+    const float2 w10 = nmx_cmul(w2, w8), w12 = nmx_cmul(w4, w8);
+    v[1] = nmx_cmul(v[1], w1); v[2] = nmx_cmul(v[2], w2); v[3] = nmx_cmul(v[3], w3);
+    v[4] = nmx_cmul(v[4], w4); v[5] = nmx_cmul(v[5], w5); v[6] = nmx_cmul(v[6], w6);
+    v[7] = nmx_cmul(v[7], nmx_cmul(w3, w4)); v[8] = nmx_cmul(v[8], w8); v[9] = nmx_cmul(v[9], w9);
+    v[10] = nmx_cmul(v[10], w10); v[11] = nmx_cmul(v[11], nmx_cmul(w3, w8)); v[12] = nmx_cmul(v[12], w12);
+    v[13] = nmx_cmul(v[13], nmx_cmul(w5, w8)); v[14] = nmx_cmul(v[14], nmx_cmul(w6, w8));
+    v[15] = nmx_cmul(v[15], nmx_cmul(w3, w12));
+  }
+  nmx_dft16<DIR>(v);
+}
+NMX_DEV void nmx_w64_passB_store(const float2* v, float2* X, int lane) {
+  float2* Xo = X + (lane >> 4) * 256 + (lane & 15);
+NMX_UNROLL
+  for (int r = 0; r < 16; ++r) Xo[16 * r] = v[r];
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passC(float2* v, const float2* X, const NmxW64Tw& T, int lane) {
+NMX_UNROLL
+  for (int t = 0; t < 4; ++t) {
+    const float2* Xi = X + lane;
+    float2 a0 = Xi[64 * t], a1 = Xi[64 * t + 256], a2 = Xi[64 * t + 512], a3 = Xi[64 * t + 768];
+    // exp(-2 pi i r (lane + 64 t) / 1024) = c_r * exp(-2 pi i r t / 16) (compile-time constant)
+    a1 = nmx_cmul(a1, nmx_twd<DIR>(nmx_cmul(T.c1, NMX_C32((2 * t) & 15))));
+    a2 = nmx_cmul(a2, nmx_twd<DIR>(nmx_cmul(T.c2, NMX_C32((4 * t) & 15))));
+    a3 = nmx_cmul(a3, nmx_twd<DIR>(t == 3 ? nmx_cmul(T.c3, make_float2(-nmx_c32_re[2], -nmx_c32_im[2]))
+                                          : nmx_cmul(T.c3, NMX_C32((6 * t) & 15))));
+    nmx_dft4<DIR>(a0, a1, a2, a3);
+    v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
+  }
+}
+
+// wave reductions (single-wave workgroup)
+#ifdef NMX_HOST_EMU
+#define NMX_W64_REDUCE_SUM(acc_array, result)      \
+  { float s_ = 0.f; for (int l = 0; l < 64; ++l) s_ += acc_array[l]; result = s_; }
+#else
+#define NMX_W64_REDUCE_SUM(acc_array, result)                                  \
+  { float s_ = acc_array[0];                                                   \
+    for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_);             \
+    result = s_; }
+#endif
+
+// PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
+template <int PAD>
+NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem) {
+  const NmxBankArgs& A = AA.b;
+  float2* X = (float2*)(smem + AA.off_X);   // [1024 + 64] exchange buffer (the only LDS tile)
+  float* red = smem + AA.off_red;
+  const int W = A.W, n = NMX_W64_N;
+  float* out_row = A.out ? A.out + (long long)w * A.n_outputs : nullptr;
+  const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
+                     (A.starts ? A.starts[w] : 0ll);
+  float2 v[NMX_LANES][16];
+  float2 zr[NMX_LANES][16];   // forward transform Z, kept in registers: zr[4 t + r] = Z[l + 64 t + 256 r]
+  NmxW64Tw T[NMX_LANES];
+  NMX_LANE_LOOP { nmx_w64_load_tw(T[NMX_LI], A.fft, l); }
+
+  // ---- forward: window -> registers (packed complex, lane-consecutive) -> pass A ------------
+  if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
+    float* xs = (float*)X;
+    NMX_LANE_LOOP {
+      for (int i = l; i < W; i += 64) {
+        float t = src[i];
+        if (A.clean_on_load) t = nmx_clean(t);
+        xs[i] = t;
+      }
+    }
+    NMX_WSYNC();
+  }
+  NMX_LANE_LOOP {
+    float2* vv = v[NMX_LI];
+    if (PAD == 0) {
+      NMX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int n0 = 2 * (l + 64 * r);
+        float v0 = n0 < W ? src[n0] : 0.f, v1 = (n0 + 1) < W ? src[n0 + 1] : 0.f;
+        if (A.clean_on_load) { v0 = nmx_clean(v0); v1 = nmx_clean(v1); }
+        vv[r] = make_float2(v0, v1);
+      }
+    } else {
+      const float* xs = (const float*)X;
+      const int h = A.pad_half, ne = A.n_edge;
+      const float x0 = xs[0], xl = xs[W - 1];
+      NMX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        float e2[2];
+        for (int u = 0; u < 2; ++u) {
+          const int jp = 2 * (l + 64 * r) + u;
+          float val = 0.f;
+          if (jp < W + 2 * h) {
+            const int j = jp - h;
+            if (j < 0) val = (-j <= ne) ? 2.f * x0 - xs[-j] : 0.f;
+            else if (j < W) val = xs[j];
+            else { const int rr = j - (W - 1); val = (rr <= ne) ? 2.f * xl - xs[W - 1 - rr] : 0.f; }
+          }
+          e2[u] = val;
+        }
+        vv[r] = make_float2(e2[0], e2[1]);
+      }
+    }
+  }
+  NMX_WSYNC();  // (pad_mode 1: everyone has read xs before X is overwritten)
+  NMX_LANE_LOOP { nmx_w64_passA<-1>(v[NMX_LI], X, l); }
+  NMX_WSYNC();
+  NMX_LANE_LOOP { nmx_w64_passB_load<-1>(v[NMX_LI], X, T[NMX_LI], l); }
+  NMX_WSYNC();
+  NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
+  NMX_WSYNC();
+  NMX_LANE_LOOP {
+    float2* vv = v[NMX_LI];
+    nmx_w64_passC<-1>(vv, X, T[NMX_LI], l);
+    NMX_UNROLL
+    for (int i = 0; i < 16; ++i) zr[NMX_LI][i] = vv[i];
+  }
+  NMX_WSYNC();
+
+  const int yoff = (PAD == 1) ? A.pad_half : 0;
+  for (int fi = 0; fi < A.n_filters; ++fi) {
+    const NmxFilterDev& F = A.f[fi];
+    const float* NMX_RESTRICT Hs = AA.Hs[fi];
+    const float* NMX_RESTRICT Hd = AA.Hd[fi];
+    // ---- fused split * H * unsplit into registers, then inverse passes -----------------------
+    NMX_LANE_LOOP {
+      float2* vv = v[NMX_LI];
+      NMX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        // k = l + 64 r lives in register j2i(r); its partner n - k = (64 - l) + 64 (15 - r) lives in
+        // lane (64 - l) & 63, register j2i(15 - r)  (lane 0: its own register j2i(16 - r), Z[n] = Z[0])
+        const float2 zk = zr[NMX_LI][NMX_J2I(r)];
+#ifdef NMX_HOST_EMU
+        float2 zc = zr[(64 - l) & 63][NMX_J2I(15 - r)];
+#else
+        const float2 zs = zr[0][NMX_J2I(15 - r)];
+        float2 zc = make_float2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
+#endif
+        if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
+        const float ha = (Hs + l)[64 * r], hb = (Hd + l)[64 * r];
+        // Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),  A = Hs - Hd sin(th_k), B = Hd cos(th_k)
+        vv[r] = make_float2(ha * zk.x + hb * zc.y, ha * zk.y + hb * zc.x);
+        if ((r & 3) == 3) NMX_SCHED_FENCE();
+      }
+      nmx_w64_passA<+1>(vv, X, l);
+    }
+    NMX_WSYNC();
+    NMX_LANE_LOOP { nmx_w64_passB_load<+1>(v[NMX_LI], X, T[NMX_LI], l); }
+    NMX_WSYNC();
+    NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
+    NMX_WSYNC();
+    NMX_LANE_LOOP { nmx_w64_passC<+1>(v[NMX_LI], X, T[NMX_LI], l); }
+    // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
+
+    if (F.bp_seglen > 0) {
+      const bool need_mc = (A.bp_features & 6u) != 0;
+      if (!need_mc) {  // activity only: variance straight from registers
+        const int lo = W - F.bp_seglen + yoff, hi = W + yoff;
+        float part[NMX_LANES];
+        NMX_LANE_LOOP {
+          float s = 0.f;
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i) {
+            const int m = l + 64 * (i >> 2) + 256 * (i & 3);
+            const float2 val = v[NMX_LI][i];
+            if (2 * m >= lo && 2 * m < hi) s += val.x;
+            if (2 * m + 1 >= lo && 2 * m + 1 < hi) s += val.y;
+          }
+          part[NMX_LI] = s;
+        }
+        float tot;
+        NMX_W64_REDUCE_SUM(part, tot);
+        const float mean = tot / (float)F.bp_seglen;
+        NMX_LANE_LOOP {
+          float s = 0.f;
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i) {
+            const int m = l + 64 * (i >> 2) + 256 * (i & 3);
+            const float2 val = v[NMX_LI][i];
+            if (2 * m >= lo && 2 * m < hi) { const float d = val.x - mean; s += d * d; }
+            if (2 * m + 1 >= lo && 2 * m + 1 < hi) { const float d = val.y - mean; s += d * d; }
+          }
+          part[NMX_LI] = s;
+        }
+        NMX_W64_REDUCE_SUM(part, tot);
+        const float act = tot / (float)F.bp_seglen;
+        NMX_LANE_LOOP {
+          if (l == 0) {
+            const int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
+            out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act);
+          }
+        }
+      } else {  // mobility / complexity need neighbours: go through LDS (natural order)
+        NMX_WSYNC();
+        NMX_LANE_LOOP {
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i) X[l + 64 * (i >> 2) + 256 * (i & 3)] = v[NMX_LI][i];
+        }
+        NMX_WSYNC();
+        const float* y = (const float*)X + yoff;
+        float act, mob, comp;
+        nmx_hjorth(y + (W - F.bp_seglen), F.bp_seglen, red, 1, true, act, mob, comp);
+        if (NMX_TID == 0) {
+          int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
+          if (A.bp_features & 1u) { out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act); col += A.bp_cols.b_stride; }
+          if (A.bp_features & 2u) { out_row[col] = nmx_nan_to_num(mob); col += A.bp_cols.b_stride; }
+          if (A.bp_features & 4u) out_row[col] = nmx_nan_to_num(comp);
+        }
+      }
+    }
+    // ---- filtered series to HBM (lane-consecutive) ---------------------------------------------
+    if (PAD == 0) {
+      float* dsw = F.sw_index >= 0
+          ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
+      float* dyb = F.burst_index >= 0
+          ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
+      const bool vec = ((W & 1) == 0);   // rows start 8-byte aligned when W is even
+      NMX_LANE_LOOP {
+        NMX_UNROLL
+        for (int i = 0; i < 16; ++i) {
+          const int m = 64 * (i >> 2) + 256 * (i & 3);   // + l
+          const float2 val = v[NMX_LI][i];
+          if (2 * (m + l) + 1 < W) {
+            if (vec) {
+              if (dsw) ((float2*)dsw + l)[m] = val;
+              if (dyb) ((float2*)dyb + l)[m] = val;
+            } else {
+              if (dsw) { (dsw + 2 * l)[2 * m] = val.x; (dsw + 2 * l)[2 * m + 1] = val.y; }
+              if (dyb) { (dyb + 2 * l)[2 * m] = val.x; (dyb + 2 * l)[2 * m + 1] = val.y; }
+            }
+          } else if (2 * (m + l) < W) {
+            if (dsw) (dsw + 2 * l)[2 * m] = val.x;
+            if (dyb) (dyb + 2 * l)[2 * m] = val.x;
+          }
+        }
+      }
+    } else if (F.store_raw) {
+      float* d2 = A.y_out + ((long long)w * A.n_channels + c) * W - yoff;
+      NMX_LANE_LOOP {
+        NMX_UNROLL
+        for (int i = 0; i < 16; ++i) {
+          const int s0 = 2 * (l + 64 * (i >> 2) + 256 * (i & 3));
+          const float2 val = v[NMX_LI][i];
+          if (s0 >= yoff && s0 < W + yoff) d2[s0] = val.x;
+          if (s0 + 1 >= yoff && s0 + 1 < W + yoff) d2[s0 + 1] = val.y;
+        }
+      }
+    }
+    NMX_WSYNC();
+  }
+}
+
+// ---- Hilbert envelope kernel: y[item][W] -> |analytic(y)| (exact length-W transforms) ----------
+struct NmxHilbertArgs {
+  const float* y;   // [n_items][W]
+  float* env;       // [n_items][W]
+  int W;
+  NmxFft hil_r;     // complex length W/2 (W even) or W (odd)
+  NmxFft hil_c;     // complex length W
+  int hil_full;
+  int off_a, off_b, lds_floats;
+};
+
+NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* smem) {
+  float2* bufA = (float2*)(smem + A.off_a);
+  float2* bufB = (float2*)(smem + A.off_b);
+  const int W = A.W, Wh = W >> 1;
+  const float* src = A.y + item * W;
+  if (A.hil_full) {
+    for (int i = NMX_TID; i < W; i += NMX_NT) bufB[i] = make_float2(src[i], 0.f);
+  } else {
+    for (int i = NMX_TID; i < Wh; i += NMX_NT) bufB[i] = make_float2(src[2 * i], src[2 * i + 1]);
+  }
+  NMX_SYNC();
+  const float2* Zy = nmx_fft<-1>(A.hil_r, bufB, bufA, bufB);
+  float2* Ab = (Zy == bufA) ? bufB : bufA;
+  const float invW = 1.f / (float)W;
+  // one-sided spectrum; Zy (W/2 points) and Ab (W points) live in different buffers
+  for (int k = NMX_TID; k < W; k += NMX_NT) {
+    float2 val = make_float2(0.f, 0.f);
+    if (A.hil_full) {
+      if (k == 0) val = Zy[0];
+      else if (k <= (W - 1) / 2) val = make_float2(2.f * Zy[k].x, 2.f * Zy[k].y);
+    } else if (k <= Wh) {
+      val = nmx_rfft_bin(Zy, A.hil_r.twr, Wh, k);
+      if (k != 0 && k != Wh) val = make_float2(2.f * val.x, 2.f * val.y);
+    }
+    Ab[k] = make_float2(val.x * invW, val.y * invW);
+  }
+  NMX_SYNC();
+  float2* Zbuf = (Ab == bufA) ? bufB : bufA;
+  const float2* an = nmx_fft<+1>(A.hil_c, Ab, Zbuf, Ab);
+  float* dst = A.env + item * W;
+  for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
+}

@@ -20,6 +20,9 @@
 #pragma once
 
 #include "nmx_device.h"
+#ifdef NMX_HOST_EMU
+#include <vector>
+#endif
 
 struct NmxBurstThrArgs {
   const float* env;     // [n_windows][C][Bb][W]
@@ -73,61 +76,145 @@ NMX_DEV int nmx_count_ge(const float* l, int n, float v) {
   return lo;
 }
 
+// first index j in ascending ins[0..n) with ins[j] > i  (== number of ins values <= i)
+NMX_DEV int nmx_upper_bound_i(const int* ins, int n, int i) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ins[mid] <= i) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// One hop of the sequential threshold walk costs ~4 barriers: rank the new samples by counting
+// (broadcast LDS reads, no dependent chain), one binary search per NEW sample into the list,
+// then an in-place merge in which every thread stages a contiguous chunk of the list in
+// registers and writes it back shifted (merge path) -- no second list buffer, so two
+// workgroups of this kernel only hold ~70 KiB of a CU's LDS and other kernels can overlap.
+template <int CH>
 NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
-  float* l0 = smem + A.off_l0;
-  float* l1 = smem + A.off_l1;
-  float* pc = smem + A.off_p;
+  float* L = smem + A.off_l0;
+  float* pc = smem + A.off_p;            // [P2] raw new samples
+  float* ps = pc + A.P2;                 // [P2] sorted (descending) new samples
+  int* ins = (int*)(ps + A.P2);          // [P2] insertion index of ps[j] into L
   const int K = A.K, W = A.W;
   const long long sidx = (long long)c * A.n_bands + bi;
-  long long total = A.counts[2 * sidx];       // samples appended so far
-  long long nwin = A.counts[2 * sidx + 1];    // windows seen so far
+  long long total = A.counts[2 * sidx];
+  long long nwin = A.counts[2 * sidx + 1];
   int len = (int)(total < K ? total : K);
   float* gtop = A.top + sidx * K;
-  for (int i = NMX_TID; i < len; i += NMX_NT) l0[i] = gtop[i];
-  NMX_SYNC();
-  float* cur = l0;
-  float* nxt = l1;
+  for (int i = NMX_TID; i < len; i += NMX_NT) L[i] = gtop[i];
+  const int chunk = (K + NMX_NT - 1) / NMX_NT;   // <= CH
+  const int i0 = NMX_TID * chunk;
+#ifdef NMX_HOST_EMU
+  std::vector<float> vals_store(K > 0 ? K : 1);
+  float* vals = vals_store.data();
+  const int CHB = chunk;   // the emulator's single "thread" owns the whole list
+#else
+  float vals[CH];
+  constexpr int CHB = CH;
+#endif
+  // software prefetch of the next hop's new samples (one per thread) hides the HBM latency
+  const bool can_prefetch = A.overlap <= NMX_NT;
+  float pre = 0.f;
+  bool have_pre = false;
   for (int w = 0; w < A.n_windows; ++w) {
     const int n_new = (nwin == 0) ? W : A.overlap;
+    int n4 = (n_new + 3) & ~3;   // pc is padded with -inf to a multiple of 4 (float4 reads)
     const float* e = A.env + (((long long)w * A.n_channels + c) * A.n_bands + bi) * W + (W - n_new);
-    int n2 = 1;
-    while (n2 < n_new) n2 <<= 1;
-    for (int i = NMX_TID; i < n2; i += NMX_NT) pc[i] = i < n_new ? e[i] : -INFINITY;
+    if (have_pre) {
+      if (NMX_TID < n_new) pc[NMX_TID] = pre;
+    } else {
+      for (int i = NMX_TID; i < n_new; i += NMX_NT) pc[i] = e[i];
+    }
+    for (int i = n_new + NMX_TID; i < n4; i += NMX_NT) pc[i] = -INFINITY;
+    have_pre = false;
+    if (can_prefetch && w + 1 < A.n_windows) {
+      const float* en = A.env + (((long long)(w + 1) * A.n_channels + c) * A.n_bands + bi) * W + (W - A.overlap);
+      if (NMX_TID < A.overlap) pre = en[NMX_TID];
+      have_pre = true;
+    }
     NMX_SYNC();
-    nmx_bitonic_desc(pc, n2);
-    // merge (descending); equal values: list elements first
-    for (int i = NMX_TID; i < len; i += NMX_NT) {
-      const float v = cur[i];
-      const int pos = i + nmx_count_gt(pc, n_new, v);
-      if (pos < K) nxt[pos] = v;
+    // 1. rank by counting -> ps descending (ties keep input order); float4 broadcast reads
+    for (int t = NMX_TID; t < n_new; t += NMX_NT) {
+      const float v = pc[t];
+      int rank = 0;
+#ifndef NMX_HOST_EMU
+#pragma unroll 8
+#endif
+      for (int j = 0; j < n4; j += 4) {
+        const float u0 = pc[j], u1 = pc[j + 1], u2 = pc[j + 2], u3 = pc[j + 3];
+        rank += (u0 > v) || (u0 == v && j < t);
+        rank += (u1 > v) || (u1 == v && j + 1 < t);
+        rank += (u2 > v) || (u2 == v && j + 2 < t);
+        rank += (u3 > v) || (u3 == v && j + 3 < t);
+      }
+      ps[rank] = v;
+    }
+    NMX_SYNC();
+    // 2. insertion index of each new sample (after all list entries >= it)
+    for (int j = NMX_TID; j < n_new; j += NMX_NT) ins[j] = nmx_count_ge(L, len, ps[j]);
+    // stage my chunk of the list in registers
+    const int i1 = (i0 + chunk) < len ? (i0 + chunk) : len;
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+    for (int k = 0; k < CHB; ++k) {
+      if (k < chunk && i0 + k < i1) vals[k] = L[i0 + k];
+    }
+    NMX_SYNC();
+    // 3. shifted write-back (merge path): entry i moves down by the number of new samples > L[i]
+    if (i0 < i1) {
+      int cnt = nmx_upper_bound_i(ins, n_new, i0);
+      const int cnt_end = nmx_upper_bound_i(ins, n_new, i1 - 1);
+      if (cnt == cnt_end) {   // common case: no new sample lands inside my chunk
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+        for (int k = 0; k < CHB; ++k) {
+          const int i = i0 + k;
+          if (k < chunk && i < i1 && i + cnt < K) L[i + cnt] = vals[k];
+        }
+      } else {
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+        for (int k = 0; k < CHB; ++k) {
+          const int i = i0 + k;
+          if (k < chunk && i < i1) {
+            while (cnt < n_new && ins[cnt] <= i) ++cnt;
+            const int pos = i + cnt;
+            if (pos < K) L[pos] = vals[k];
+          }
+        }
+      }
     }
     for (int j = NMX_TID; j < n_new; j += NMX_NT) {
-      const float v = pc[j];
-      const int pos = j + nmx_count_ge(cur, len, v);
-      if (pos < K) nxt[pos] = v;
+      const int pos = ins[j] + j;
+      if (pos < K) L[pos] = ps[j];
     }
     NMX_SYNC();
     len = (len + n_new) < K ? (len + n_new) : K;
     total += n_new;
     nwin += 1;
-    float* t = cur; cur = nxt; nxt = t;
     if (NMX_TID == 0) {
       const long long m = total < A.n_ring ? total : A.n_ring;
       const double pos = A.q * (double)(m - 1);
       const long long lo = (long long)floor(pos);
       const double frac = pos - (double)lo;
-      const double a = (double)cur[m - 1 - lo];
+      const double a = (double)L[m - 1 - lo];
       double r = a;
       if (lo + 1 <= m - 1) {
-        const double b = (double)cur[m - 2 - lo];
+        const double b = (double)L[m - 2 - lo];
         const double d = b - a;
         r = (frac >= 0.5) ? b - d * (1.0 - frac) : a + d * frac;  // NumPy _lerp
       }
       A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] = (float)r;
     }
-    NMX_SYNC();
+    // (no barrier needed here: the next hop only reads L until its own barrier 2)
   }
-  for (int i = NMX_TID; i < len; i += NMX_NT) gtop[i] = cur[i];
+  NMX_SYNC();
+  for (int i = NMX_TID; i < len; i += NMX_NT) gtop[i] = L[i];
   if (NMX_TID == 0) {
     A.counts[2 * sidx] = total;
     A.counts[2 * sidx + 1] = nwin;

@@ -1,19 +1,33 @@
 // nmx_k_sharpwave.h -- kernel E: SharpwaveAnalyzer.analyze_waveform + estimators
 // (features/sharpwaves.py:259-328,330-465) for one pre-filtered series per WAVE.
 //
-// Work per item ((window, channel, filter), both polarities): local maxima with SciPy's
+// Work per item ((window, channel, filter), both polarities): local extrema with SciPy's
 // plateau rule, SciPy's priority-ordered `distance` suppression (greedy by height, solved
 // here as a parallel fixed point -- a peak is kept once every higher neighbour within
 // `distance` is removed, removed once a higher neighbour is kept), trough <-> peak pairing,
-// the 13 per-trough quantities and the estimators.  Everything lives in LDS; ordered
-// compaction uses contiguous per-lane chunks + a wave prefix sum so results are
-// deterministic.  Ties of equal height inside `distance`: the later peak wins (SciPy's own
-// order there is NumPy's unstable argsort, i.e. implementation-defined).
+// the 13 per-trough quantities and the estimators.
+//
+// The kernel is latency bound (a few thousand instructions per series, long dependent chains),
+// so the structure minimises dependent LDS round trips and wave-wide reductions:
+//   * maxima AND minima are detected in ONE pass over per-lane contiguous chunks held in
+//     registers (the "Trough" polarity analyses -y, whose peaks are y's minima: the two raw
+//     extrema lists serve all four find_peaks calls of the reference);
+//   * the two distance selections of a polarity run in the same fixed-point loop and share its
+//     barriers / ballot; peaks without any neighbour inside `distance` are settled up front;
+//   * ordered compaction = per-lane chunk + one wave prefix sum (deterministic output order);
+//   * index lists are 16-bit, scratch arrays are aliased: ~11 KiB LDS per series.
+// Ties of equal height inside `distance`: the later peak wins (SciPy's own order there is
+// NumPy's unstable argsort, i.e. implementation-defined).
 #pragma once
 
 #include "nmx_device.h"
 
 #include "../../include/nmx.h"  // NMX_SW_* feature ids and NMX_SWE_* estimator ids
+#ifdef NMX_HOST_EMU
+#include <vector>
+#endif
+
+typedef unsigned short nmx_u16;
 
 struct NmxSharpArgs {
   const float* y;   // [n_windows][C][n_filters][W] pre-filtered series
@@ -31,15 +45,20 @@ struct NmxSharpArgs {
   NmxCols cols;       // a = filter, b = slot (x n_polarities + polarity when !between)
   NmxCols np_cols;    // num_peaks (between mode), a = filter
   int has_num_peaks;
-  int off_z, off_pk, off_tr, off_st, off_lf, off_rt, off_vals, off_res, off_red, lds_floats;
+  // LDS carve (float offsets): z[W] | emax,emin,selP,selT,lf,rt (u16[pm]) | st (u8[2 pm]) | vals | res | red
+  int off_z, off_emax, off_emin, off_selp, off_selt, off_lf, off_rt, off_st, off_vals, off_res, off_red;
+  int pm;           // capacity of the index lists (W / 2 + 2)
+  int lds_floats;
 };
 
 #ifdef NMX_HOST_EMU
 NMX_DEV int nmx_wave_excl_sum_i(int v, int* total) { *total = v; return 0; }
+NMX_DEV int nmx_wave_any(int v) { return v; }
 #else
 NMX_DEV int nmx_wave_excl_sum_i(int v, int* total) {
   const int lane = threadIdx.x & 63;
   int inc = v;
+#pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(inc, o);
     if (lane >= o) inc += t;
@@ -47,96 +66,140 @@ NMX_DEV int nmx_wave_excl_sum_i(int v, int* total) {
   *total = __shfl(inc, 63);
   return inc - v;
 }
+NMX_DEV int nmx_wave_any(int v) { return __any(v); }
 #endif
 
-// local maxima of sgn * z (SciPy _local_maxima_1d), ordered, into pos[]; returns count
-NMX_DEV int nmx_local_maxima(const float* z, float sgn, int W, int* pos) {
-  const int n_idx = W - 2;  // candidate indices 1 .. W-2
+// ---- extrema detection -----------------------------------------------------------------------
+// SciPy _local_maxima_1d on z (maxima) and on -z (minima) in one pass.  Lane chunk [i0, i1);
+// a plateau is owned by the lane of its first sample; its midpoint may lie beyond the chunk.
+NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min) {
+  const int n_idx = W - 2;
   const int chunk = n_idx > 0 ? (n_idx + NMX_NT - 1) / NMX_NT : 0;
   const int i0 = 1 + NMX_TID * chunk;
   const int i1 = (i0 + chunk) < (W - 1) ? (i0 + chunk) : (W - 1);
-  int cnt = 0;
+  int cmax = 0, cmin = 0;
   for (int pass = 0; pass < 2; ++pass) {
-    int base = 0;
+    int bmax = 0, bmin = 0;
     if (pass == 1) {
       int total;
-      base = nmx_wave_excl_sum_i(cnt, &total);
-      cnt = total;
+      const int packed = cmax | (cmin << 16);
+      const int base = nmx_wave_excl_sum_i(packed, &total);
+      bmax = base & 0xffff;
+      bmin = base >> 16;
+      *n_max = total & 0xffff;
+      *n_min = total >> 16;
     }
-    int k = 0;
-    for (int i = i0; i < i1; ++i) {
-      const float v = sgn * z[i];
-      if (sgn * z[i - 1] < v) {
-        int ahead = i + 1;
-        while (ahead < W - 1 && sgn * z[ahead] == v) ++ahead;
-        if (sgn * z[ahead] < v) {
-          if (pass == 1) pos[base + k] = (i + ahead - 1) >> 1;
-          ++k;
+    int kmax = 0, kmin = 0;
+    if (i0 < i1) {
+      float prev = z[i0 - 1], cur = z[i0];
+      for (int i = i0; i < i1; ++i) {
+        const float nxt = z[i + 1];
+        if (prev < cur) {          // candidate maximum (plateau start)
+          int ahead = i + 1;
+          float a = nxt;
+          while (a == cur && ahead < W - 1) { ++ahead; a = z[ahead]; }
+          if (a < cur) {
+            if (pass == 1) emax[bmax + kmax] = (nmx_u16)((i + ahead - 1) >> 1);
+            ++kmax;
+          }
+        } else if (prev > cur) {   // candidate minimum
+          int ahead = i + 1;
+          float a = nxt;
+          while (a == cur && ahead < W - 1) { ++ahead; a = z[ahead]; }
+          if (a > cur) {
+            if (pass == 1) emin[bmin + kmin] = (nmx_u16)((i + ahead - 1) >> 1);
+            ++kmin;
+          }
         }
+        prev = cur;
+        cur = nxt;
       }
     }
-    if (pass == 0) cnt = k;
+    if (pass == 0) { cmax = kmax; cmin = kmin; }
   }
   NMX_SYNC();
-  return cnt;
 }
 
-// SciPy _select_by_peak_distance: in-place state st[] (1 keep, 2 removed), then ordered
-// compaction of pos[] ; returns the new count
-NMX_DEV int nmx_select_by_distance(const float* z, float sgn, int* pos, int n, int dist, int* st,
-                                   float* red) {
-  if (dist <= 1 || n <= 1) return n;
-  for (int j = NMX_TID; j < n; j += NMX_NT) st[j] = 0;
+// ---- distance selection (two problems per call share barriers) -------------------------------
+struct NmxSelProb {
+  const nmx_u16* pos;   // raw extrema (ascending positions)
+  int n;
+  float sgn;            // +1: maxima of z, -1: maxima of -z
+  int dist;
+  unsigned char* st;    // 0 undecided, 1 keep, 2 removed
+  nmx_u16* out;         // compacted survivors
+  int n_out;
+};
+
+NMX_DEV void nmx_select2(const float* z, NmxSelProb* P) {
+  // settle peaks without neighbours inside `dist`
+  for (int p = 0; p < 2; ++p) {
+    const NmxSelProb& Q = P[p];
+    for (int j = NMX_TID; j < Q.n; j += NMX_NT) {
+      unsigned char s = 1;
+      if (Q.dist > 1) {
+        const int pj = Q.pos[j];
+        const bool nl = (j > 0) && (pj - (int)Q.pos[j - 1] < Q.dist);
+        const bool nr = (j + 1 < Q.n) && ((int)Q.pos[j + 1] - pj < Q.dist);
+        s = (nl || nr) ? 0 : 1;
+      }
+      Q.st[j] = s;
+    }
+  }
   NMX_SYNC();
   for (;;) {
     int undecided = 0;
-    for (int j = NMX_TID; j < n; j += NMX_NT) {
-      if (st[j] != 0) continue;
-      const int pj = pos[j];
-      const float vj = sgn * z[pj];
-      bool removed = false, wait = false;
-      for (int k = j - 1; k >= 0 && pj - pos[k] < dist; --k) {
-        const float vk = sgn * z[pos[k]];
-        if (vk > vj) {  // strictly higher; equal height: the later index (j) has priority
-          const int s = st[k];
-          if (s == 1) removed = true; else if (s == 0) wait = true;
+    for (int p = 0; p < 2; ++p) {
+      const NmxSelProb& Q = P[p];
+      for (int j = NMX_TID; j < Q.n; j += NMX_NT) {
+        if (Q.st[j] != 0) continue;
+        const int pj = Q.pos[j];
+        const float vj = Q.sgn * z[pj];
+        bool removed = false, wait = false;
+        for (int k = j - 1; k >= 0 && pj - (int)Q.pos[k] < Q.dist; --k) {
+          if (Q.sgn * z[Q.pos[k]] > vj) {  // strictly higher; equal height: later index wins
+            const int s = Q.st[k];
+            if (s == 1) removed = true; else if (s == 0) wait = true;
+          }
         }
-      }
-      for (int k = j + 1; k < n && pos[k] - pj < dist; ++k) {
-        const float vk = sgn * z[pos[k]];
-        if (vk >= vj) {
-          const int s = st[k];
-          if (s == 1) removed = true; else if (s == 0) wait = true;
+        for (int k = j + 1; k < Q.n && (int)Q.pos[k] - pj < Q.dist; ++k) {
+          if (Q.sgn * z[Q.pos[k]] >= vj) {
+            const int s = Q.st[k];
+            if (s == 1) removed = true; else if (s == 0) wait = true;
+          }
         }
+        if (removed) Q.st[j] = 2;
+        else if (!wait) Q.st[j] = 1;
+        else undecided = 1;
       }
-      if (removed) st[j] = 2;
-      else if (!wait) st[j] = 1;
-      else undecided = 1;
     }
     NMX_SYNC();
-    if (!nmx_block_or(undecided, red)) break;
+    if (!nmx_wave_any(undecided)) break;
   }
-  // ordered compaction of kept peaks (in place is safe: write index <= read index, but lanes
-  // run concurrently -> stage through registers per chunk)
-  const int chunk = (n + NMX_NT - 1) / NMX_NT;
-  const int i0 = NMX_TID * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
-  int cnt = 0;
-  for (int i = i0; i < i1; ++i) cnt += (st[i] == 1);
+  // ordered compaction of both lists with one prefix sum
+  int cnt[2], i0[2], i1[2];
+  for (int p = 0; p < 2; ++p) {
+    const int chunk = (P[p].n + NMX_NT - 1) / NMX_NT;
+    i0[p] = NMX_TID * chunk;
+    i1[p] = (i0[p] + chunk) < P[p].n ? (i0[p] + chunk) : P[p].n;
+    int c = 0;
+    for (int i = i0[p]; i < i1[p]; ++i) c += (P[p].st[i] == 1);
+    cnt[p] = c;
+  }
   int total;
-  const int base = nmx_wave_excl_sum_i(cnt, &total);
-  // second array needed: reuse st as destination after reading my chunk's kept positions
-  int k = 0;
+  const int base = nmx_wave_excl_sum_i(cnt[0] | (cnt[1] << 16), &total);
+  const int b[2] = {base & 0xffff, base >> 16};
+  P[0].n_out = total & 0xffff;
+  P[1].n_out = total >> 16;
+  for (int p = 0; p < 2; ++p) {
+    int k = 0;
+    for (int i = i0[p]; i < i1[p]; ++i)
+      if (P[p].st[i] == 1) { P[p].out[b[p] + k] = P[p].pos[i]; ++k; }
+  }
   NMX_SYNC();
-  // two-step: first write compacted positions into st-sized scratch held in registers is not
-  // possible for arbitrary chunk sizes; encode instead: st[i] = kept ? pos[i] : -1, then gather
-  for (int i = i0; i < i1; ++i) st[i] = (st[i] == 1) ? pos[i] : -1;
-  NMX_SYNC();
-  for (int i = i0; i < i1; ++i)
-    if (st[i] >= 0) { pos[base + k] = st[i]; ++k; }
-  NMX_SYNC();
-  return total;
 }
 
+// ---- estimators --------------------------------------------------------------------------------
 NMX_DEV float nmx_sw_estimate(int est, const float* v, int n, float* red) {
   if (n == 0) return 0.f;  // sharpwaves.py:294: empty -> 0
   switch (est) {
@@ -165,11 +228,13 @@ NMX_DEV float nmx_sw_pair(int est, float a, float b) {
 // one WAVE per (window, channel, filter)
 NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* smem) {
   float* z = smem + A.off_z;
-  int* pk = (int*)(smem + A.off_pk);
-  int* tr = (int*)(smem + A.off_tr);
-  int* st = (int*)(smem + A.off_st);
-  int* lf = (int*)(smem + A.off_lf);
-  int* rt = (int*)(smem + A.off_rt);
+  nmx_u16* emax = (nmx_u16*)(smem + A.off_emax);
+  nmx_u16* emin = (nmx_u16*)(smem + A.off_emin);
+  nmx_u16* selP = (nmx_u16*)(smem + A.off_selp);
+  nmx_u16* selT = (nmx_u16*)(smem + A.off_selt);
+  nmx_u16* lf = (nmx_u16*)(smem + A.off_lf);
+  nmx_u16* rt = (nmx_u16*)(smem + A.off_rt);
+  unsigned char* st = (unsigned char*)(smem + A.off_st);
   float* vals = smem + A.off_vals;
   float* res = smem + A.off_res;   // [2][n_combos] + [2] num_peaks
   float* red = smem + A.off_red;
@@ -177,39 +242,63 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
   const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
   for (int i = NMX_TID; i < W; i += NMX_NT) z[i] = src[i];
   NMX_SYNC();
+  int n_max = 0, n_min = 0;
+  nmx_extrema(z, W, emax, emin, &n_max, &n_min);
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
   for (int pol = 0; pol < 2; ++pol) {
     if ((pol == 0 && !A.est_peaks) || (pol == 1 && !A.est_troughs)) continue;
     const float sgn = pol == 0 ? 1.f : -1.f;   // "Trough" analysis runs on -y
-    // peaks of sgn*z (distance_peaks) and troughs = peaks of -sgn*z (distance_troughs)
-    int nPk = nmx_local_maxima(z, sgn, W, pk);
-    nPk = nmx_select_by_distance(z, sgn, pk, nPk, A.dist_peaks, st, red);
-    int nTr = nmx_local_maxima(z, -sgn, W, tr);
-    nTr = nmx_select_by_distance(z, -sgn, tr, nTr, A.dist_troughs, st, red);
-    // pairing (sharpwaves.py:347-374)
+    // peaks of sgn*z with distance_peaks, troughs (= peaks of -sgn*z) with distance_troughs
+    NmxSelProb P[2];
+    P[0].pos = pol == 0 ? emax : emin; P[0].n = pol == 0 ? n_max : n_min; P[0].sgn = sgn;
+    P[0].dist = A.dist_peaks; P[0].st = st; P[0].out = selP; P[0].n_out = 0;
+    P[1].pos = pol == 0 ? emin : emax; P[1].n = pol == 0 ? n_min : n_max; P[1].sgn = -sgn;
+    P[1].dist = A.dist_troughs; P[1].st = st + A.pm; P[1].out = selT; P[1].n_out = 0;
+    nmx_select2(z, P);
+    const int nPk = P[0].n_out, nTr = P[1].n_out;
+    const nmx_u16* pk = selP;
+    const nmx_u16* tr = selT;
+    // pairing (sharpwaves.py:347-374): ptr = first peak at or after the trough
     int n_leftinv = 0, lastv = 0, n_pairs = 0;
     for (int i = NMX_TID; i < nTr; i += NMX_NT) {
       const int t = tr[i];
-      int lo = 0, hi = nPk;   // first peak with pos >= t
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (pk[mid] < t) lo = mid + 1; else hi = mid; }
-      st[i] = lo;
+      int lo = 0, hi = nPk;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pk[mid] < t) lo = mid + 1; else hi = mid; }
+      lf[i] = (nmx_u16)lo;   // temporarily the pointer
       if (lo == 0) ++n_leftinv;
       else if (lo < nPk) { lastv = i > lastv ? i : lastv; ++n_pairs; }
     }
-    n_leftinv = nmx_block_sum_i(n_leftinv, red);
-    n_pairs = nmx_block_sum_i(n_pairs, red);
-    lastv = (int)nmx_block_max((float)lastv, red);
+    // one reduction for the two counters (each < 2^15)
+    {
+      const int packed = nmx_block_sum_i(n_leftinv | (n_pairs << 16), red);
+      n_leftinv = packed & 0xffff;
+      n_pairs = packed >> 16;
+      lastv = (int)nmx_block_max((float)lastv, red);
+    }
     NMX_SYNC();
     const int first_valid = n_leftinv;
-    int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
+    const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
     const int nT = last_excl > first_valid ? last_excl - first_valid : 0;
-    const int* trv = tr + first_valid;  // trough list after the reference's slice
-    for (int p = NMX_TID; p < n_pairs; p += NMX_NT) {
-      const int ptr = st[first_valid + p];
-      lf[p] = pk[ptr - 1];
-      rt[p] = pk[ptr];
+    const nmx_u16* trv = tr + first_valid;  // trough list after the reference's slice
+    // pointer -> (left, right) peak positions; rt first (lf[] holds the pointers)
+    for (int p = NMX_TID; p < n_pairs; p += NMX_NT) rt[p] = pk[lf[first_valid + p]];
+    NMX_SYNC();
+    {
+#ifdef NMX_HOST_EMU
+      std::vector<nmx_u16> tmp(n_pairs > 0 ? n_pairs : 1);
+      for (int p = 0; p < n_pairs; ++p) tmp[p] = pk[lf[first_valid + p] - 1];
+      for (int p = 0; p < n_pairs; ++p) lf[p] = tmp[p];
+#else
+      // in place: read my entries, barrier, write (lane-strided -> at most pm / 64 registers)
+      nmx_u16 keep[16];
+      int kk = 0;
+      for (int p = NMX_TID; p < n_pairs && kk < 16; p += NMX_NT) keep[kk++] = pk[lf[first_valid + p] - 1];
+      NMX_SYNC();
+      kk = 0;
+      for (int p = NMX_TID; p < n_pairs && kk < 16; p += NMX_NT) lf[p] = keep[kk++];
+#endif
     }
     NMX_SYNC();
     const int nPT = (n_pairs == nT) ? n_pairs : 0;  // arrays that broadcast pairs with troughs
@@ -222,7 +311,7 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
         case NMX_SW_PEAK_LEFT: n = n_pairs; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = sgn * z[lf[p]]; break;
         case NMX_SW_PEAK_RIGHT: n = n_pairs; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = sgn * z[rt[p]]; break;
         case NMX_SW_TROUGH: n = nT; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = sgn * z[trv[p]]; break;
-        case NMX_SW_WIDTH: n = n_pairs; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)(rt[p] - lf[p]); break;
+        case NMX_SW_WIDTH: n = n_pairs; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)((int)rt[p] - (int)lf[p]); break;
         case NMX_SW_PROMINENCE:
           n = nPT;
           for (int p = NMX_TID; p < n; p += NMX_NT)
@@ -230,17 +319,18 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
           break;
         case NMX_SW_INTERVAL:
           n = nT;
-          for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = p == 0 ? 0.f : (float)(trv[p] - trv[p - 1]) * A.ms;
+          for (int p = NMX_TID; p < n; p += NMX_NT)
+            vals[p] = p == 0 ? 0.f : (float)((int)trv[p] - (int)trv[p - 1]) * A.ms;
           break;
-        case NMX_SW_DECAY_TIME: n = nPT; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)(lf[p] - trv[p]) * A.ms; break;
-        case NMX_SW_RISE_TIME: n = nPT; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)(rt[p] - trv[p]) * A.ms; break;
+        case NMX_SW_DECAY_TIME: n = nPT; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)((int)lf[p] - (int)trv[p]) * A.ms; break;
+        case NMX_SW_RISE_TIME: n = nPT; for (int p = NMX_TID; p < n; p += NMX_NT) vals[p] = (float)((int)rt[p] - (int)trv[p]) * A.ms; break;
         case NMX_SW_SHARPNESS: {
           // ordered compaction of troughs with a +-sharp_off margin (sharpwaves.py:393-406)
           const int s = A.sharp_off;
           const int chunk = (nT + NMX_NT - 1) / NMX_NT;
           const int i0 = NMX_TID * chunk, i1 = (i0 + chunk) < nT ? (i0 + chunk) : nT;
           int cnt = 0;
-          for (int i = i0; i < i1; ++i) cnt += (trv[i] - s > 0 && trv[i] + s < W);
+          for (int i = i0; i < i1; ++i) cnt += ((int)trv[i] - s > 0 && (int)trv[i] + s < W);
           int total;
           const int base = nmx_wave_excl_sum_i(cnt, &total);
           int k = 0;
@@ -260,11 +350,11 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
           n = nPT;
           for (int p = NMX_TID; p < n; p += NMX_NT) {
             float rise = 0.f, decay = 0.f;
-            for (int j = lf[p]; j <= trv[p]; ++j) {
+            for (int j = lf[p]; j <= (int)trv[p]; ++j) {
               const float d = j > 0 ? fabsf(z[j] - z[j - 1]) : 0.f;
               rise = d > rise ? d : rise;
             }
-            for (int j = trv[p]; j <= rt[p]; ++j) {
+            for (int j = trv[p]; j <= (int)rt[p]; ++j) {
               const float d = j > 0 ? fabsf(z[j] - z[j - 1]) : 0.f;
               decay = d > decay ? d : decay;
             }

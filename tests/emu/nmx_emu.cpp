@@ -14,6 +14,7 @@
 
 #define NMX_HOST_EMU 1
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_bank_w64.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bursts.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
@@ -38,7 +39,13 @@ static void be_h2d_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t
 static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v, n); }
 static int be_sync(be_stream_t) { return 0; }
 static be_stream_t be_stream_create() { return nullptr; }
+static be_stream_t be_stream_create_high() { return nullptr; }
 static void be_stream_destroy(be_stream_t) {}
+typedef int be_event_t;
+static void be_event_create(be_event_t&) {}
+static void be_event_destroy(be_event_t&) {}
+static void be_event_record(be_event_t&, be_stream_t) {}
+static void be_stream_wait(be_stream_t, be_event_t&) {}
 static void be_timer_create(be_timer_t&) {}
 static void be_timer_destroy(be_timer_t&) {}
 static void be_timer_start(be_timer_t&, be_stream_t) {}
@@ -54,9 +61,20 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int, size_t lds, b
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_bank_item(A, it / A.n_channels, it % A.n_channels, sm.data());
 }
+static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) {
+    if (A.b.pad_mode == 0) nmx_bank_w64_item<0>(A, it / A.b.n_channels, it % A.b.n_channels, sm.data());
+    else nmx_bank_w64_item<1>(A, it / A.b.n_channels, it % A.b.n_channels, sm.data());
+  }
+}
+static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (long long it = 0; it < n_items; ++it) nmx_hilbert_item(A, it, sm.data());
+}
 static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
-  for (int it = 0; it < n_items; ++it) nmx_burst_thr_item(A, it / A.n_bands, it % A.n_bands, sm.data());
+  for (int it = 0; it < n_items; ++it) nmx_burst_thr_item<1>(A, it / A.n_bands, it % A.n_bands, sm.data());
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
