@@ -45,6 +45,9 @@ __global__ void __launch_bounds__(64) nmx_kern_sharp(const NmxSharpArgs A) {
 __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
   nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
 }
+__global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
+  nmx_car_sample(A, (long long)blockIdx.x * 256 + threadIdx.x);
+}
 __global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
   const int item = blockIdx.x;
   nmx_nanmask_item(A, item / A.C_in, item % A.C_in, nmx_smem);
@@ -198,6 +201,9 @@ static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_s
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
   hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+}
+static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 255) / 256)), dim3(256), 0, s, A);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);

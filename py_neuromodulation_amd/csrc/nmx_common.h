@@ -71,6 +71,7 @@ struct NmxOsc {
   int enabled;
   int n;         // real transform length (FFT: N, Welch/STFT: nperseg)
   int nfreq;     // n / 2 + 1
+  int k_lo, k_hi;  // bins actually evaluated: union of the bands (all bins with return_spectrum)
   int nseg;      // segments (FFT: 1)
   int step;      // hop between segments
   int half;      // STFT: even-extension length nperseg / 2

@@ -21,6 +21,8 @@
 
 #include "nmx_device.h"
 #ifdef NMX_HOST_EMU
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 #endif
 
@@ -86,17 +88,115 @@ NMX_DEV int nmx_upper_bound_i(const int* ins, int n, int i) {
   return lo;
 }
 
-// One hop of the sequential threshold walk costs ~4 barriers: rank the new samples by counting
-// (broadcast LDS reads, no dependent chain), one binary search per NEW sample into the list,
-// then an in-place merge in which every thread stages a contiguous chunk of the list in
-// registers and writes it back shifted (merge path) -- no second list buffer, so two
-// workgroups of this kernel only hold ~70 KiB of a CU's LDS and other kernels can overlap.
+// descending rank-by-counting sort of pc[0..n) -> ps (pc padded with -inf to a multiple of 4)
+NMX_DEV void nmx_rank_sort_desc(const float* pc, int n, float* ps) {
+  const int n4 = (n + 3) & ~3;
+  for (int t = NMX_TID; t < n; t += NMX_NT) {
+    const float v = pc[t];
+    int rank = 0;
+#ifndef NMX_HOST_EMU
+#pragma unroll 8
+#endif
+    for (int j = 0; j < n4; j += 4) {
+      const float u0 = pc[j], u1 = pc[j + 1], u2 = pc[j + 2], u3 = pc[j + 3];
+      rank += (u0 > v) || (u0 == v && j < t);
+      rank += (u1 > v) || (u1 == v && j + 1 < t);
+      rank += (u2 > v) || (u2 == v && j + 2 < t);
+      rank += (u3 > v) || (u3 == v && j + 3 < t);
+    }
+    ps[rank] = v;
+  }
+}
+
+// In-place merge of the sorted (descending) ps[0..n_new) into the descending list L[0..len),
+// truncated to K entries: every thread stages a contiguous chunk of L in registers and writes
+// it back shifted by the number of new samples that sort before it (merge path).  Equal values:
+// list entries first.  Barriers inside; returns the new length.
+template <int CH>
+NMX_DEV int nmx_merge_into(float* L, int len, int K, const float* ps, int* ins, int n_new, float* vals) {
+  const int chunk = (K + NMX_NT - 1) / NMX_NT;   // <= CH
+  const int i0 = NMX_TID * chunk;
+#ifdef NMX_HOST_EMU
+  const int CHB = chunk;
+#else
+  constexpr int CHB = CH;
+#endif
+  for (int j = NMX_TID; j < n_new; j += NMX_NT) ins[j] = nmx_count_ge(L, len, ps[j]);
+  const int i1 = (i0 + chunk) < len ? (i0 + chunk) : len;
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+  for (int k = 0; k < CHB; ++k) {
+    if (k < chunk && i0 + k < i1) vals[k] = L[i0 + k];
+  }
+  NMX_SYNC();
+  if (i0 < i1) {
+    int cnt = nmx_upper_bound_i(ins, n_new, i0);
+    const int cnt_end = nmx_upper_bound_i(ins, n_new, i1 - 1);
+    if (cnt == cnt_end) {   // common case: no new sample lands inside my chunk
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int k = 0; k < CHB; ++k) {
+        const int i = i0 + k;
+        if (k < chunk && i < i1 && i + cnt < K) L[i + cnt] = vals[k];
+      }
+    } else {
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int k = 0; k < CHB; ++k) {
+        const int i = i0 + k;
+        if (k < chunk && i < i1) {
+          while (cnt < n_new && ins[cnt] <= i) ++cnt;
+          const int pos = i + cnt;
+          if (pos < K) L[pos] = vals[k];
+        }
+      }
+    }
+  }
+  for (int j = NMX_TID; j < n_new; j += NMX_NT) {
+    const int pos = ins[j] + j;
+    if (pos < K) L[pos] = ps[j];
+  }
+  NMX_SYNC();
+  return (len + n_new) < K ? (len + n_new) : K;
+}
+
+NMX_DEV float nmx_lerp_thr(double a, double b, double frac, bool have_b) {
+  if (!have_b) return (float)a;
+  const double d = b - a;
+  return (float)((frac >= 0.5) ? b - d * (1.0 - frac) : a + d * frac);  // NumPy _lerp
+}
+
+#define NMX_THR_F 512     // capacity of the sorted low fringe
+#define NMX_THR_FREFILL 384
+#define NMX_THR_P 1024    // capacity of the pending (unsorted) list
+
+// Threshold walk of one (channel, band) over the hops of a batch.
+//
+// Fill regime (fewer than n_ring samples so far): every hop merges its sorted new samples into
+// the descending top-K list L (in-place merge path, ~4 barriers).
+//
+// Steady regime (ring full; the long-run state): the rank that is read is pinned a fixed
+// distance above the SMALLEST kept value, a new sample only matters if it exceeds that
+// smallest value, and each accepted sample evicts the current smallest.  The kept set is held
+// as  L_main (sorted, untouched)  +  P (pending accepted samples above the fringe, unsorted)
+//   +  F (the few hundred smallest kept values, sorted ascending).
+// A hop classifies its <= `overlap` new samples against F's ends, appends to P or inserts into
+// F, drops the a smallest of F and reads the threshold from F -- a handful of tiny steps; only
+// when F runs low or P fills up (every ~10 hops) P is sorted and merged into L_main and F is
+// re-cut from the list's tail.  Bit-identical to the per-hop full merge.
 template <int CH>
 NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
   float* L = smem + A.off_l0;
-  float* pc = smem + A.off_p;            // [P2] raw new samples
-  float* ps = pc + A.P2;                 // [P2] sorted (descending) new samples
-  int* ins = (int*)(ps + A.P2);          // [P2] insertion index of ps[j] into L
+  float* pc = smem + A.off_p;            // [P2] raw new samples / flush staging
+  float* ps = pc + A.P2;                 // [P2] sorted new samples
+  int* ins = (int*)(ps + A.P2);          // [P2] insertion indices
+  float* F = (float*)(ins + A.P2);       // [NMX_THR_F] ascending fringe
+  float* F2 = F + NMX_THR_F;
+  float* Pp = F2 + NMX_THR_F;            // [NMX_THR_P] pending
+  int* cnts = (int*)(Pp + NMX_THR_P);    // [4] LDS counters
   const int K = A.K, W = A.W;
   const long long sidx = (long long)c * A.n_bands + bi;
   long long total = A.counts[2 * sidx];
@@ -104,23 +204,29 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
   int len = (int)(total < K ? total : K);
   float* gtop = A.top + sidx * K;
   for (int i = NMX_TID; i < len; i += NMX_NT) L[i] = gtop[i];
-  const int chunk = (K + NMX_NT - 1) / NMX_NT;   // <= CH
-  const int i0 = NMX_TID * chunk;
 #ifdef NMX_HOST_EMU
   std::vector<float> vals_store(K > 0 ? K : 1);
   float* vals = vals_store.data();
-  const int CHB = chunk;   // the emulator's single "thread" owns the whole list
 #else
   float vals[CH];
-  constexpr int CHB = CH;
 #endif
-  // software prefetch of the next hop's new samples (one per thread) hides the HBM latency
+  // steady-state bookkeeping
+  const bool steady_ok = A.P2 >= NMX_THR_P && K > 2 * NMX_THR_F && A.overlap <= 256;
+  bool steady = false;
+  int Lm = 0, nF = 0, nP = 0;
+  const long long m_ring = A.n_ring;
+  const double pos_ring = A.q * (double)(m_ring - 1);
+  const long long lo_ring = (long long)floor(pos_ring);
+  const double frac_ring = pos_ring - (double)lo_ring;
+  const int ia_ring = (int)(m_ring - 1 - lo_ring);   // descending index of s[lo]
+
   const bool can_prefetch = A.overlap <= NMX_NT;
   float pre = 0.f;
   bool have_pre = false;
+  NMX_SYNC();
   for (int w = 0; w < A.n_windows; ++w) {
     const int n_new = (nwin == 0) ? W : A.overlap;
-    int n4 = (n_new + 3) & ~3;   // pc is padded with -inf to a multiple of 4 (float4 reads)
+    const int n4 = (n_new + 3) & ~3;
     const float* e = A.env + (((long long)w * A.n_channels + c) * A.n_bands + bi) * W + (W - n_new);
     if (have_pre) {
       if (NMX_TID < n_new) pc[NMX_TID] = pre;
@@ -134,84 +240,100 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
       if (NMX_TID < A.overlap) pre = en[NMX_TID];
       have_pre = true;
     }
+    const bool want_steady = steady_ok && total >= m_ring && len == K && ia_ring >= K - 3 && ia_ring < K;
+    if (want_steady && !steady) {   // enter: cut the fringe from the list's tail
+      nF = NMX_THR_FREFILL;
+      Lm = K - nF;
+      nP = 0;
+      NMX_SYNC();
+      for (int j = NMX_TID; j < nF; j += NMX_NT) F[j] = L[K - 1 - j];
+      steady = true;
+#ifdef NMX_HOST_EMU
+      if (getenv("NMX_EMU_TRACE")) fprintf(stderr, "[emu] steady regime entered at hop %d (c=%d b=%d)\n", w, c, bi);
+#endif
+    }
+    if (NMX_TID == 0) { cnts[0] = 0; cnts[1] = 0; cnts[2] = 0; }
     NMX_SYNC();
-    // 1. rank by counting -> ps descending (ties keep input order); float4 broadcast reads
+    if (!steady) {
+      nmx_rank_sort_desc(pc, n_new, ps);
+      NMX_SYNC();
+      len = nmx_merge_into<CH>(L, len, K, ps, ins, n_new, vals);
+      total += n_new;
+      nwin += 1;
+      if (NMX_TID == 0) {
+        const long long m = total < m_ring ? total : m_ring;
+        const double pos = A.q * (double)(m - 1);
+        const long long lo = (long long)floor(pos);
+        A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] =
+            nmx_lerp_thr((double)L[m - 1 - lo], lo + 1 <= m - 1 ? (double)L[m - 2 - lo] : 0.0,
+                         pos - (double)lo, lo + 1 <= m - 1);
+      }
+      continue;
+    }
+    // ---------------- steady hop ----------------
+    const float T = F[0], Fmax = F[nF - 1];
     for (int t = NMX_TID; t < n_new; t += NMX_NT) {
-      const float v = pc[t];
-      int rank = 0;
-#ifndef NMX_HOST_EMU
-#pragma unroll 8
+      const float x = pc[t];
+      if (x > T) {
+#ifdef NMX_HOST_EMU
+        if (x <= Fmax) ps[cnts[1]++] = x; else Pp[nP + cnts[2]++] = x;
+        cnts[0]++;
+#else
+        if (x <= Fmax) ps[atomicAdd(&cnts[1], 1)] = x; else Pp[nP + atomicAdd(&cnts[2], 1)] = x;
+        atomicAdd(&cnts[0], 1);
 #endif
-      for (int j = 0; j < n4; j += 4) {
-        const float u0 = pc[j], u1 = pc[j + 1], u2 = pc[j + 2], u3 = pc[j + 3];
-        rank += (u0 > v) || (u0 == v && j < t);
-        rank += (u1 > v) || (u1 == v && j + 1 < t);
-        rank += (u2 > v) || (u2 == v && j + 2 < t);
-        rank += (u3 > v) || (u3 == v && j + 3 < t);
-      }
-      ps[rank] = v;
-    }
-    NMX_SYNC();
-    // 2. insertion index of each new sample (after all list entries >= it)
-    for (int j = NMX_TID; j < n_new; j += NMX_NT) ins[j] = nmx_count_ge(L, len, ps[j]);
-    // stage my chunk of the list in registers
-    const int i1 = (i0 + chunk) < len ? (i0 + chunk) : len;
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-    for (int k = 0; k < CHB; ++k) {
-      if (k < chunk && i0 + k < i1) vals[k] = L[i0 + k];
-    }
-    NMX_SYNC();
-    // 3. shifted write-back (merge path): entry i moves down by the number of new samples > L[i]
-    if (i0 < i1) {
-      int cnt = nmx_upper_bound_i(ins, n_new, i0);
-      const int cnt_end = nmx_upper_bound_i(ins, n_new, i1 - 1);
-      if (cnt == cnt_end) {   // common case: no new sample lands inside my chunk
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-        for (int k = 0; k < CHB; ++k) {
-          const int i = i0 + k;
-          if (k < chunk && i < i1 && i + cnt < K) L[i + cnt] = vals[k];
-        }
-      } else {
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-        for (int k = 0; k < CHB; ++k) {
-          const int i = i0 + k;
-          if (k < chunk && i < i1) {
-            while (cnt < n_new && ins[cnt] <= i) ++cnt;
-            const int pos = i + cnt;
-            if (pos < K) L[pos] = vals[k];
-          }
-        }
       }
     }
-    for (int j = NMX_TID; j < n_new; j += NMX_NT) {
-      const int pos = ins[j] + j;
-      if (pos < K) L[pos] = ps[j];
-    }
     NMX_SYNC();
-    len = (len + n_new) < K ? (len + n_new) : K;
+    const int a = cnts[0], nI = cnts[1];
+    nP += cnts[2];
+    // new fringe = (F u I) minus its a smallest; ties: fringe entries first
+    for (int i = NMX_TID; i < nF; i += NMX_NT) {
+      const float v = F[i];
+      int lt = 0;
+      for (int r = 0; r < nI; ++r) lt += (ps[r] < v);
+      const int idx = i + lt - a;
+      if (idx >= 0) F2[idx] = v;
+    }
+    for (int r = NMX_TID; r < nI; r += NMX_NT) {
+      const float v = ps[r];
+      int rank = 0;   // among the insert candidates (ascending, stable)
+      for (int j = 0; j < nI; ++j) rank += (ps[j] < v) || (ps[j] == v && j < r);
+      int le = 0;     // fringe entries <= v  (binary search, F ascending)
+      { int lo2 = 0, hi2 = nF; while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (F[mid] <= v) lo2 = mid + 1; else hi2 = mid; } le = lo2; }
+      const int idx = rank + le - a;
+      if (idx >= 0) F2[idx] = v;
+    }
+    nF = nF + nI - a;
+    { float* tsw = F; F = F2; F2 = tsw; }
     total += n_new;
     nwin += 1;
+    NMX_SYNC();
     if (NMX_TID == 0) {
-      const long long m = total < A.n_ring ? total : A.n_ring;
-      const double pos = A.q * (double)(m - 1);
-      const long long lo = (long long)floor(pos);
-      const double frac = pos - (double)lo;
-      const double a = (double)L[m - 1 - lo];
-      double r = a;
-      if (lo + 1 <= m - 1) {
-        const double b = (double)L[m - 2 - lo];
-        const double d = b - a;
-        r = (frac >= 0.5) ? b - d * (1.0 - frac) : a + d * frac;  // NumPy _lerp
-      }
-      A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] = (float)r;
+      // s[lo] = kept value with descending index ia_ring -> ascending fringe index K - 1 - ia_ring
+      const int ja = K - 1 - ia_ring;
+      A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] =
+          nmx_lerp_thr((double)F[ja], (double)F[ja + 1], frac_ring, true);
     }
-    // (no barrier needed here: the next hop only reads L until its own barrier 2)
+    // flush when the fringe could run dry or the pending list could overflow on the next hop
+    if (nF < A.overlap + 8 || nP + A.overlap > NMX_THR_P || w + 1 == A.n_windows) {
+      NMX_SYNC();
+      // sort pending (descending) through pc -> ps, then merge into L_main
+      for (int i = NMX_TID; i < nP; i += NMX_NT) pc[i] = Pp[i];
+      for (int i = nP + NMX_TID; i < ((nP + 3) & ~3); i += NMX_NT) pc[i] = -INFINITY;
+      NMX_SYNC();
+      nmx_rank_sort_desc(pc, nP, ps);
+      NMX_SYNC();
+      Lm = nmx_merge_into<CH>(L, Lm, K, ps, ins, nP, vals);
+      for (int j = NMX_TID; j < nF; j += NMX_NT) L[Lm + j] = F[nF - 1 - j];
+      NMX_SYNC();
+      // (Lm + nF == K by construction)
+      nF = NMX_THR_FREFILL;
+      Lm = K - nF;
+      nP = 0;
+      for (int j = NMX_TID; j < nF; j += NMX_NT) F[j] = L[K - 1 - j];
+      NMX_SYNC();
+    }
   }
   NMX_SYNC();
   for (int i = NMX_TID; i < len; i += NMX_NT) gtop[i] = L[i];

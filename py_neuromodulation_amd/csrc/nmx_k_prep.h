@@ -41,6 +41,27 @@ NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
   for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = acc[i];
 }
 
+// Common-average style matrices R = (d - o) I + o 1 1^T (the reference's DEFAULT channel table,
+// utils/channels.py:289-296, gives d = 1, o = -1/(n-1)): y_i = (d - o) x_i + o * sum_j x_j, i.e.
+// one column sum per sample instead of a dense C x C product -- HBM-bound.
+struct NmxCarArgs {
+  const float* x;
+  long long ldx;
+  float* y;
+  long long ldy;
+  int C;
+  long long T;
+  float diag, off;
+};
+
+NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
+  if (t >= A.T) return;
+  float s = 0.f;
+  for (int j = 0; j < A.C; ++j) s += nmx_clean(A.x[(long long)j * A.ldx + t]);
+  const float a = A.diag - A.off, b = A.off * s;
+  for (int j = 0; j < A.C; ++j) A.y[(long long)j * A.ldy + t] = a * nmx_clean(A.x[(long long)j * A.ldx + t]) + b;
+}
+
 struct NmxNanMaskArgs {
   const float* x;
   long long ldx;

@@ -56,7 +56,7 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
   for (int b = 0; b < n_bands; ++b) {
     const int lo = O.bin_lo[b], hi = O.bin_hi[b];
     const int cnt = (hi - lo) * vals_per_bin;
-    const float* v = spec + lo * vals_per_bin;
+    const float* v = spec + (lo - O.k_lo) * vals_per_bin;
     int slot = 0;
     float mean = NAN;
     const bool need_mean = O.estimators & (NMXD_EST_MEAN | NMXD_EST_STD);
@@ -148,11 +148,11 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     }
     NMX_SYNC();
     const float2* Z = nmx_osc_fft(O, bufA, bufB);
-    for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+    for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
       const float2 X = nmx_osc_bin(O, Z, k);
       float v = sqrtf(X.x * X.x + X.y * X.y);
       if (O.log_transform) v = log10f(v);
-      spec[k] = v;
+      spec[k - O.k_lo] = v;
     }
     NMX_SYNC();
     nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red);
@@ -181,17 +181,17 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       }
       NMX_SYNC();
       const float2* Z = nmx_osc_fft(O, bufA, bufB);
-      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+      for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
         const float2 X = nmx_osc_bin(O, Z, k);
         float p = (X.x * X.x + X.y * X.y) * O.scale;
         const bool edge = (k == 0) || ((N % 2 == 0) && k == N / 2);
         if (!edge) p *= 2.f;
-        spec[k] = (sgi == 0) ? p : spec[k] + p;
+        spec[k - O.k_lo] = (sgi == 0) ? p : spec[k - O.k_lo] + p;
       }
       NMX_SYNC();
     }
     const float inv = 1.f / (float)O.nseg;
-    for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+    for (int k = NMX_TID; k < O.k_hi - O.k_lo; k += NMX_NT) {
       float v = spec[k] * inv;
       if (O.log_transform) v = log10f(v);
       spec[k] = v;
@@ -224,11 +224,11 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       }
       NMX_SYNC();
       const float2* Z = nmx_osc_fft(O, bufA, bufB);
-      for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
+      for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
         const float2 X = nmx_osc_bin(O, Z, k);
         float v = sqrtf(X.x * X.x + X.y * X.y) * O.scale;
         if (O.log_transform) v = log10f(v);
-        spec[k * O.nseg + sgi] = v;
+        spec[(k - O.k_lo) * O.nseg + sgi] = v;
       }
     }
     NMX_SYNC();

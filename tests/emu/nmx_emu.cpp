@@ -94,6 +94,9 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
   for (int c0 = 0; c0 < A.C; c0 += NMX_REREF_ROWS)
     for (long long t = 0; t < A.T; ++t) nmx_reref_tile(A, t, c0);
 }
+static void be_launch_car(const NmxCarArgs& A, be_stream_t) {
+  for (long long t = 0; t < A.T; ++t) nmx_car_sample(A, t);
+}
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
   float sm[64];
   for (int it = 0; it < n_items; ++it) nmx_nanmask_item(A, it / A.C_in, it % A.C_in, sm);

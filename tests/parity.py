@@ -14,6 +14,11 @@ in fp32, the reference in float64:
   * bursts: `env >= thr` is a discrete decision; one borderline sample moves a duration by
     1/sfreq.  amplitude_max: 1e-5 rel.  Other outputs: compared exactly-to-1e-5 first; a row
     may differ only by what ONE flipped sample explains (checked explicitly).
+  * near-null spectral bins: a log10-valued feature averages log10|X_k|; fp32 puts an ABSOLUTE
+    error of ~1e-7 * rms on every bin, so a bin whose magnitude happens to be 100x below the rms
+    level (Rayleigh statistics: ~1 bin in 10^4) carries a 1e-5..1e-3 error in log10.  Such
+    conditioning outliers (err <= 2e-3, at most 1 per 500 compared log-spectral entries, minimum
+    1 per call) are tolerated and counted; everything else must meet 1e-5.
   * degenerate rows (all-zero / constant input): spectral bins that are exactly 0 in exact
     arithmetic are rounding noise (1e-16 in float64, 1e-8 in fp32); log10 of noise is not
     comparable and those entries are skipped; +-inf / nan_to_num'ed +-huge values must agree in
@@ -74,6 +79,8 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, burst_sla
     """Returns (n_bad, report, max_rel_by_family).  `skip(key) -> bool` drops degenerate entries."""
     bad = []
     worst: dict[str, float] = {}
+    n_log = 0
+    outliers = []
     for k, g, w in zip(keys, got, want):
         g, w = float(g), float(w)
         if skip is not None and skip(k):
@@ -89,8 +96,16 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, burst_sla
         ok = err <= rtol * abs(w) + atol
         if np.isfinite(w) and w != 0:
             worst[fam] = max(worst.get(fam, 0.0), err / max(abs(w), atol / max(rtol, 1e-30)))
+        is_log = (fam in ("fft", "welch", "stft") and getattr(settings, f"{fam}_settings").log_transform) or \
+                 (fam == "bandpass" and "_activity_" in k and settings.bandpass_filter_settings.log_transform)
+        n_log += bool(is_log)
+        if not ok and is_log and err <= 2e-3:
+            outliers.append((k, g, w))   # near-null-bin conditioning (module docstring)
+            continue
         if not ok:
             bad.append((k, g, w))
+    if len(outliers) > max(1, n_log // 500):
+        bad.extend(outliers)
     report = "\n".join(f"  {k}: got {g!r} want {w!r}" for k, g, w in bad[:15])
     return len(bad), report, worst
 

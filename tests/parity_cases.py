@@ -197,3 +197,45 @@ def case_pipeline_nan_and_channel_table(lib):
         for r in range(len(got)):
             n_bad, rep, _ = parity.compare(cols, got[r], want[r], s, 1000.0, 30.0, 1000)
             assert n_bad == 0, f"{tag} row {r}\n{rep}"
+
+
+def case_bursts_steady_state_vs_oracle(lib):
+    """Ring of 5 s (K = 1251 > fringe capacity): 40 fill hops, then 110 hops in the steady
+    regime (fringe / pending-list algorithm of the threshold kernel), vs the CPU oracle; the same
+    sequence is also fed in uneven batches and single windows (flush on batch boundaries)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.bursts_settings.time_duration_s = 5
+    s.bursts_settings.frequency_bands = ["low_beta", "high_beta"]
+    s = s.validate()
+    sfreq, C, n_hops = 1000.0, 2, 150
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(21)
+    t = np.arange(T) / sfreq
+    amp = 1 + 0.8 * np.sin(2 * np.pi * 0.3 * t) + t / t[-1]          # non-stationary power
+    data = rng.standard_normal((C, T)) * 20 + 30 * amp * np.sin(2 * np.pi * 18 * t)
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * 100
+    ob = orc.Bursts(s, ch, sfreq)
+    want = np.array([[float(v) for v in ob.calc_feature(data[:, a:a + 1000]).values()] for a in starts])
+    keys = list(ob.calc_feature(data[:, :1000]).keys())
+    amp_scale = float(np.abs(data).max())
+    for plan in ([n_hops], [37, 1, 1, 50, 13, 48]):
+        eng = HotPathEngine(s, ch, sfreq, lib=lib, features=["bursts"], bank_taps=None)
+        assert eng.keys == keys
+        rows, i = [], 0
+        for n in plan:
+            if n == 1:
+                rows.append(eng.process_window(data[:, starts[i]:starts[i] + 1000])[None])
+            else:
+                rows.append(eng.process_batch(data, starts[i:i + n]))
+            i += n
+        got = np.concatenate(rows)
+        for r in range(n_hops):
+            b, rep, _ = parity.compare(keys, got[r], want[r], s, sfreq, amp_scale, 1000, burst_slack=True)
+            assert b == 0, f"plan {plan} hop {r}\n{rep}"
+        assert np.isclose(got, want, rtol=1e-4, atol=1e-6).mean() > 0.97
+        eng.close()

@@ -89,3 +89,7 @@ def test_pipeline_readme_default_zscore(gpu_lib):
 
 def test_pipeline_nan_and_channel_table(gpu_lib):
     pc.case_pipeline_nan_and_channel_table(gpu_lib)
+
+
+def test_bursts_steady_state_vs_oracle(gpu_lib):
+    pc.case_bursts_steady_state_vs_oracle(gpu_lib)

@@ -64,3 +64,7 @@ def test_pipeline_readme_default_zscore(emu_lib):
 
 def test_pipeline_nan_and_channel_table(emu_lib):
     pc.case_pipeline_nan_and_channel_table(emu_lib)
+
+
+def test_bursts_steady_state_vs_oracle(emu_lib):
+    pc.case_bursts_steady_state_vs_oracle(emu_lib)

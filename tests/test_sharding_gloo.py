@@ -73,7 +73,13 @@ def test_two_rank_channel_shards_equal_single_process(tmp_path):
     s.postprocessing.feature_normalization = False
     rng = np.random.default_rng(7)
     data = rng.standard_normal((5, 2500)) * 20 + rng.uniform(-100, 100, (5, 1))
-    single = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+    # same arithmetic on both sides: dense re-reference rows (the single-GPU common-average fast
+    # path sums in a different order, which would only test fp32 rounding, not the sharding)
+    os.environ["NMX_CAR_FAST"] = "0"
+    try:
+        single = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+    finally:
+        del os.environ["NMX_CAR_FAST"]
     assert list(sharded.columns) == list(single.columns)
     a, b = sharded.to_numpy(float), single.to_numpy(float)
     assert a.shape == b.shape and not np.isnan(a).any()
