@@ -88,6 +88,7 @@ def main() -> None:
     ap.add_argument("--windows", type=int, default=1024, help="hops per step (batch)")
     ap.add_argument("--cpu-windows", type=int, default=24, help="hops timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-preproc", action="store_true", help="skip notch + re-referencing")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -95,14 +96,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; NMX_BENCH_FORCE_DEVICE lets a 1-GPU box exercise the N > 1 code path
+    dev_index = int(os.environ.get("NMX_BENCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(args.backend)
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     from py_neuromodulation_amd import fir_design
     from py_neuromodulation_amd.engine import HotPathEngine
@@ -115,7 +118,7 @@ def main() -> None:
     T = W + (n_win - 1) * hop
     ch = [f"ch{i}_avgref" for i in range(C)]
     pre = not args.no_preproc
-    eng = HotPathEngine(s, ch, sfreq, device=local_rank,
+    eng = HotPathEngine(s, ch, sfreq, device=dev_index,
                         ref_matrix=car_matrix(C) if pre else None,
                         notch_taps=fir_design.notch_bank(sfreq, 50) if pre else None)
     F = eng.n_outputs
@@ -146,7 +149,7 @@ def main() -> None:
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
     bad = int(torch.isnan(out).sum().item())
@@ -157,9 +160,9 @@ def main() -> None:
         F_c = F / C
         bytes_cw = 4 * W + 4 * F_c                      # fp32 window in + features out
         bank_ms = kt["bank"] / args.steps
-        # dominant kernel = FIR bank: reads each (channel, window) once, writes its 4 band-pass
-        # features; the envelope / filtered-series hand-off to the bursts and sharp-wave kernels is
-        # NOT algorithmic traffic
+        # dominant kernel = FIR bank (nmx_kern_bank_w64_*): reads each (channel, window) once, writes
+        # its 4 band-pass features; the filtered-series hand-off to the Hilbert / sharp-wave kernels
+        # is NOT algorithmic traffic (it shows up in `traffic`)
         bank_bytes = n_win * C * (4 * W + 4 * 4)
         achieved = bank_bytes / (bank_ms * 1e-3) / 1e9 if bank_ms > 0 else 0.0
         traffic = None
@@ -182,7 +185,7 @@ def main() -> None:
             "algorithmic_GBps_pipeline": value / world * C * bytes_cw / 1e9,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
             "nan_outputs": bad,
-            "roofline": {"bound": "hbm", "kernel": "nmx_kern_bank", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "nmx_kern_bank_w64_scalar", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "note": "FIR bank is LDS/FP32-vector bound (SURVEY 8d); frac is vs the HBM roof"},

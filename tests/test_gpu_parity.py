@@ -93,3 +93,118 @@ def test_pipeline_nan_and_channel_table(gpu_lib):
 
 def test_bursts_steady_state_vs_oracle(gpu_lib):
     pc.case_bursts_steady_state_vs_oracle(gpu_lib)
+
+
+def _bench_like_engine(gpu_lib, C, scale=1.0, pre=True, device=0):
+    from py_neuromodulation_amd import NMSettings, fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.bandpass_filter = True
+    s.features.stft = True
+    ch = [f"ch{i}_avgref" for i in range(C)]
+    R = np.full((C, C), -1.0 / (C - 1))
+    np.fill_diagonal(R, 1.0)
+    eng = HotPathEngine(s, ch, 1000.0, lib=gpu_lib, ref_matrix=R if pre else None,
+                        notch_taps=fir_design.notch_bank(1000.0, 50) if pre else None)
+    return s, eng
+
+
+def test_full_size_properties_256ch(gpu_lib):
+    """BASELINE headline size (256 ch @ 1 kHz, W=1000, hop=100, all features, notch + CAR), where the
+    oracle is too slow to run everything: size-independent properties instead.
+      (1) the batch path equals the one-window path bit for bit (windows are strided views);
+      (2) scaling the input by 4 scales amplitude-like features by 4, power-like by 16 (log: +log10),
+          leaves shape-like features (mobility, complexity, intervals) unchanged;
+      (3) three hops are checked against the CPU oracle on 256 channels."""
+    from oracle import nm_oracle as orc
+
+    C, n_hops = 256, 48
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(1234)
+    t = np.arange(T) / 1000.0
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + 5 * np.sin(2 * np.pi * 70 * t)
+         + rng.uniform(-500, 500, (C, 1))).astype(np.float32)
+    starts = np.arange(n_hops) * 100
+    s, eng = _bench_like_engine(gpu_lib, C)
+    got = eng.process_batch(x, starts)
+    assert not np.isnan(got).any()
+    # (1) stateless columns must agree exactly between batch and single-window calls
+    s1, eng1 = _bench_like_engine(gpu_lib, C)
+    stateless = np.array(["_bursts_" not in k for k in eng.keys])
+    for i in (0, 17, 47):
+        one = eng1.process_window(x[:, starts[i]:starts[i] + 1000].astype(np.float64))
+        np.testing.assert_array_equal(one[stateless], got[i][stateless])
+    # (2) scaling
+    s4, eng4 = _bench_like_engine(gpu_lib, C)
+    got4 = eng4.process_batch(x * 4.0, starts)
+    keys = np.array(eng.keys)
+
+    def sel(sub):
+        return np.array([sub in k for k in keys])
+
+    np.testing.assert_allclose(got4[:, sel("_raw")], 4 * got[:, sel("_raw")], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(got4[:, sel("_LineLength")], 4 * got[:, sel("_LineLength")], rtol=1e-5)
+    np.testing.assert_allclose(got4[:, sel("RawHjorth_Activity")], 16 * got[:, sel("RawHjorth_Activity")], rtol=1e-5)
+    np.testing.assert_allclose(got4[:, sel("RawHjorth_Mobility")], got[:, sel("RawHjorth_Mobility")], rtol=1e-5)
+    lg = np.log10(4.0)
+    for fam in ("_fft_", "_welch_", "_stft_"):
+        add = 2 * lg if fam == "_welch_" else lg
+        np.testing.assert_allclose(got4[:, sel(fam)], got[:, sel(fam)] + add, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got4[:, sel("_bandpass_activity_")], got[:, sel("_bandpass_activity_")] + 2 * lg,
+                               rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got4[:, sel("_interval_")], got[:, sel("_interval_")], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(got4[:, sel("_prominence_")], 4 * got[:, sel("_prominence_")], rtol=1e-4, atol=1e-3)
+    # (3) oracle on three hops (stateless features; bursts need the whole history)
+    names = [f"ch{i}" for i in range(C)]
+    channels = {"name": names, "rereference": ["average"] * C, "used": [1] * C, "target": [0] * C,
+                "type": ["ecog"] * C, "status": ["good"] * C, "new_name": [f"{n}_avgref" for n in names]}
+    s.postprocessing.feature_normalization = False
+    s.preprocessing = ["notch_filter", "re_referencing"]
+    s.features.bursts = False
+    dp = orc.DataProcessor(1000.0, s, channels, line_noise=50)
+    okeys = None
+    for i in (0, 31):
+        want = dp.process(x[:, starts[i]:starts[i] + 1000].astype(np.float64))
+        okeys = list(want.keys())
+        idx = [eng.keys.index(k) for k in okeys]
+        n_bad, rep, _ = parity.compare(okeys, got[i][idx], list(want.values()), s, 1000.0, 300.0, 1000)
+        assert n_bad == 0, rep
+    for e in (eng, eng1, eng4):
+        e.close()
+
+
+def test_config3_2khz_8bands_generic_path(gpu_lib):
+    """BASELINE config[2] shape at reduced channel count: 2 kHz, W=2000, 8 bands (L=1999 -> generic
+    multi-wave FIR kernel with a 3000-point convolution), STFT(500) and bursts, vs the oracle."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.bandpass_filter = s.features.stft = s.features.bursts = True
+    s.frequency_ranges_hz = {"theta": [4, 8], "alpha": [8, 12], "low_beta": [13, 20], "high_beta": [20, 35],
+                             "low_gamma": [60, 80], "high_gamma": [90, 200], "HFA": [200, 400],
+                             "broadband": [4, 400]}
+    s.bandpass_filter_settings.segment_lengths_ms["broadband"] = 1000
+    s = s.validate()
+    sfreq, C, n_hops = 2000.0, 6, 4
+    T = 2000 + (n_hops - 1) * 200
+    rng = np.random.default_rng(5)
+    t = np.arange(T) / sfreq
+    x = rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-300, 300, (C, 1))
+    ch = [f"ch{i}" for i in range(C)]
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    starts = np.arange(n_hops) * 200
+    got = eng.process_batch(x, starts)
+    feats = [orc.BandPower(s, ch, sfreq), orc.STFT(s, ch, sfreq), orc.Bursts(s, ch, sfreq)]
+    for i, a in enumerate(starts):
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(x[:, a:a + 2000]))
+        assert list(want) == eng.keys
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, 2000,
+                                       burst_slack=True)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
