@@ -170,11 +170,26 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds
 }
 extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
+extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t);
+extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t);
 static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s) {
   static int variant = -1;
   if (variant < 0) {
     const char* v = getenv("NMX_W64_VARIANT");
     variant = (v && v[0] == 's' && v[1] == 'l') ? 1 : 0;  // "slp" | "scalar" (default)
+  }
+  static int persistent = -1, n_cu = 0;
+  if (persistent < 0) {
+    const char* v = getenv("NMX_W64_PERSISTENT");
+    persistent = (v && v[0] == '0') ? 0 : 1;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+  }
+  if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
+    if ((variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s) : nmx_w64p_launch_scalar(&A, n_items, n_cu, s)))
+      return;
   }
   if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
   else nmx_w64_launch_scalar(&A, n_items, lds, s);

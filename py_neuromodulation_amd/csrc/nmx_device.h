@@ -109,9 +109,12 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
       if (R == 4) {
         float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m];
         if (ns > 1) {
-          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
-          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
-          a3 = nmx_cmul(a3, nmx_tw<DIR>(tw, 3 * tb));
+          // one table gather per butterfly: w^2, w^3 by multiplication (<= 2 ulp) -- the gathers
+          // are uncoalesced 8-byte loads through the vector L1, the scarce resource of this loop
+          const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1), w3 = nmx_cmul(w2, w1);
+          a1 = nmx_cmul(a1, w1);
+          a2 = nmx_cmul(a2, w2);
+          a3 = nmx_cmul(a3, w3);
         }
         const float2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
         const float2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
@@ -127,10 +130,12 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
       } else if (R == 5) {
         float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m], a4 = in[j + 4 * m];
         if (ns > 1) {
-          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
-          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
-          a3 = nmx_cmul(a3, nmx_tw<DIR>(tw, 3 * tb));
-          a4 = nmx_cmul(a4, nmx_tw<DIR>(tw, 4 * tb));
+          const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1);
+          const float2 w3 = nmx_cmul(w2, w1), w4 = nmx_cmul(w2, w2);
+          a1 = nmx_cmul(a1, w1);
+          a2 = nmx_cmul(a2, w2);
+          a3 = nmx_cmul(a3, w3);
+          a4 = nmx_cmul(a4, w4);
         }
         const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;
         const float s1 = DIR * 0.95105651629515353f, s2 = DIR * 0.58778525229247314f;
@@ -149,8 +154,9 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
       } else if (R == 3) {
         float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m];
         if (ns > 1) {
-          a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
-          a2 = nmx_cmul(a2, nmx_tw<DIR>(tw, 2 * tb));
+          const float2 w1 = nmx_tw<DIR>(tw, tb);
+          a1 = nmx_cmul(a1, w1);
+          a2 = nmx_cmul(a2, nmx_cmul(w1, w1));
         }
         const float s = DIR * 0.86602540378443865f;
         const float2 t = nmx_cadd(a1, a2), d = nmx_csub(a1, a2);

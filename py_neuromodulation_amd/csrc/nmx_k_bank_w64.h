@@ -60,7 +60,7 @@ struct NmxBankW64Args {
 #define NMX_WSYNC() ((void)0)
 #else
 #define NMX_LANES 1
-#define NMX_LANE_LOOP for (int l = (int)threadIdx.x, l_once_ = 0; l_once_ < 1; ++l_once_)
+#define NMX_LANE_LOOP for (int l = (int)(threadIdx.x & 63), l_once_ = 0; l_once_ < 1; ++l_once_)
 #define NMX_LI 0
 #define NMX_WSYNC() NMX_WAVE_FENCE()
 #endif
@@ -199,8 +199,10 @@ NMX_UNROLL
 #endif
 
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
-template <int PAD>
-NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem) {
+// TAB = 1: the A/B tables of all filters sit in LDS at `tab` ([filter][A[n], B[n]]), staged once
+// per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
+template <int PAD, int TAB, int MC>
+NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab) {
   const NmxBankArgs& A = AA.b;
   float2* X = (float2*)(smem + AA.off_X);   // [1024 + 64] exchange buffer (the only LDS tile)
   float* red = smem + AA.off_red;
@@ -275,8 +277,8 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   const int yoff = (PAD == 1) ? A.pad_half : 0;
   for (int fi = 0; fi < A.n_filters; ++fi) {
     const NmxFilterDev& F = A.f[fi];
-    const float* NMX_RESTRICT Hs = AA.Hs[fi];
-    const float* NMX_RESTRICT Hd = AA.Hd[fi];
+    const float* NMX_RESTRICT Hs = TAB ? tab + (size_t)fi * 2 * NMX_W64_N : AA.Hs[fi];
+    const float* NMX_RESTRICT Hd = TAB ? tab + (size_t)fi * 2 * NMX_W64_N + NMX_W64_N : AA.Hd[fi];
     // ---- fused split * H * unsplit into registers, then inverse passes -----------------------
     NMX_LANE_LOOP {
       float2* vv = v[NMX_LI];
@@ -292,10 +294,16 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         float2 zc = make_float2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
 #endif
         if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
+#if defined(NMX_EXP) && NMX_EXP == 3
+        const float ha = 0.5f + 0.001f * r, hb = 0.25f;
+#else
         const float ha = (Hs + l)[64 * r], hb = (Hd + l)[64 * r];
+#endif
         // Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),  A = Hs - Hd sin(th_k), B = Hd cos(th_k)
         vv[r] = make_float2(ha * zk.x + hb * zc.y, ha * zk.y + hb * zc.x);
+#if !defined(NMX_EXP) || NMX_EXP != 2
         if ((r & 3) == 3) NMX_SCHED_FENCE();
+#endif
       }
       nmx_w64_passA<+1>(vv, X, l);
     }
@@ -308,7 +316,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
 
     if (F.bp_seglen > 0) {
-      const bool need_mc = (A.bp_features & 6u) != 0;
+      const bool need_mc = MC && (A.bp_features & 6u) != 0;   // MC = 0: compiled for activity only
       if (!need_mc) {  // activity only: variance straight from registers
         const int lo = W - F.bp_seglen + yoff, hi = W + yoff;
         float part[NMX_LANES];
@@ -375,7 +383,11 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         for (int i = 0; i < 16; ++i) {
           const int m = 64 * (i >> 2) + 256 * (i & 3);   // + l
           const float2 val = v[NMX_LI][i];
+#if defined(NMX_EXP) && NMX_EXP == 1
+          if (val.x == 12345.678f) {
+#else
           if (2 * (m + l) + 1 < W) {
+#endif
             if (vec) {
               if (dsw) ((float2*)dsw + l)[m] = val;
               if (dyb) ((float2*)dyb + l)[m] = val;
