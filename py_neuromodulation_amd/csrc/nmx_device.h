@@ -86,6 +86,25 @@ NMX_DEV float2 nmx_mul_i(float2 a) {
   return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
 
+
+// in-register 5-point DFT (DIR = -1 forward, +1 inverse)
+template <int DIR>
+NMX_DEV void nmx_dft5(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4) {
+  const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;
+  const float s1 = DIR * 0.95105651629515353f, s2 = DIR * 0.58778525229247314f;
+  const float2 t1 = nmx_cadd(a1, a4), t2 = nmx_cadd(a2, a3);
+  const float2 d1 = nmx_csub(a1, a4), d2 = nmx_csub(a2, a3);
+  const float2 m1 = make_float2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+  const float2 m2 = make_float2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+  const float2 n1 = make_float2(-(s1 * d1.y + s2 * d2.y), s1 * d1.x + s2 * d2.x);
+  const float2 n2 = make_float2(-(s2 * d1.y - s1 * d2.y), s2 * d1.x - s1 * d2.x);
+  a0 = make_float2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+  a1 = nmx_cadd(m1, n1);
+  a4 = nmx_csub(m1, n1);
+  a2 = nmx_cadd(m2, n2);
+  a3 = nmx_csub(m2, n2);
+}
+
 // ---------------------------------------------------------------------------------------
 // Stockham autosort FFT in LDS.  DIR = -1 forward, +1 inverse (unnormalised).
 // Stage (radix R, Ns = product of earlier radices): butterfly j reads in[j + r * n/R],
@@ -93,7 +112,9 @@ NMX_DEV float2 nmx_mul_i(float2 a) {
 // out[(j / Ns) * Ns * R + k + r * Ns].  Reads are unit-stride across lanes.
 // Returns the buffer that holds the result (a or b); `in0` is never written.
 // ---------------------------------------------------------------------------------------
-template <int DIR>
+// R10 = false compiles the radix-10 branch out (kernels that are register/occupancy limited and
+// whose plans are built without radix 10)
+template <int DIR, bool R10 = false>
 NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b) {
   const float2* in = in0;
   float2* out = a;
@@ -106,7 +127,43 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
       const int k = j - q * ns;
       const int o = q * ns * R + k;
       const int tb = k * tstep;
-      if (R == 4) {
+      if (R10 && R == 10) {
+        // radix 10 = 2 x 5 in registers: three passes for N = 1000 instead of five
+        float2 e0 = in[j], o0 = in[j + m], e1 = in[j + 2 * m], o1 = in[j + 3 * m], e2 = in[j + 4 * m];
+        float2 o2 = in[j + 5 * m], e3 = in[j + 6 * m], o3 = in[j + 7 * m], e4 = in[j + 8 * m], o4 = in[j + 9 * m];
+        if (ns > 1) {
+          // one table gather; w^2..w^9 by at most three multiplications (<= 4 ulp)
+          const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1), w4 = nmx_cmul(w2, w2), w8 = nmx_cmul(w4, w4);
+          const float2 w3 = nmx_cmul(w2, w1);
+          o0 = nmx_cmul(o0, w1);
+          e1 = nmx_cmul(e1, w2);
+          o1 = nmx_cmul(o1, w3);
+          e2 = nmx_cmul(e2, w4);
+          o2 = nmx_cmul(o2, nmx_cmul(w4, w1));
+          e3 = nmx_cmul(e3, nmx_cmul(w4, w2));
+          o3 = nmx_cmul(o3, nmx_cmul(w4, w3));
+          e4 = nmx_cmul(e4, w8);
+          o4 = nmx_cmul(o4, nmx_cmul(w8, w1));
+        }
+        nmx_dft5<DIR>(e0, e1, e2, e3, e4);   // even inputs x0, x2, .., x8
+        nmx_dft5<DIR>(o0, o1, o2, o3, o4);   // odd inputs  x1, x3, .., x9
+        // y[q] = E[q] + w10^q O[q], y[q + 5] = E[q] - w10^q O[q],  w10 = exp(DIR 2 pi i / 10)
+        const float sg = (float)DIR;
+        o1 = nmx_cmul(o1, make_float2(0.80901699437494745f, sg * 0.58778525229247314f));
+        o2 = nmx_cmul(o2, make_float2(0.30901699437494745f, sg * 0.95105651629515353f));
+        o3 = nmx_cmul(o3, make_float2(-0.30901699437494745f, sg * 0.95105651629515353f));
+        o4 = nmx_cmul(o4, make_float2(-0.80901699437494745f, sg * 0.58778525229247314f));
+        out[o] = nmx_cadd(e0, o0);
+        out[o + ns] = nmx_cadd(e1, o1);
+        out[o + 2 * ns] = nmx_cadd(e2, o2);
+        out[o + 3 * ns] = nmx_cadd(e3, o3);
+        out[o + 4 * ns] = nmx_cadd(e4, o4);
+        out[o + 5 * ns] = nmx_csub(e0, o0);
+        out[o + 6 * ns] = nmx_csub(e1, o1);
+        out[o + 7 * ns] = nmx_csub(e2, o2);
+        out[o + 8 * ns] = nmx_csub(e3, o3);
+        out[o + 9 * ns] = nmx_csub(e4, o4);
+      } else if (R == 4) {
         float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m];
         if (ns > 1) {
           // one table gather per butterfly: w^2, w^3 by multiplication (<= 2 ulp) -- the gathers
