@@ -388,6 +388,8 @@ NMX_DEV void nmx_wave_excl_latest(int& pos, double& val) {
 }
 #endif
 
+#define NMX_EP(i) ((i) + ((i) >> 4))
+
 // one WAVE (64 threads) per (window, channel, band)
 NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi, float* smem) {
   float* e = smem + A.off_e;
@@ -395,7 +397,9 @@ NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi
   const int W = A.W;
   const long long item = ((long long)w * A.n_channels + c) * A.n_bands + bi;
   const float* src = A.env + item * W;
-  for (int i = NMX_TID; i < W; i += NMX_NT) e[i] = src[i];
+  // padded layout (one pad dword per 16 samples): per-lane contiguous chunks would otherwise hit
+  // two LDS banks per half-wave (71 % of this kernel's LDS cycles were bank conflicts)
+  for (int i = NMX_TID; i < W; i += NMX_NT) e[NMX_EP(i)] = src[i];
   NMX_SYNC();
   const float thr = A.thr[item];
   // contiguous chunk per lane
@@ -406,8 +410,9 @@ NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi
   int zpos = -1;
   double zpre = 0.0;
   for (int i = i0; i < i1; ++i) {
-    csum += (double)e[i];
-    if (!(e[i] >= thr)) { zpos = i; zpre = csum; }
+    const float ev = e[NMX_EP(i)];
+    csum += (double)ev;
+    if (!(ev >= thr)) { zpos = i; zpre = csum; }
   }
   double total;
   const double base = nmx_wave_excl_sum_d(csum, &total);
@@ -422,9 +427,9 @@ NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi
   double pre = base;
   int lastz = carry_z;
   double lastz_pre = carry_p;
-  bool prev = (i0 > 0 && i0 < W) ? (e[i0 - 1] >= thr) : false;
+  bool prev = (i0 > 0 && i0 < W) ? (e[NMX_EP(i0 - 1)] >= thr) : false;
   for (int i = i0; i < i1; ++i) {
-    const float v = e[i];
+    const float v = e[NMX_EP(i)];
     const bool b = v >= thr;
     if (b != prev) ++n_trans;
     if (b) {
@@ -462,7 +467,7 @@ NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi
     vals[2] = n_valid ? (float)(sm / (double)n_valid) : 0.f;
     vals[3] = amax;
     vals[4] = dmean / A.seg_s;
-    vals[5] = (e[W - 1] >= thr) ? 1.f : 0.f;
+    vals[5] = (e[NMX_EP(W - 1)] >= thr) ? 1.f : 0.f;
     float* row = A.out + (long long)w * A.n_outputs;
     int col = A.cols.base + c * A.cols.ch_stride + bi * A.cols.a_stride;
     for (int s = 0; s < 6; ++s)
