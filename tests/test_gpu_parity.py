@@ -208,3 +208,16 @@ def test_config3_2khz_8bands_generic_path(gpu_lib):
                                        burst_slack=True)
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def test_ragged_float_sfreq_stream(gpu_lib):
+    pc.case_ragged_float_sfreq_stream(gpu_lib)
+
+
+def test_odd_windows_and_spectra(gpu_lib):
+    pc.case_odd_windows_and_spectra(gpu_lib)
+
+
+def test_reference_property_tests(gpu_lib):
+    """Drop-in plugin classes (package loader, no lib injection) under the reference's property tests."""
+    pc.case_reference_property_tests(gpu_lib)

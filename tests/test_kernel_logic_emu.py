@@ -68,3 +68,11 @@ def test_pipeline_nan_and_channel_table(emu_lib):
 
 def test_bursts_steady_state_vs_oracle(emu_lib):
     pc.case_bursts_steady_state_vs_oracle(emu_lib)
+
+
+def test_ragged_float_sfreq_stream(emu_lib):
+    pc.case_ragged_float_sfreq_stream(emu_lib)
+
+
+def test_odd_windows_and_spectra(emu_lib):
+    pc.case_odd_windows_and_spectra(emu_lib)
