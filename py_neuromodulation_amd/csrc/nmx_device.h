@@ -246,6 +246,123 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
   return (float2*)in;
 }
 
+// ---------------------------------------------------------------------------------------
+// Statically planned transforms for the default window lengths (1 s / 500 ms at 1 kHz:
+// n = 1000, 500, 250).  The generic engine above is driven by a run-time stage table: per stage
+// it costs scalar loads of the stage record, a radix switch and run-time index division -- and a
+// CU has ONE scalar unit shared by all its waves; the first profiles showed as many SALU as
+// VALU instructions in the FFT kernels (SQ_INSTS_SALU ~ SQ_INSTS_VALU), i.e. they were
+// scalar-issue bound.  Here radix, Ns and all strides are compile-time constants.
+// ---------------------------------------------------------------------------------------
+template <int DIR, int R, int NS, int N>
+NMX_DEV void nmx_stage_static(const float2* in, float2* out, const float2* NMX_RESTRICT tw) {
+  constexpr int m = N / R, tstep = N / (NS * R);
+  for (int j = NMX_TID; j < m; j += NMX_NT) {
+    const int q = j / NS, k = j - q * NS;   // NS is a constant: mul/shift, no division
+    const int o = q * NS * R + k;
+    const int tb = k * tstep;
+    if (R == 10) {
+      float2 e0 = in[j], o0 = in[j + m], e1 = in[j + 2 * m], o1 = in[j + 3 * m], e2 = in[j + 4 * m];
+      float2 o2 = in[j + 5 * m], e3 = in[j + 6 * m], o3 = in[j + 7 * m], e4 = in[j + 8 * m], o4 = in[j + 9 * m];
+      if (NS > 1) {
+        const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1), w4 = nmx_cmul(w2, w2), w8 = nmx_cmul(w4, w4);
+        const float2 w3 = nmx_cmul(w2, w1);
+        o0 = nmx_cmul(o0, w1);
+        e1 = nmx_cmul(e1, w2);
+        o1 = nmx_cmul(o1, w3);
+        e2 = nmx_cmul(e2, w4);
+        o2 = nmx_cmul(o2, nmx_cmul(w4, w1));
+        e3 = nmx_cmul(e3, nmx_cmul(w4, w2));
+        o3 = nmx_cmul(o3, nmx_cmul(w4, w3));
+        e4 = nmx_cmul(e4, w8);
+        o4 = nmx_cmul(o4, nmx_cmul(w8, w1));
+      }
+      nmx_dft5<DIR>(e0, e1, e2, e3, e4);
+      nmx_dft5<DIR>(o0, o1, o2, o3, o4);
+      const float sg = (float)DIR;
+      o1 = nmx_cmul(o1, make_float2(0.80901699437494745f, sg * 0.58778525229247314f));
+      o2 = nmx_cmul(o2, make_float2(0.30901699437494745f, sg * 0.95105651629515353f));
+      o3 = nmx_cmul(o3, make_float2(-0.30901699437494745f, sg * 0.95105651629515353f));
+      o4 = nmx_cmul(o4, make_float2(-0.80901699437494745f, sg * 0.58778525229247314f));
+      out[o] = nmx_cadd(e0, o0);
+      out[o + NS] = nmx_cadd(e1, o1);
+      out[o + 2 * NS] = nmx_cadd(e2, o2);
+      out[o + 3 * NS] = nmx_cadd(e3, o3);
+      out[o + 4 * NS] = nmx_cadd(e4, o4);
+      out[o + 5 * NS] = nmx_csub(e0, o0);
+      out[o + 6 * NS] = nmx_csub(e1, o1);
+      out[o + 7 * NS] = nmx_csub(e2, o2);
+      out[o + 8 * NS] = nmx_csub(e3, o3);
+      out[o + 9 * NS] = nmx_csub(e4, o4);
+    } else if (R == 5) {
+      float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m], a4 = in[j + 4 * m];
+      if (NS > 1) {
+        const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1);
+        a1 = nmx_cmul(a1, w1);
+        a2 = nmx_cmul(a2, w2);
+        a3 = nmx_cmul(a3, nmx_cmul(w2, w1));
+        a4 = nmx_cmul(a4, nmx_cmul(w2, w2));
+      }
+      nmx_dft5<DIR>(a0, a1, a2, a3, a4);
+      out[o] = a0; out[o + NS] = a1; out[o + 2 * NS] = a2; out[o + 3 * NS] = a3; out[o + 4 * NS] = a4;
+    } else if (R == 4) {
+      float2 a0 = in[j], a1 = in[j + m], a2 = in[j + 2 * m], a3 = in[j + 3 * m];
+      if (NS > 1) {
+        const float2 w1 = nmx_tw<DIR>(tw, tb), w2 = nmx_cmul(w1, w1);
+        a1 = nmx_cmul(a1, w1);
+        a2 = nmx_cmul(a2, w2);
+        a3 = nmx_cmul(a3, nmx_cmul(w2, w1));
+      }
+      const float2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+      const float2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
+      out[o] = nmx_cadd(t0, t2);
+      out[o + NS] = nmx_cadd(t1, t3);
+      out[o + 2 * NS] = nmx_csub(t0, t2);
+      out[o + 3 * NS] = nmx_csub(t1, t3);
+    } else {  // R == 2
+      float2 a0 = in[j], a1 = in[j + m];
+      if (NS > 1) a1 = nmx_cmul(a1, nmx_tw<DIR>(tw, tb));
+      out[o] = nmx_cadd(a0, a1);
+      out[o + NS] = nmx_csub(a0, a1);
+    }
+  }
+  NMX_SYNC();
+}
+
+// three / four statically planned stages; same buffer protocol as nmx_fft (in0 never written)
+template <int DIR, int N, int R1, int R2, int R3>
+NMX_DEV float2* nmx_fft3(const float2* in0, float2* a, float2* b, const float2* tw) {
+  nmx_stage_static<DIR, R1, 1, N>(in0, a, tw);
+  nmx_stage_static<DIR, R2, R1, N>(a, b, tw);
+  nmx_stage_static<DIR, R3, R1 * R2, N>(b, a, tw);
+  return a;
+}
+template <int DIR, int N, int R1, int R2, int R3, int R4>
+NMX_DEV float2* nmx_fft4(const float2* in0, float2* a, float2* b, const float2* tw) {
+  nmx_stage_static<DIR, R1, 1, N>(in0, a, tw);
+  nmx_stage_static<DIR, R2, R1, N>(a, b, tw);
+  nmx_stage_static<DIR, R3, R1 * R2, N>(b, a, tw);
+  nmx_stage_static<DIR, R4, R1 * R2 * R3, N>(a, b, tw);
+  return b;
+}
+
+// dispatcher: static plan when one exists for p.n, generic stage table otherwise.
+// R10: allow the radix-10 plans (more registers, fewer LDS passes).
+template <int DIR, bool R10 = false>
+NMX_DEV float2* nmx_fft_auto(const NmxFft& p, const float2* in0, float2* a, float2* b) {
+#ifndef NMX_NO_STATIC_FFT
+  if (R10) {
+    if (p.n == 1000) return nmx_fft3<DIR, 1000, 10, 10, 10>(in0, a, b, p.tw);
+    if (p.n == 500) return nmx_fft3<DIR, 500, 10, 10, 5>(in0, a, b, p.tw);
+    if (p.n == 250) return nmx_fft3<DIR, 250, 10, 5, 5>(in0, a, b, p.tw);
+  } else {
+    if (p.n == 500) return nmx_fft4<DIR, 500, 5, 5, 5, 4>(in0, a, b, p.tw);
+    if (p.n == 250) return nmx_fft4<DIR, 250, 5, 5, 5, 2>(in0, a, b, p.tw);
+  }
+#endif
+  return nmx_fft<DIR, R10>(p, in0, a, b);
+}
+
 // Forward real FFT of even length N = 2 n from the half-length transform Z of
 // z[k] = x[2k] + i x[2k+1]:  X[k] = E[k] + exp(-2 pi i k / N) O[k],  k = 0..n.
 NMX_DEV float2 nmx_rfft_bin(const float2* Z, const float2* NMX_RESTRICT twr, int n, int k) {

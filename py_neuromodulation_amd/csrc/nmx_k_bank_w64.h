@@ -439,7 +439,7 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
     for (int i = NMX_TID; i < Wh; i += NMX_NT) bufB[i] = make_float2(src[2 * i], src[2 * i + 1]);
   }
   NMX_SYNC();
-  const float2* Zy = nmx_fft<-1, true>(A.hil_r, bufB, bufA, bufB);
+  const float2* Zy = nmx_fft_auto<-1, true>(A.hil_r, bufB, bufA, bufB);
   float2* Ab = (Zy == bufA) ? bufB : bufA;
   const float invW = 1.f / (float)W;
   // one-sided spectrum; Zy (W/2 points) and Ab (W points) live in different buffers
@@ -456,7 +456,7 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
   }
   NMX_SYNC();
   float2* Zbuf = (Ab == bufA) ? bufB : bufA;
-  const float2* an = nmx_fft<+1, true>(A.hil_c, Ab, Zbuf, Ab);
+  const float2* an = nmx_fft_auto<+1, true>(A.hil_c, Ab, Zbuf, Ab);
   float* dst = A.env + item * W;
   for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
 }

@@ -87,7 +87,7 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
 // real transform of the packed / windowed segment already sitting in `bufB` (as n/2 complex,
 // or n complex with zero imaginary part when O.complex_full); returns pointer to Z
 NMX_DEV float2* nmx_osc_fft(const NmxOsc& O, float2* bufA, float2* bufB) {
-  return nmx_fft<-1>(O.fft, bufB, bufA, bufB);
+  return nmx_fft_auto<-1>(O.fft, bufB, bufA, bufB);
 }
 
 NMX_DEV float2 nmx_osc_bin(const NmxOsc& O, const float2* Z, int k) {
