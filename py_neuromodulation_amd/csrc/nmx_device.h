@@ -55,6 +55,38 @@ NMX_DEV int nmx_block_or(int v, float* red) {
 }
 #endif
 
+// several sums with ONE barrier pair (the shuffle chains of the values interleave); N <= 8,
+// compile-time so the value array stays in registers
+#ifdef NMX_HOST_EMU
+template <int N>
+NMX_DEV void nmx_block_sum_n(float*, float*) {}
+#else
+template <int N>
+NMX_DEV void nmx_block_sum_n(float* v, float* red) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float t = v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    v[i] = t;
+  }
+  const int nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[(threadIdx.x >> 6) * 8 + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float t = red[i];
+    for (int w = 1; w < nw; ++w) t += red[w * 8 + i];
+    v[i] = t;
+  }
+}
+#endif
+
 NMX_DEV float nmx_nanmax(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
 NMX_DEV float nmx_nanmin(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
 

@@ -294,16 +294,10 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         float2 zc = make_float2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
 #endif
         if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
-#if defined(NMX_EXP) && NMX_EXP == 3
-        const float ha = 0.5f + 0.001f * r, hb = 0.25f;
-#else
         const float ha = (Hs + l)[64 * r], hb = (Hd + l)[64 * r];
-#endif
         // Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),  A = Hs - Hd sin(th_k), B = Hd cos(th_k)
         vv[r] = make_float2(ha * zk.x + hb * zc.y, ha * zk.y + hb * zc.x);
-#if !defined(NMX_EXP) || NMX_EXP != 2
         if ((r & 3) == 3) NMX_SCHED_FENCE();
-#endif
       }
       nmx_w64_passA<+1>(vv, X, l);
     }
@@ -383,11 +377,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         for (int i = 0; i < 16; ++i) {
           const int m = 64 * (i >> 2) + 256 * (i & 3);   // + l
           const float2 val = v[NMX_LI][i];
-#if defined(NMX_EXP) && NMX_EXP == 1
-          if (val.x == 12345.678f) {
-#else
           if (2 * (m + l) + 1 < W) {
-#endif
             if (vec) {
               if (dsw) ((float2*)dsw + l)[m] = val;
               if (dyb) ((float2*)dyb + l)[m] = val;

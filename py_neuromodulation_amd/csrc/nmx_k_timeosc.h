@@ -53,6 +53,34 @@ NMX_DEV void nmx_hjorth(const float* y, int n, float* red, int mode, bool need_m
 
 NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin, int n_bands,
                             float* out_row, int c, float* red) {
+  if (O.estimators == NMXD_EST_MEAN && n_bands <= 8) {
+    // default configuration: all band means with one multi-value reduction
+    float p[8];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+    for (int b = 0; b < 8; ++b) {
+      float sacc = 0.f;
+      if (b < n_bands) {
+        const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
+        const float* v = spec + (O.bin_lo[b] - O.k_lo) * vals_per_bin;
+        for (int i = NMX_TID; i < cnt; i += NMX_NT) sacc += v[i];
+      }
+      p[b] = sacc;
+    }
+    nmx_block_sum_n<8>(p, red);
+    if (NMX_TID == 0) {
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int b = 0; b < 8; ++b)
+        if (b < n_bands) {
+          const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
+          out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? p[b] / (float)cnt : NAN;
+        }
+    }
+    return;
+  }
   for (int b = 0; b < n_bands; ++b) {
     const int lo = O.bin_lo[b], hi = O.bin_hi[b];
     const int cnt = (hi - lo) * vals_per_bin;
@@ -114,26 +142,59 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
   }
   NMX_SYNC();
 
-  // ---- time-domain features -----------------------------------------------------------
-  if (A.features & NMXD_F_HJORTH) {
-    float act, mob, comp;
-    nmx_hjorth(xs, W, red, 0, true, act, mob, comp);
+  // ---- time-domain features: Hjorth + LineLength fused, two multi-value reductions ---------
+  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH)) {
+    // pass 1: sums of x, dx, d2x (for the means) and of |dx| (line length)
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = NMX_TID; i < W; i += NMX_NT) {
+      const float x0 = xs[i];
+      p[0] += x0;
+      if (i + 1 < W) {
+        const float d1 = xs[i + 1] - x0;
+        p[1] += d1;
+        p[3] += fabsf(d1);
+        if (i + 2 < W) p[2] += (xs[i + 2] - xs[i + 1]) - d1;
+      }
+    }
+    nmx_block_sum_n<4>(p, red);
+    const float m0 = p[0] / (float)W, m1 = p[1] / (float)(W - 1), m2 = p[2] / (float)(W - 2);
+    const float ll = p[3];
+    // pass 2: mean-shifted sums of squares (np.var is two-pass)
+    float q[3] = {0.f, 0.f, 0.f};
+    for (int i = NMX_TID; i < W; i += NMX_NT) {
+      const float x0 = xs[i];
+      const float e0 = x0 - m0;
+      q[0] += e0 * e0;
+      if (i + 1 < W) {
+        const float d1 = xs[i + 1] - x0;
+        const float e1 = d1 - m1;
+        q[1] += e1 * e1;
+        if (i + 2 < W) {
+          const float e2 = ((xs[i + 2] - xs[i + 1]) - d1) - m2;
+          q[2] += e2 * e2;
+        }
+      }
+    }
+    nmx_block_sum_n<3>(q, red);
     if (NMX_TID == 0) {
-      const int col = A.hjorth_cols.base + c * A.hjorth_cols.ch_stride;
-      out_row[col] = nmx_nan_to_num(act);
-      out_row[col + A.hjorth_cols.a_stride] = mob;
-      out_row[col + 2 * A.hjorth_cols.a_stride] = comp;
+      if (A.features & NMXD_F_HJORTH) {
+        const float v0 = q[0] / (float)W, v1 = q[1] / (float)(W - 1), v2 = q[2] / (float)(W - 2);
+        // hjorth_raw.py:24-34: complexity divides by the nan_to_num'ed mobility
+        const float mob = nmx_nan_to_num(sqrtf(v1 / v0));
+        const float comp = nmx_nan_to_num(sqrtf(v2 / v1) / mob);
+        const int col = A.hjorth_cols.base + c * A.hjorth_cols.ch_stride;
+        out_row[col] = nmx_nan_to_num(v0);
+        out_row[col + A.hjorth_cols.a_stride] = mob;
+        out_row[col + 2 * A.hjorth_cols.a_stride] = comp;
+      }
+      if (A.features & NMXD_F_LINELENGTH) {
+        const float wm1 = (float)(W - 1);
+        out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = ll / wm1 / wm1;
+      }
     }
   }
   if ((A.features & NMXD_F_RAW) && NMX_TID == 0)
     out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = xs[W - 1];
-  if (A.features & NMXD_F_LINELENGTH) {
-    float s = 0.f;
-    for (int i = NMX_TID; i < W - 1; i += NMX_NT) s += fabsf(xs[i + 1] - xs[i]);
-    s = nmx_block_sum(s, red);
-    const float wm1 = (float)(W - 1);
-    if (NMX_TID == 0) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = s / wm1 / wm1;
-  }
 
   // ---- FFT band power -------------------------------------------------------------------
   if (A.fft.enabled) {
