@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Host-boundary numbers that are NOT bench.py's `value`: PCIe-inclusive batch rate (host buffers
+in / out through nmx_process_batch memspace 0) and the latency of the reference's one-window call
+shape (DataProcessor.process -> dict) on the bench workload."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench  # noqa: E402
+
+
+def main():
+    from py_neuromodulation_amd import fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = bench.make_settings()
+    C, W, hop, n = 256, 1000, 100, 1024
+    T = W + (n - 1) * hop
+    eng = HotPathEngine(s, [f"ch{i}_avgref" for i in range(C)], 1000.0, ref_matrix=bench.car_matrix(C),
+                        notch_taps=fir_design.notch_bank(1000.0, 50))
+    x = bench.synth(C, T, 1000.0, 1)
+    starts = np.arange(n, dtype=np.int64) * hop
+    eng.process_batch(x, starts)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        eng.process_batch(x, starts)
+    dt = (time.perf_counter() - t0) / reps
+    lat = []
+    w64 = x[:, :W].astype(np.float64)
+    for _ in range(30):
+        t1 = time.perf_counter()
+        out = eng.process_window(w64)
+        d = dict(zip(eng.keys, out.tolist()))
+        lat.append(time.perf_counter() - t1)
+    print(json.dumps({"pcie_inclusive_windows_per_s": n / dt, "ms_per_1024_hops": dt * 1e3,
+                      "h2d_MB": x.nbytes / 1e6, "d2h_MB": n * eng.n_outputs * 4 / 1e6,
+                      "one_window_256ch_latency_ms_median": float(np.median(lat)) * 1e3,
+                      "one_window_features": len(d)}))
+
+
+if __name__ == "__main__":
+    main()
