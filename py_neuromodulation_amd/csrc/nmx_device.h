@@ -99,6 +99,55 @@ NMX_DEV float nmx_clean(float v) {
 }
 
 // ---------------------------------------------------------------------------------------
+// row staging (global -> LDS)
+// ---------------------------------------------------------------------------------------
+// `for (i = tid; i < n; i += nt) dst[i] = src[i]` with a run-time trip count compiles to
+// load -> s_waitcnt vmcnt(0) -> ds_write per iteration: n/nt SERIALIZED HBM round trips per item
+// (the first profiles spent ~15 us per single-wave item just there).  nmx_stage_row issues a batch of
+// independent loads (16-byte ones when the row is aligned) before the first store.  `put(i, v)`
+// receives element i of the row.
+template <class Put>
+NMX_DEV void nmx_stage_row(const float* src, int n, Put put) {
+#ifdef NMX_HOST_EMU
+  for (int i = 0; i < n; ++i) put(i, src[i]);
+#else
+  const int nt = NMX_NT, tid = NMX_TID;
+  if ((((unsigned long long)src) & 15ull) == 0ull) {
+    const float4* s4 = (const float4*)src;
+    const int n4 = n >> 2;
+    for (int base = 0; base < n4; base += 4 * nt) {
+      float4 r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = base + k * nt + tid;
+        r[k] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = base + k * nt + tid;
+        if (i < n4) { put(4 * i, r[k].x); put(4 * i + 1, r[k].y); put(4 * i + 2, r[k].z); put(4 * i + 3, r[k].w); }
+      }
+    }
+    for (int i = 4 * n4 + tid; i < n; i += nt) put(i, src[i]);   // <= 3 elements
+  } else {
+    for (int base = 0; base < n; base += 8 * nt) {
+      float r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + k * nt + tid;
+        r[k] = i < n ? src[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + k * nt + tid;
+        if (i < n) put(i, r[k]);
+      }
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
 // complex helpers
 // ---------------------------------------------------------------------------------------
 NMX_DEV float2 nmx_cmul(float2 a, float2 b) {

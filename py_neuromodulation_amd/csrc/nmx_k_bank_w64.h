@@ -219,10 +219,17 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
     float* xs = (float*)X;
     NMX_LANE_LOOP {
-      for (int i = l; i < W; i += 64) {
-        float t = src[i];
-        if (A.clean_on_load) t = nmx_clean(t);
-        xs[i] = t;
+      // all 16 loads in flight before the first LDS store (W < 1024 on this path)
+      float t[16];
+      NMX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int i = l + 64 * r;
+        t[r] = i < W ? src[i] : 0.f;
+      }
+      NMX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int i = l + 64 * r;
+        if (i < W) xs[i] = A.clean_on_load ? nmx_clean(t[r]) : t[r];
       }
     }
     NMX_WSYNC();
@@ -424,9 +431,10 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
   const int W = A.W, Wh = W >> 1;
   const float* src = A.y + item * W;
   if (A.hil_full) {
-    for (int i = NMX_TID; i < W; i += NMX_NT) bufB[i] = make_float2(src[i], 0.f);
+    nmx_stage_row(src, W, [=](int i, float v) { bufB[i] = make_float2(v, 0.f); });
   } else {
-    for (int i = NMX_TID; i < Wh; i += NMX_NT) bufB[i] = make_float2(src[2 * i], src[2 * i + 1]);
+    float* pk = (float*)bufB;   // packed complex: (x[2i], x[2i+1])
+    nmx_stage_row(src, W, [=](int i, float v) { pk[i] = v; });
   }
   NMX_SYNC();
   const float2* Zy = nmx_fft_auto<-1, true>(A.hil_r, bufB, bufA, bufB);

@@ -399,7 +399,7 @@ NMX_DEV void nmx_burst_stat_item(const NmxBurstStatArgs& A, int w, int c, int bi
   const float* src = A.env + item * W;
   // padded layout (one pad dword per 16 samples): per-lane contiguous chunks would otherwise hit
   // two LDS banks per half-wave (71 % of this kernel's LDS cycles were bank conflicts)
-  for (int i = NMX_TID; i < W; i += NMX_NT) e[NMX_EP(i)] = src[i];
+  nmx_stage_row(src, W, [=](int i, float v) { e[NMX_EP(i)] = v; });
   NMX_SYNC();
   const float thr = A.thr[item];
   // contiguous chunk per lane

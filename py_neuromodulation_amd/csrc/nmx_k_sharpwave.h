@@ -45,6 +45,8 @@ struct NmxSharpArgs {
   NmxCols cols;       // a = filter, b = slot (x n_polarities + polarity when !between)
   NmxCols np_cols;    // num_peaks (between mode), a = filter
   int has_num_peaks;
+  int dbg_skip;          // experiment switch (0 in production)
+  int fast_estimators;   // all pairs are mean/max/min of loop-free per-trough quantities
   // LDS carve (float offsets): z[W] | emax,emin,selP,selT,lf,rt (u16[pm]) | st (u8[2 pm]) | vals | res | red
   int off_z, off_emax, off_emin, off_selp, off_selt, off_lf, off_rt, off_st, off_vals, off_res, off_red;
   int pm;           // capacity of the index lists (W / 2 + 2)
@@ -72,6 +74,7 @@ NMX_DEV int nmx_wave_any(int v) { return __any(v); }
 // ---- extrema detection -----------------------------------------------------------------------
 // SciPy _local_maxima_1d on z (maxima) and on -z (minima) in one pass.  Lane chunk [i0, i1);
 // a plateau is owned by the lane of its first sample; its midpoint may lie beyond the chunk.
+#ifdef NMX_HOST_EMU
 NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min) {
   const int n_idx = W - 2;
   const int chunk = n_idx > 0 ? (n_idx + NMX_NT - 1) / NMX_NT : 0;
@@ -119,6 +122,59 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
   }
   NMX_SYNC();
 }
+#else
+// Device version: the per-lane chunk (<= 64 samples) is classified without branches into two
+// bitmasks (a divergent `if` costs several scalar instructions and the CU has one scalar unit);
+// only plateau starts -- rare -- take a branch.  Bit k = extremum whose (plateau) start is i0 + k.
+NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min) {
+  const int n_idx = W - 2;
+  const int chunk = n_idx > 0 ? (n_idx + NMX_NT - 1) / NMX_NT : 0;
+  const int i0 = 1 + NMX_TID * chunk;
+  const int i1 = (i0 + chunk) < (W - 1) ? (i0 + chunk) : (W - 1);
+  unsigned long long mmax = 0ull, mmin = 0ull;
+  if (i0 < i1) {
+    float prev = z[i0 - 1], cur = z[i0];
+    for (int i = i0; i < i1; ++i) {
+      const float nxt = z[i + 1];
+      const bool up = prev < cur, dn = prev > cur;
+      const unsigned long long bit = 1ull << (i - i0);
+      mmax |= (up && nxt < cur) ? bit : 0ull;
+      mmin |= (dn && nxt > cur) ? bit : 0ull;
+      if ((up || dn) && nxt == cur) {   // plateau start (rare)
+        int ahead = i + 1;
+        float a = nxt;
+        while (a == cur && ahead < W - 1) { ++ahead; a = z[ahead]; }
+        if (up && a < cur) mmax |= bit;
+        if (dn && a > cur) mmin |= bit;
+      }
+      prev = cur;
+      cur = nxt;
+    }
+  }
+  int total;
+  const int base = nmx_wave_excl_sum_i(__popcll(mmax) | (__popcll(mmin) << 16), &total);
+  int bmax = base & 0xffff, bmin = base >> 16;
+  *n_max = total & 0xffff;
+  *n_min = total >> 16;
+  while (mmax) {
+    const int i = i0 + __ffsll((long long)mmax) - 1;
+    mmax &= mmax - 1;
+    int ahead = i + 1;
+    const float cur = z[i];
+    while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    emax[bmax++] = (nmx_u16)((i + ahead - 1) >> 1);
+  }
+  while (mmin) {
+    const int i = i0 + __ffsll((long long)mmin) - 1;
+    mmin &= mmin - 1;
+    int ahead = i + 1;
+    const float cur = z[i];
+    while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    emin[bmin++] = (nmx_u16)((i + ahead - 1) >> 1);
+  }
+  NMX_SYNC();
+}
+#endif
 
 // ---- distance selection (two problems per call share barriers) -------------------------------
 struct NmxSelProb {
@@ -240,10 +296,10 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
   float* red = smem + A.off_red;
   const int W = A.W;
   const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
-  for (int i = NMX_TID; i < W; i += NMX_NT) z[i] = src[i];
+  nmx_stage_row(src, W, [=](int i, float v) { z[i] = v; });
   NMX_SYNC();
   int n_max = 0, n_min = 0;
-  nmx_extrema(z, W, emax, emin, &n_max, &n_min);
+  if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min);
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
@@ -256,7 +312,7 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
     P[0].dist = A.dist_peaks; P[0].st = st; P[0].out = selP; P[0].n_out = 0;
     P[1].pos = pol == 0 ? emin : emax; P[1].n = pol == 0 ? n_min : n_max; P[1].sgn = -sgn;
     P[1].dist = A.dist_troughs; P[1].st = st + A.pm; P[1].out = selT; P[1].n_out = 0;
-    nmx_select2(z, P);
+    if (A.dbg_skip & 1) { P[0].n_out = 0; P[1].n_out = 0; } else nmx_select2(z, P);
     const int nPk = P[0].n_out, nTr = P[1].n_out;
     const nmx_u16* pk = selP;
     const nmx_u16* tr = selT;
@@ -264,8 +320,11 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
     int n_leftinv = 0, lastv = 0, n_pairs = 0;
     for (int i = NMX_TID; i < nTr; i += NMX_NT) {
       const int t = tr[i];
-      int lo = 0, hi = nPk;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pk[mid] < t) lo = mid + 1; else hi = mid; }
+      int lo = 0;   // number of peaks before t: branch-free bisection (nPk <= 1024)
+      for (int step = 512; step > 0; step >>= 1) {
+        const int idx = lo + step;
+        lo = (idx <= nPk && (int)pk[idx - 1] < t) ? idx : lo;
+      }
       lf[i] = (nmx_u16)lo;   // temporarily the pointer
       if (lo == 0) ++n_leftinv;
       else if (lo < nPk) { lastv = i > lastv ? i : lastv; ++n_pairs; }
@@ -303,6 +362,52 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
     NMX_SYNC();
     const int nPT = (n_pairs == nT) ? n_pairs : 0;  // arrays that broadcast pairs with troughs
     if (NMX_TID == 0) res[2 * A.n_combos + pol] = (float)nT;
+#ifndef NMX_HOST_EMU
+    if (A.fast_estimators) {
+      // every (feature, estimator) pair is an associative reduction (mean / max / min) of a
+      // per-trough quantity that needs no inner loop: ONE pass over the troughs, no value lists,
+      // one shuffle reduction per pair (default settings: 3 pairs)
+      const int s_off = A.sharp_off;
+      for (int cb = 0; cb < A.n_combos; ++cb) {
+        const int f = A.combo_feature[cb], e = A.combo_est[cb];
+        if (f == NMX_SW_NUM_PEAKS) continue;
+        float acc = e == NMX_SWE_MEAN ? 0.f : (e == NMX_SWE_MAX ? -INFINITY : INFINITY);
+        int cnt = 0;
+        const int n = (f == NMX_SW_PEAK_LEFT || f == NMX_SW_PEAK_RIGHT || f == NMX_SW_WIDTH) ? n_pairs
+                      : ((f == NMX_SW_TROUGH || f == NMX_SW_INTERVAL || f == NMX_SW_SHARPNESS) ? nT : nPT);
+        for (int p = NMX_TID; p < n; p += NMX_NT) {
+          float v;
+          bool ok = true;
+          switch (f) {
+            case NMX_SW_PEAK_LEFT: v = sgn * z[lf[p]]; break;
+            case NMX_SW_PEAK_RIGHT: v = sgn * z[rt[p]]; break;
+            case NMX_SW_TROUGH: v = sgn * z[trv[p]]; break;
+            case NMX_SW_WIDTH: v = (float)((int)rt[p] - (int)lf[p]); break;
+            case NMX_SW_PROMINENCE: v = fabsf((sgn * z[rt[p]] + sgn * z[lf[p]]) * 0.5f - sgn * z[trv[p]]); break;
+            case NMX_SW_INTERVAL: v = p == 0 ? 0.f : (float)((int)trv[p] - (int)trv[p - 1]) * A.ms; break;
+            case NMX_SW_DECAY_TIME: v = (float)((int)lf[p] - (int)trv[p]) * A.ms; break;
+            case NMX_SW_RISE_TIME: v = (float)((int)rt[p] - (int)trv[p]) * A.ms; break;
+            default: {  // NMX_SW_SHARPNESS
+              const int t = trv[p];
+              ok = (t - s_off > 0) && (t + s_off < W);
+              v = ok ? sgn * z[t] - 0.5f * (sgn * z[t - s_off] + sgn * z[t + s_off]) : 0.f;
+            }
+          }
+          if (ok) {
+            ++cnt;
+            acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_nanmax(acc, v) : nmx_nanmin(acc, v));
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float t2 = __shfl_xor(acc, o);
+          acc = e == NMX_SWE_MEAN ? acc + t2 : (e == NMX_SWE_MAX ? nmx_nanmax(acc, t2) : nmx_nanmin(acc, t2));
+          cnt += __shfl_xor(cnt, o);
+        }
+        if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
+      }
+    } else
+#endif
     for (int f = 0; f < NMX_SW_NFEAT; ++f) {
       if (!(A.feature_mask & (1u << f)) || f == NMX_SW_NUM_PEAKS) continue;
       int n = 0;

@@ -135,10 +135,9 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
   // ---- stage the window in LDS (lane-consecutive, coalesced) ---------------------------
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
                      (A.starts ? A.starts[w] : 0ll);
-  for (int i = NMX_TID; i < W; i += NMX_NT) {
-    float v = src[i];
-    if (A.clean_on_load) v = nmx_clean(v);
-    xs[i] = v;
+  {
+    const int clean = A.clean_on_load;
+    nmx_stage_row(src, W, [=](int i, float v) { xs[i] = clean ? nmx_clean(v) : v; });
   }
   NMX_SYNC();
 
