@@ -32,16 +32,9 @@ __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs 
   const int item = blockIdx.x;
   nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
 }
-__global__ void __launch_bounds__(64) nmx_kern_burst_stat(const NmxBurstStatArgs A) {
-  const int item = blockIdx.x;
-  const int bi = item % A.n_bands, r = item / A.n_bands;
-  nmx_burst_stat_item(A, r / A.n_channels, r % A.n_channels, bi, nmx_smem);
-}
-__global__ void __launch_bounds__(64) nmx_kern_sharp(const NmxSharpArgs A) {
-  const int item = blockIdx.x;
-  const int fi = item % A.n_filters, r = item / A.n_filters;
-  nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem);
-}
+// one-item-per-wave kernels live in nmx_wave.hip (compile-time workgroup size)
+extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_items, size_t lds, hipStream_t s);
+extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s);
 __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
   nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
 }
@@ -156,8 +149,6 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<32>);
   be_allow_lds(nmx_kern_burst_thr<64>);
   be_allow_lds(nmx_kern_burst_thr<128>);
-  be_allow_lds(nmx_kern_burst_stat);
-  be_allow_lds(nmx_kern_sharp);
 }
 
 static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
@@ -207,11 +198,11 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, s
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t s) {
   be_init_once();
-  hipLaunchKernelGGL(nmx_kern_burst_stat, dim3(n_items), dim3(64), lds, s, A);
+  nmx_wave_launch_burst_stat(&A, n_items, lds, s);
 }
 static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_stream_t s) {
   be_init_once();
-  hipLaunchKernelGGL(nmx_kern_sharp, dim3(n_items), dim3(64), lds, s, A);
+  nmx_wave_launch_sharp(&A, n_items, lds, s);
 }
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));

@@ -25,19 +25,46 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #else
 #include <hip/hip_runtime.h>
 #define NMX_DEV __device__ __forceinline__
+#ifdef NMX_NT_FIXED
+// translation units of the one-item-per-WAVE kernels (nmx_wave.hip): the workgroup size is a
+// compile-time 64, so no blockDim load from the implicit kernel arguments (a dependent global
+// load at the top of every item) and every "block" reduction collapses to its wave part
+#define NMX_TID ((int)(threadIdx.x & 63))
+#define NMX_NT 64
+#else
 #define NMX_TID ((int)threadIdx.x)
 #define NMX_NT ((int)blockDim.x)
+#endif
 // Workgroup barrier.  A single-wave workgroup needs no s_barrier: its LDS operations execute
 // in order, so a compiler fence + lgkmcnt(0) is enough -- and, unlike __syncthreads(), it does
 // not drain vmcnt, i.e. it does not stall on outstanding global loads/stores (table prefetches,
 // result stores) at every phase boundary.
 #define NMX_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef NMX_NT_FIXED
+#define NMX_SYNC() NMX_WAVE_FENCE()
+#else
 #define NMX_SYNC()                                   \
   do {                                               \
     if (blockDim.x <= 64) { NMX_WAVE_FENCE(); }      \
     else { __syncthreads(); }                        \
   } while (0)
+#endif
 #define NMX_RESTRICT __restrict__
+#endif
+
+// Values that are wave-uniform by construction but that the compiler cannot prove uniform (results
+// of vector memory loads, threadIdx >> 6): moving them to SGPRs keeps the derived addresses, buffer
+// descriptors and branches on the scalar unit.
+#ifdef NMX_HOST_EMU
+static inline int nmx_uniform_i(int v) { return v; }
+static inline long long nmx_uniform_ll(long long v) { return v; }
+#else
+__device__ __forceinline__ int nmx_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long nmx_uniform_ll(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 #endif
 
 #define NMX_MAX_STAGES 12

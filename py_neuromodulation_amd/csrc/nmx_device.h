@@ -28,7 +28,7 @@ template <typename T, typename Op>
 NMX_DEV T nmx_block_reduce(T v, float* red, Op op) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
-  const int nw = (blockDim.x + 63) >> 6;
+  const int nw = (NMX_NT + 63) >> 6;
   if (nw == 1) return v;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) ((T*)red)[threadIdx.x >> 6] = v;
@@ -70,7 +70,7 @@ NMX_DEV void nmx_block_sum_n(float* v, float* red) {
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     v[i] = t;
   }
-  const int nw = (blockDim.x + 63) >> 6;
+  const int nw = (NMX_NT + 63) >> 6;
   if (nw == 1) return;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
@@ -147,32 +147,85 @@ NMX_DEV void nmx_stage_row(const float* src, int n, Put put) {
 #endif
 }
 
+// ---- packed complex arithmetic ---------------------------------------------------------------
+// All four kernels of the path are VALU-issue bound (PMC: 60-80 % of the SIMD issue slots), and
+// v_pk_{add,mul,fma}_f32 process a (re, im) pair per lane at the rate of one scalar-float op.  The
+// register-blocked transform therefore works on a 2-element ext-vector type: a complex add is ONE
+// instruction, a complex multiply TWO (pk_mul + pk_fma; the (im, re) swizzle and the sign go into
+// the op_sel / neg modifiers), multiplication by +-i folds into the consuming add.  The SLP
+// vectoriser's automatic packing of the scalar formulation was slower (register-pair shuffles);
+// this TU is still built with -fno-slp-vectorize so that only the explicit packing happens.
+#ifdef NMX_HOST_EMU
+typedef float2 nmx_c2;
+NMX_DEV nmx_c2 nmx_mk2(float x, float y) { return make_float2(x, y); }
+NMX_DEV nmx_c2 nmx_to_c2(float2 a) { return a; }
+NMX_DEV nmx_c2 nmx_c2_axpby_swap(float a, nmx_c2 z, float b, nmx_c2 zc) {
+  return make_float2(a * z.x + b * zc.y, a * z.y + b * zc.x);
+}
+NMX_DEV nmx_c2 nmx_c2_fma(nmx_c2 a, nmx_c2 b, nmx_c2 c) { return make_float2(a.x * b.x + c.x, a.y * b.y + c.y); }
+#else
+typedef float nmx_c2 __attribute__((ext_vector_type(2)));
+NMX_DEV nmx_c2 nmx_c2_fma(nmx_c2 a, nmx_c2 b, nmx_c2 c) { return __builtin_elementwise_fma(a, b, c); }
+NMX_DEV nmx_c2 nmx_mk2(float x, float y) { nmx_c2 r = {x, y}; return r; }
+NMX_DEV nmx_c2 nmx_to_c2(float2 a) { nmx_c2 r = {a.x, a.y}; return r; }
+NMX_DEV nmx_c2 nmx_cadd(nmx_c2 a, nmx_c2 b) { return a + b; }
+NMX_DEV nmx_c2 nmx_csub(nmx_c2 a, nmx_c2 b) { return a - b; }
+NMX_DEV nmx_c2 nmx_cmul(nmx_c2 a, nmx_c2 w) {
+  const nmx_c2 t = a * w.xx;
+  const nmx_c2 wi = {-w.y, w.y};
+  return __builtin_elementwise_fma(a.yx, wi, t);
+}
+template <int DIR>
+NMX_DEV nmx_c2 nmx_mul_i(nmx_c2 a) {
+  nmx_c2 r;
+  if (DIR > 0) { r.x = -a.y; r.y = a.x; } else { r.x = a.y; r.y = -a.x; }
+  return r;
+}
+// a z + b swap(zc)  (a, b real): the collapsed split * H * unsplit step
+NMX_DEV nmx_c2 nmx_c2_axpby_swap(float a, nmx_c2 z, float b, nmx_c2 zc) {
+  const nmx_c2 t = z * a;
+  const nmx_c2 bb = {b, b};
+  return __builtin_elementwise_fma(zc.yx, bb, t);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
-// complex helpers
+// complex helpers on float2 (LDS element type); on the device they forward to the packed forms
 // ---------------------------------------------------------------------------------------
+#ifdef NMX_HOST_EMU
 NMX_DEV float2 nmx_cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 NMX_DEV float2 nmx_cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 NMX_DEV float2 nmx_csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by DIR * i  (DIR = -1 forward: (x, y) -> (y, -x); DIR = +1: (x, y) -> (-y, x))
+template <int DIR>
+NMX_DEV float2 nmx_mul_i(float2 a) {
+  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+#else
+NMX_DEV float2 nmx_to_f2(nmx_c2 a) { return make_float2(a.x, a.y); }
+NMX_DEV float2 nmx_cmul(float2 a, float2 b) { return nmx_to_f2(nmx_cmul(nmx_to_c2(a), nmx_to_c2(b))); }
+NMX_DEV float2 nmx_cadd(float2 a, float2 b) { return nmx_to_f2(nmx_to_c2(a) + nmx_to_c2(b)); }
+NMX_DEV float2 nmx_csub(float2 a, float2 b) { return nmx_to_f2(nmx_to_c2(a) - nmx_to_c2(b)); }
+template <int DIR>
+NMX_DEV float2 nmx_mul_i(float2 a) {
+  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+#endif
 template <int DIR>
 NMX_DEV float2 nmx_tw(const float2* NMX_RESTRICT tw, int idx) {
   float2 t = tw[idx];
   if (DIR > 0) t.y = -t.y;
   return t;
 }
-// multiply by DIR * i  (DIR = -1 forward: (x, y) -> (y, -x); DIR = +1: (x, y) -> (-y, x))
-template <int DIR>
-NMX_DEV float2 nmx_mul_i(float2 a) {
-  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-}
-
 
 // in-register 5-point DFT (DIR = -1 forward, +1 inverse)
 template <int DIR>
 NMX_DEV void nmx_dft5(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4) {
   const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;
   const float s1 = DIR * 0.95105651629515353f, s2 = DIR * 0.58778525229247314f;
+#ifdef NMX_HOST_EMU
   const float2 t1 = nmx_cadd(a1, a4), t2 = nmx_cadd(a2, a3);
   const float2 d1 = nmx_csub(a1, a4), d2 = nmx_csub(a2, a3);
   const float2 m1 = make_float2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
@@ -184,6 +237,18 @@ NMX_DEV void nmx_dft5(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4
   a4 = nmx_csub(m1, n1);
   a2 = nmx_cadd(m2, n2);
   a3 = nmx_csub(m2, n2);
+#else
+  const nmx_c2 x0 = nmx_to_c2(a0), x1 = nmx_to_c2(a1), x2 = nmx_to_c2(a2), x3 = nmx_to_c2(a3), x4 = nmx_to_c2(a4);
+  const nmx_c2 t1 = x1 + x4, t2 = x2 + x3, d1 = x1 - x4, d2 = x2 - x3;
+  const nmx_c2 m1 = x0 + c1 * t1 + c2 * t2, m2 = x0 + c2 * t1 + c1 * t2;
+  const nmx_c2 u1 = s1 * d1 + s2 * d2, u2 = s2 * d1 - s1 * d2;
+  const nmx_c2 n1 = {-u1.y, u1.x}, n2 = {-u2.y, u2.x};
+  a0 = nmx_to_f2(x0 + t1 + t2);
+  a1 = nmx_to_f2(m1 + n1);
+  a4 = nmx_to_f2(m1 - n1);
+  a2 = nmx_to_f2(m2 + n2);
+  a3 = nmx_to_f2(m2 - n2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

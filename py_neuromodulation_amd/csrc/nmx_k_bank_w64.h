@@ -65,11 +65,28 @@ struct NmxBankW64Args {
 #define NMX_WSYNC() NMX_WAVE_FENCE()
 #endif
 
+// ---- buffer addressing (device) ---------------------------------------------------------------
+// Rows are read / written through raw buffer descriptors whose num_records is the row length:
+// out-of-range lanes read 0 and their stores are dropped BY THE HARDWARE, so the zero padding of the
+// window and the ragged end of a row cost no compares, no exec-mask branches and no 64-bit address
+// arithmetic (the offsets 512 r are instruction immediates).
+#ifndef NMX_HOST_EMU
+typedef __amdgpu_buffer_rsrc_t nmx_rsrc;
+NMX_DEV nmx_rsrc nmx_make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+// NaN -> 0, +-inf -> +-FLT_MAX without branches
+NMX_DEV float nmx_clean_bl(float v) {
+  v = (v != v) ? 0.f : v;
+  return __builtin_amdgcn_fmed3f(v, -3.402823466e+38f, 3.402823466e+38f);
+}
+#endif
+
 // 4-point DFT, DIR = -1 forward / +1 inverse
 template <int DIR>
-NMX_DEV void nmx_dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
-  const float2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
-  const float2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
+NMX_DEV void nmx_dft4(nmx_c2& a0, nmx_c2& a1, nmx_c2& a2, nmx_c2& a3) {
+  const nmx_c2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+  const nmx_c2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
   a0 = nmx_cadd(t0, t2);
   a1 = nmx_cadd(t1, t3);
   a2 = nmx_csub(t0, t2);
@@ -78,7 +95,7 @@ NMX_DEV void nmx_dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
 
 // in-register 16-point DFT: y_q = sum_r a_r w^(q r), w = exp(DIR 2 pi i / 16); in/out v[0..15]
 template <int DIR>
-NMX_DEV void nmx_dft16(float2* v) {
+NMX_DEV void nmx_dft16(nmx_c2* v) {
   // step 1: for each r0, DFT4 over r1 of a[r0 + 4 r1]  -> inner[r0][q1] stored at v[r0 + 4 q1]
 NMX_UNROLL
   for (int r0 = 0; r0 < 4; ++r0) nmx_dft4<DIR>(v[r0], v[r0 + 4], v[r0 + 8], v[r0 + 12]);
@@ -86,20 +103,20 @@ NMX_UNROLL
   const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
   const float sg = (float)DIR;
   // w^1 = (c1, sg s1), w^2 = (h, sg h), w^3 = (s1, sg c1), w^4 = (0, sg), w^6 = (-h, sg h), w^9 = (-c1, -sg s1)
-  v[1 + 4] = nmx_cmul(v[1 + 4], make_float2(c1, sg * s1));   // q1=1, r0=1 : w^1
-  v[2 + 4] = nmx_cmul(v[2 + 4], make_float2(h, sg * h));     // q1=1, r0=2 : w^2
-  v[3 + 4] = nmx_cmul(v[3 + 4], make_float2(s1, sg * c1));   // q1=1, r0=3 : w^3
-  v[1 + 8] = nmx_cmul(v[1 + 8], make_float2(h, sg * h));     // q1=2, r0=1 : w^2
+  v[1 + 4] = nmx_cmul(v[1 + 4], nmx_mk2(c1, sg * s1));   // q1=1, r0=1 : w^1
+  v[2 + 4] = nmx_cmul(v[2 + 4], nmx_mk2(h, sg * h));     // q1=1, r0=2 : w^2
+  v[3 + 4] = nmx_cmul(v[3 + 4], nmx_mk2(s1, sg * c1));   // q1=1, r0=3 : w^3
+  v[1 + 8] = nmx_cmul(v[1 + 8], nmx_mk2(h, sg * h));     // q1=2, r0=1 : w^2
   v[2 + 8] = nmx_mul_i<DIR>(v[2 + 8]);                       // q1=2, r0=2 : w^4
-  v[3 + 8] = nmx_cmul(v[3 + 8], make_float2(-h, sg * h));    // q1=2, r0=3 : w^6
-  v[1 + 12] = nmx_cmul(v[1 + 12], make_float2(s1, sg * c1));  // q1=3, r0=1 : w^3
-  v[2 + 12] = nmx_cmul(v[2 + 12], make_float2(-h, sg * h));   // q1=3, r0=2 : w^6
-  v[3 + 12] = nmx_cmul(v[3 + 12], make_float2(-c1, -sg * s1)); // q1=3, r0=3 : w^9
+  v[3 + 8] = nmx_cmul(v[3 + 8], nmx_mk2(-h, sg * h));    // q1=2, r0=3 : w^6
+  v[1 + 12] = nmx_cmul(v[1 + 12], nmx_mk2(s1, sg * c1));  // q1=3, r0=1 : w^3
+  v[2 + 12] = nmx_cmul(v[2 + 12], nmx_mk2(-h, sg * h));   // q1=3, r0=2 : w^6
+  v[3 + 12] = nmx_cmul(v[3 + 12], nmx_mk2(-c1, -sg * s1)); // q1=3, r0=3 : w^9
   // step 3: for each q1, DFT4 over r0 -> y[q1 + 4 q0] ; store so that v[q] = y_q
 NMX_UNROLL
   for (int q1 = 0; q1 < 4; ++q1) nmx_dft4<DIR>(v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
   // now v[4 q1 + q0] = y[q1 + 4 q0]: transpose the 4x4 index in registers
-  float2 t;
+  nmx_c2 t;
 #define NMX_SWAP(i, j) t = v[i]; v[i] = v[j]; v[j] = t;
   NMX_SWAP(1, 4) NMX_SWAP(2, 8) NMX_SWAP(3, 12) NMX_SWAP(6, 9) NMX_SWAP(7, 13) NMX_SWAP(11, 14)
 #undef NMX_SWAP
@@ -109,21 +126,22 @@ NMX_UNROLL
 // exact table values are kept; the rest are products with compile-time constants or of at most
 // three table values (<= 3 ulp), which keeps the kernel at ~2 waves/SIMD worth of VGPRs.
 struct NmxW64Tw {
-  float2 b1, b2, b4, b8;  // pass B: exp(-2 pi i r k / 256), k = lane % 16, r = 1, 2, 4, 8
-  float2 c1, c2, c3;      // pass C: exp(-2 pi i r lane / 1024), r = 1, 2, 3
+  nmx_c2 b1, b2, b4, b8;  // pass B: exp(-2 pi i r k / 256), k = lane % 16, r = 1, 2, 4, 8
+  nmx_c2 c1, c2, c3;      // pass C: exp(-2 pi i r lane / 1024), r = 1, 2, 3
 };
 
 NMX_DEV void nmx_w64_load_tw(NmxW64Tw& T, const NmxFft& f, int lane) {
   const int k = lane & 15;
-  T.b1 = f.tw[4 * k]; T.b2 = f.tw[8 * k]; T.b4 = f.tw[16 * k]; T.b8 = f.tw[(32 * k) & 1023];
-  T.c1 = f.tw[lane]; T.c2 = f.tw[2 * lane]; T.c3 = f.tw[3 * lane];
+  T.b1 = nmx_to_c2(f.tw[4 * k]); T.b2 = nmx_to_c2(f.tw[8 * k]); T.b4 = nmx_to_c2(f.tw[16 * k]);
+  T.b8 = nmx_to_c2(f.tw[(32 * k) & 1023]);
+  T.c1 = nmx_to_c2(f.tw[lane]); T.c2 = nmx_to_c2(f.tw[2 * lane]); T.c3 = nmx_to_c2(f.tw[3 * lane]);
 }
 
 template <int DIR>
-NMX_DEV float2 nmx_twd(float2 t) { return DIR > 0 ? make_float2(t.x, -t.y) : t; }
+NMX_DEV nmx_c2 nmx_twd(nmx_c2 t) { return DIR > 0 ? nmx_mk2(t.x, -t.y) : t; }
 
 // exp(-2 pi i m / 32), m = 0..15 (split twiddle of point lane + 64 r is s0 * this[r])
-#define NMX_C32(m) make_float2(nmx_c32_re[m], nmx_c32_im[m])
+#define NMX_C32(m) nmx_mk2(nmx_c32_re[m], nmx_c32_im[m])
 static constexpr float nmx_c32_re[16] = {
     1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
     0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f, -0.19509032201612825f,
@@ -139,24 +157,24 @@ static constexpr float nmx_c32_im[16] = {
 NMX_DEV int nmx_w64_pad(int idx) { return idx + (idx >> 4); }
 
 // Passes A (from registers) .. C (to registers).  v: 16 points per lane, in: v[r] = x[lane + 64 r]
-// out: v[4 t + r] = y[lane + 64 t + 256 r].  X = exchange buffer (>= 1024 + 64 float2).
+// out: v[4 t + r] = y[lane + 64 t + 256 r].  X = exchange buffer (>= 1024 + 64 nmx_c2).
 // Phase functions are split so the host emulator can run them lane by lane.
 template <int DIR>
-NMX_DEV void nmx_w64_passA(float2* v, float2* X, int lane) {
+NMX_DEV void nmx_w64_passA(nmx_c2* v, nmx_c2* X, int lane) {
   nmx_dft16<DIR>(v);
-  float2* Xo = X + 17 * lane;  // == pad(16 lane + r) for r < 16: base + constant offsets
+  nmx_c2* Xo = X + 17 * lane;  // == pad(16 lane + r) for r < 16: base + constant offsets
   NMX_UNROLL
   for (int r = 0; r < 16; ++r) Xo[r] = v[r];
 }
 template <int DIR>
-NMX_DEV void nmx_w64_passB_load(float2* v, const float2* X, const NmxW64Tw& T, int lane) {
-  const float2* Xi = X + lane + (lane >> 4);  // pad(lane + 64 r) = lane + lane/16 + 68 r
+NMX_DEV void nmx_w64_passB_load(nmx_c2* v, const nmx_c2* X, const NmxW64Tw& T, int lane) {
+  const nmx_c2* Xi = X + lane + (lane >> 4);  // pad(lane + 64 r) = lane + lane/16 + 68 r
   NMX_UNROLL
   for (int r = 0; r < 16; ++r) v[r] = Xi[68 * r];
   {
-    const float2 w1 = nmx_twd<DIR>(T.b1), w2 = nmx_twd<DIR>(T.b2), w4 = nmx_twd<DIR>(T.b4), w8 = nmx_twd<DIR>(T.b8);
-    const float2 w3 = nmx_cmul(w1, w2), w5 = nmx_cmul(w1, w4), w6 = nmx_cmul(w2, w4), w9 = nmx_cmul(w1, w8);
-    const float2 w10 = nmx_cmul(w2, w8), w12 = nmx_cmul(w4, w8);
+    const nmx_c2 w1 = nmx_twd<DIR>(T.b1), w2 = nmx_twd<DIR>(T.b2), w4 = nmx_twd<DIR>(T.b4), w8 = nmx_twd<DIR>(T.b8);
+    const nmx_c2 w3 = nmx_cmul(w1, w2), w5 = nmx_cmul(w1, w4), w6 = nmx_cmul(w2, w4), w9 = nmx_cmul(w1, w8);
+    const nmx_c2 w10 = nmx_cmul(w2, w8), w12 = nmx_cmul(w4, w8);
     v[1] = nmx_cmul(v[1], w1); v[2] = nmx_cmul(v[2], w2); v[3] = nmx_cmul(v[3], w3);
     v[4] = nmx_cmul(v[4], w4); v[5] = nmx_cmul(v[5], w5); v[6] = nmx_cmul(v[6], w6);
     v[7] = nmx_cmul(v[7], nmx_cmul(w3, w4)); v[8] = nmx_cmul(v[8], w8); v[9] = nmx_cmul(v[9], w9);
@@ -166,21 +184,21 @@ NMX_DEV void nmx_w64_passB_load(float2* v, const float2* X, const NmxW64Tw& T, i
   }
   nmx_dft16<DIR>(v);
 }
-NMX_DEV void nmx_w64_passB_store(const float2* v, float2* X, int lane) {
-  float2* Xo = X + (lane >> 4) * 256 + (lane & 15);
+NMX_DEV void nmx_w64_passB_store(const nmx_c2* v, nmx_c2* X, int lane) {
+  nmx_c2* Xo = X + (lane >> 4) * 256 + (lane & 15);
 NMX_UNROLL
   for (int r = 0; r < 16; ++r) Xo[16 * r] = v[r];
 }
 template <int DIR>
-NMX_DEV void nmx_w64_passC(float2* v, const float2* X, const NmxW64Tw& T, int lane) {
+NMX_DEV void nmx_w64_passC(nmx_c2* v, const nmx_c2* X, const NmxW64Tw& T, int lane) {
 NMX_UNROLL
   for (int t = 0; t < 4; ++t) {
-    const float2* Xi = X + lane;
-    float2 a0 = Xi[64 * t], a1 = Xi[64 * t + 256], a2 = Xi[64 * t + 512], a3 = Xi[64 * t + 768];
+    const nmx_c2* Xi = X + lane;
+    nmx_c2 a0 = Xi[64 * t], a1 = Xi[64 * t + 256], a2 = Xi[64 * t + 512], a3 = Xi[64 * t + 768];
     // exp(-2 pi i r (lane + 64 t) / 1024) = c_r * exp(-2 pi i r t / 16) (compile-time constant)
     a1 = nmx_cmul(a1, nmx_twd<DIR>(nmx_cmul(T.c1, NMX_C32((2 * t) & 15))));
     a2 = nmx_cmul(a2, nmx_twd<DIR>(nmx_cmul(T.c2, NMX_C32((4 * t) & 15))));
-    a3 = nmx_cmul(a3, nmx_twd<DIR>(t == 3 ? nmx_cmul(T.c3, make_float2(-nmx_c32_re[2], -nmx_c32_im[2]))
+    a3 = nmx_cmul(a3, nmx_twd<DIR>(t == 3 ? nmx_cmul(T.c3, nmx_mk2(-nmx_c32_re[2], -nmx_c32_im[2]))
                                           : nmx_cmul(T.c3, NMX_C32((6 * t) & 15))));
     nmx_dft4<DIR>(a0, a1, a2, a3);
     v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
@@ -203,15 +221,17 @@ NMX_UNROLL
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
 template <int PAD, int TAB, int MC>
 NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab) {
+  w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
+  c = nmx_uniform_i(c);
   const NmxBankArgs& A = AA.b;
-  float2* X = (float2*)(smem + AA.off_X);   // [1024 + 64] exchange buffer (the only LDS tile)
+  nmx_c2* X = (nmx_c2*)(smem + AA.off_X);   // [1024 + 64] exchange buffer (the only LDS tile)
   float* red = smem + AA.off_red;
   const int W = A.W, n = NMX_W64_N;
   float* out_row = A.out ? A.out + (long long)w * A.n_outputs : nullptr;
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
-                     (A.starts ? A.starts[w] : 0ll);
-  float2 v[NMX_LANES][16];
-  float2 zr[NMX_LANES][16];   // forward transform Z, kept in registers: zr[4 t + r] = Z[l + 64 t + 256 r]
+                     (A.starts ? nmx_uniform_ll(A.starts[w]) : 0ll);
+  nmx_c2 v[NMX_LANES][16];
+  nmx_c2 zr[NMX_LANES][16];   // forward transform Z, kept in registers: zr[4 t + r] = Z[l + 64 t + 256 r]
   NmxW64Tw T[NMX_LANES];
   NMX_LANE_LOOP { nmx_w64_load_tw(T[NMX_LI], A.fft, l); }
 
@@ -235,15 +255,33 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     NMX_WSYNC();
   }
   NMX_LANE_LOOP {
-    float2* vv = v[NMX_LI];
+    nmx_c2* vv = v[NMX_LI];
     if (PAD == 0) {
+#ifdef NMX_HOST_EMU
       NMX_UNROLL
       for (int r = 0; r < 16; ++r) {
         const int n0 = 2 * (l + 64 * r);
         float v0 = n0 < W ? src[n0] : 0.f, v1 = (n0 + 1) < W ? src[n0 + 1] : 0.f;
         if (A.clean_on_load) { v0 = nmx_clean(v0); v1 = nmx_clean(v1); }
-        vv[r] = make_float2(v0, v1);
+        vv[r] = nmx_mk2(v0, v1);
       }
+#else
+      const nmx_rsrc rs = nmx_make_rsrc(src, 4 * W);
+      if ((W & 1) == 0) {
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) vv[r] = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * l + 512 * r, 0, 0);
+      } else {   // a pair may straddle the end of the row: dword accesses are range-checked one by one
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          vv[r].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 8 * l + 512 * r, 0, 0));
+          vv[r].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 8 * l + 512 * r + 4, 0, 0));
+        }
+      }
+      if (A.clean_on_load) {
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) vv[r] = nmx_mk2(nmx_clean_bl(vv[r].x), nmx_clean_bl(vv[r].y));
+      }
+#endif
     } else {
       const float* xs = (const float*)X;
       const int h = A.pad_half, ne = A.n_edge;
@@ -262,7 +300,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
           }
           e2[u] = val;
         }
-        vv[r] = make_float2(e2[0], e2[1]);
+        vv[r] = nmx_mk2(e2[0], e2[1]);
       }
     }
   }
@@ -274,7 +312,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP {
-    float2* vv = v[NMX_LI];
+    nmx_c2* vv = v[NMX_LI];
     nmx_w64_passC<-1>(vv, X, T[NMX_LI], l);
     NMX_UNROLL
     for (int i = 0; i < 16; ++i) zr[NMX_LI][i] = vv[i];
@@ -288,22 +326,22 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     const float* NMX_RESTRICT Hd = TAB ? tab + (size_t)fi * 2 * NMX_W64_N + NMX_W64_N : AA.Hd[fi];
     // ---- fused split * H * unsplit into registers, then inverse passes -----------------------
     NMX_LANE_LOOP {
-      float2* vv = v[NMX_LI];
+      nmx_c2* vv = v[NMX_LI];
       NMX_UNROLL
       for (int r = 0; r < 16; ++r) {
         // k = l + 64 r lives in register j2i(r); its partner n - k = (64 - l) + 64 (15 - r) lives in
         // lane (64 - l) & 63, register j2i(15 - r)  (lane 0: its own register j2i(16 - r), Z[n] = Z[0])
-        const float2 zk = zr[NMX_LI][NMX_J2I(r)];
+        const nmx_c2 zk = zr[NMX_LI][NMX_J2I(r)];
 #ifdef NMX_HOST_EMU
-        float2 zc = zr[(64 - l) & 63][NMX_J2I(15 - r)];
+        nmx_c2 zc = zr[(64 - l) & 63][NMX_J2I(15 - r)];
 #else
-        const float2 zs = zr[0][NMX_J2I(15 - r)];
-        float2 zc = make_float2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
+        const nmx_c2 zs = zr[0][NMX_J2I(15 - r)];
+        nmx_c2 zc = nmx_mk2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
 #endif
         if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
         const float ha = (Hs + l)[64 * r], hb = (Hd + l)[64 * r];
         // Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),  A = Hs - Hd sin(th_k), B = Hd cos(th_k)
-        vv[r] = make_float2(ha * zk.x + hb * zc.y, ha * zk.y + hb * zc.x);
+        vv[r] = nmx_c2_axpby_swap(ha, zk, hb, zc);
         if ((r & 3) == 3) NMX_SCHED_FENCE();
       }
       nmx_w64_passA<+1>(vv, X, l);
@@ -319,32 +357,46 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     if (F.bp_seglen > 0) {
       const bool need_mc = MC && (A.bp_features & 6u) != 0;   // MC = 0: compiled for activity only
       if (!need_mc) {  // activity only: variance straight from registers
+        // Register i of every lane covers samples [2 mb, 2 mb + 127]: all but the (at most two)
+        // registers that straddle lo or hi are wave-uniformly inside or outside the tail, so the
+        // range test is a scalar branch and the sums are packed adds / fmas.
         const int lo = W - F.bp_seglen + yoff, hi = W + yoff;
         float part[NMX_LANES];
         NMX_LANE_LOOP {
-          float s = 0.f;
+          nmx_c2 acc = nmx_mk2(0.f, 0.f);
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
-            const int m = l + 64 * (i >> 2) + 256 * (i & 3);
-            const float2 val = v[NMX_LI][i];
-            if (2 * m >= lo && 2 * m < hi) s += val.x;
-            if (2 * m + 1 >= lo && 2 * m + 1 < hi) s += val.y;
+            const int mb = 64 * (i >> 2) + 256 * (i & 3);
+            if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
+            const nmx_c2 val = v[NMX_LI][i];
+            if (2 * mb >= lo && 2 * mb + 127 < hi) {
+              acc = nmx_cadd(acc, val);
+            } else {
+              const int m = l + mb;
+              acc = nmx_cadd(acc, nmx_mk2((2 * m >= lo && 2 * m < hi) ? val.x : 0.f,
+                                          (2 * m + 1 >= lo && 2 * m + 1 < hi) ? val.y : 0.f));
+            }
           }
-          part[NMX_LI] = s;
+          part[NMX_LI] = acc.x + acc.y;
         }
         float tot;
         NMX_W64_REDUCE_SUM(part, tot);
         const float mean = tot / (float)F.bp_seglen;
         NMX_LANE_LOOP {
-          float s = 0.f;
+          nmx_c2 acc = nmx_mk2(0.f, 0.f);
+          const nmx_c2 mean2 = nmx_mk2(mean, mean);
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
-            const int m = l + 64 * (i >> 2) + 256 * (i & 3);
-            const float2 val = v[NMX_LI][i];
-            if (2 * m >= lo && 2 * m < hi) { const float d = val.x - mean; s += d * d; }
-            if (2 * m + 1 >= lo && 2 * m + 1 < hi) { const float d = val.y - mean; s += d * d; }
+            const int mb = 64 * (i >> 2) + 256 * (i & 3);
+            if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
+            nmx_c2 d = nmx_csub(v[NMX_LI][i], mean2);
+            if (!(2 * mb >= lo && 2 * mb + 127 < hi)) {
+              const int m = l + mb;
+              d = nmx_mk2((2 * m >= lo && 2 * m < hi) ? d.x : 0.f, (2 * m + 1 >= lo && 2 * m + 1 < hi) ? d.y : 0.f);
+            }
+            acc = nmx_c2_fma(d, d, acc);
           }
-          part[NMX_LI] = s;
+          part[NMX_LI] = acc.x + acc.y;
         }
         NMX_W64_REDUCE_SUM(part, tot);
         const float act = tot / (float)F.bp_seglen;
@@ -378,33 +430,43 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
           ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
       float* dyb = F.burst_index >= 0
           ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
-      const bool vec = ((W & 1) == 0);   // rows start 8-byte aligned when W is even
+#ifdef NMX_HOST_EMU
       NMX_LANE_LOOP {
-        NMX_UNROLL
         for (int i = 0; i < 16; ++i) {
-          const int m = 64 * (i >> 2) + 256 * (i & 3);   // + l
-          const float2 val = v[NMX_LI][i];
-          if (2 * (m + l) + 1 < W) {
-            if (vec) {
-              if (dsw) ((float2*)dsw + l)[m] = val;
-              if (dyb) ((float2*)dyb + l)[m] = val;
-            } else {
-              if (dsw) { (dsw + 2 * l)[2 * m] = val.x; (dsw + 2 * l)[2 * m + 1] = val.y; }
-              if (dyb) { (dyb + 2 * l)[2 * m] = val.x; (dyb + 2 * l)[2 * m + 1] = val.y; }
-            }
-          } else if (2 * (m + l) < W) {
-            if (dsw) (dsw + 2 * l)[2 * m] = val.x;
-            if (dyb) (dyb + 2 * l)[2 * m] = val.x;
+          const int m = l + 64 * (i >> 2) + 256 * (i & 3);
+          const nmx_c2 val = v[NMX_LI][i];
+          if (2 * m < W) { if (dsw) dsw[2 * m] = val.x; if (dyb) dyb[2 * m] = val.x; }
+          if (2 * m + 1 < W) { if (dsw) dsw[2 * m + 1] = val.y; if (dyb) dyb[2 * m + 1] = val.y; }
+        }
+      }
+#else
+      // wave-uniform choice of destinations; the ragged row end is the buffer range check
+      const int l = (int)(threadIdx.x & 63);
+      for (int dst = 0; dst < 2; ++dst) {
+        float* d = dst ? dyb : dsw;
+        if (!d) continue;
+        const nmx_rsrc rs = nmx_make_rsrc(d, 4 * W);
+        if ((W & 1) == 0) {
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_buffer_store_b64(v[0][i], rs, 8 * l + 512 * (i >> 2) + 2048 * (i & 3), 0, 0);
+        } else {
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i) {
+            const int off = 8 * l + 512 * (i >> 2) + 2048 * (i & 3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][i].x), rs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][i].y), rs, off + 4, 0, 0);
           }
         }
       }
+#endif
     } else if (F.store_raw) {
       float* d2 = A.y_out + ((long long)w * A.n_channels + c) * W - yoff;
       NMX_LANE_LOOP {
         NMX_UNROLL
         for (int i = 0; i < 16; ++i) {
           const int s0 = 2 * (l + 64 * (i >> 2) + 256 * (i & 3));
-          const float2 val = v[NMX_LI][i];
+          const nmx_c2 val = v[NMX_LI][i];
           if (s0 >= yoff && s0 < W + yoff) d2[s0] = val.x;
           if (s0 + 1 >= yoff && s0 + 1 < W + yoff) d2[s0 + 1] = val.y;
         }

@@ -10,6 +10,11 @@
 #ifndef NMX_W64_NAME
 #error "define NMX_W64_NAME"
 #endif
+// waves per persistent workgroup (= per CU): 8 leaves the 256-VGPR budget (2 waves/SIMD) that the
+// packed-complex formulation needs to stay out of scratch
+#ifndef NMX_W64P_WAVES
+#define NMX_W64P_WAVES 8
+#endif
 #define NMX_CAT2(a, b) a##b
 #define NMX_CAT(a, b) NMX_CAT2(a, b)
 
@@ -29,7 +34,7 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // Persistent variant: one workgroup of `nw` waves per CU; the A/B tables of all filters are
 // staged in LDS once per workgroup (instead of being re-fetched from L2 for every item: 27 % of
 // the kernel's time), then every wave walks its own items with wave-local fences only.
-__global__ void __launch_bounds__(768, 3) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
+__global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
                                                                                      int n_items, int x_floats) {
   float* tab = nmx_smem_w64;
   const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
@@ -38,7 +43,9 @@ __global__ void __launch_bounds__(768, 3) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_N
     tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // readfirstlane: the wave index is wave-uniform, but only this tells the compiler (item-derived
+  // addresses, descriptors and branches then live in SGPRs)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   float* mine = nmx_smem_w64 + tab_floats + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
@@ -52,8 +59,8 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   const int x_floats = A->lds_floats;            // per-wave exchange tile (+ scratch)
   const int tab_floats = A->b.n_filters * 2 * NMX_W64_N;
   int nw = (160 * 1024 / 4 - tab_floats) / x_floats;
-  if (nw > 12) nw = 12;
-  if (nw < 8) return 0;
+  if (nw > NMX_W64P_WAVES) nw = NMX_W64P_WAVES;
+  if (nw < NMX_W64P_WAVES) return 0;
   static bool once = false;
   if (!once) {
     once = true;

@@ -1,0 +1,67 @@
+// nmx_wave.hip -- translation unit of the one-item-per-WAVE kernels (burst statistics, sharp-wave
+// analysis).  Compiled with -DNMX_NT_FIXED=64: inside an item NMX_TID is the lane, NMX_NT is the
+// constant 64, NMX_SYNC() is a wave-local LDS fence and the block reductions are shuffle-only.
+// A workgroup carries `k` independent waves (own LDS slice each), so there is no workgroup barrier
+// anywhere in these kernels.
+#ifndef NMX_NT_FIXED
+#error "compile with -DNMX_NT_FIXED=64"
+#endif
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "nmx_k_bursts.h"
+#include "nmx_k_sharpwave.h"
+
+extern __shared__ __attribute__((aligned(16))) float nmx_smem_wave[];
+
+__global__ void __launch_bounds__(256) nmx_kern_burst_stat(const NmxBurstStatArgs A, int n_items, int slice) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
+  const int item = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (item >= n_items) return;
+  const int bi = item % A.n_bands, r = item / A.n_bands;
+  nmx_burst_stat_item(A, r / A.n_channels, r % A.n_channels, bi, nmx_smem_wave + wave * slice);
+}
+
+__global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int n_items, int slice) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
+  const int item = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (item >= n_items) return;
+  const int fi = item % A.n_filters, r = item / A.n_filters;
+  nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
+}
+
+static int waves_per_wg(size_t lds_one) {
+  static int k = 0;
+  if (!k) {
+    const char* v = getenv("NMX_WAVES_PER_WG");
+    k = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 1;
+  }
+  int kk = k;
+  while (kk > 1 && lds_one * kk > 64 * 1024) --kk;
+  return kk;
+}
+
+extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_items, size_t lds, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)nmx_kern_burst_stat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int k = waves_per_wg(lds);
+  const int slice = (int)((lds / 4 + 3) & ~(size_t)3);
+  hipLaunchKernelGGL(nmx_kern_burst_stat, dim3((n_items + k - 1) / k), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
+                     n_items, slice);
+}
+
+extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)nmx_kern_sharp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int k = waves_per_wg(lds);
+  const int slice = (int)((lds / 4 + 3) & ~(size_t)3);
+  hipLaunchKernelGGL(nmx_kern_sharp, dim3((n_items + k - 1) / k), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
+                     n_items, slice);
+}
