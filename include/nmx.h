@@ -201,6 +201,31 @@ int nmx_state_import(nmx_plan* plan, const void* src, int64_t n_bytes);
  * 4 bursts kernels, 5 sharp-wave kernel.  Blocks until the events have completed. */
 int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
 
+/* ---- Feature normalisation over a batch of hops (processing/normalization.py:31-111,150-163) ----
+ * The reference post-processes every feature vector with a rolling normaliser (on by default,
+ * default_settings.yaml:69-78).  One nmx_norm carries the history of one stream.
+ *   method      NMX_NORM_MEAN ((x - mean) / mean) or NMX_NORM_ZSCORE ((x - mean) / std, std 0 -> 1);
+ *               statistics over the last n_hist rows INCLUDING the current one, NaNs ignored
+ *   clip        > 0: clip to [-clip, clip]; <= 0: none          (normalization.py:104-105)
+ *   n_hist      int(normalization_time_s * sampling_rate_features_hz) >= 2
+ *   colmask     optional [n_cols] uint8, 0 = column is passed through ("psd" keys when
+ *               normalize_psd is false, stream/data_processor.py:263-290); copied
+ * nmx_norm_process normalises rows[n_rows][ld] IN PLACE, hop by hop semantics (row i sees rows
+ * < i of the same batch and the carried history); the first row ever seen is returned unchanged.
+ * memspace / hip_stream as in nmx_process_batch. */
+#define NMX_NORM_MEAN 0
+#define NMX_NORM_ZSCORE 1
+typedef struct nmx_norm nmx_norm;
+int nmx_norm_create(int32_t device, int32_t n_cols, int32_t method, float clip, int32_t n_hist,
+                    const uint8_t* colmask, nmx_norm** out);
+int nmx_norm_destroy(nmx_norm* norm);
+int nmx_norm_process(nmx_norm* norm, float* rows, int64_t ld, int64_t n_rows, int memspace,
+                     void* hip_stream);
+int nmx_norm_reset(nmx_norm* norm);
+int nmx_norm_state_size(const nmx_norm* norm, int64_t* n_bytes);
+int nmx_norm_state_export(nmx_norm* norm, void* dst, int64_t n_bytes);
+int nmx_norm_state_import(nmx_norm* norm, const void* src, int64_t n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,8 @@ _EXPORTS = [
     "nmx_plan_destroy", "nmx_plan_n_outputs", "nmx_process_batch", "nmx_process_window",
     "nmx_preprocess_window", "nmx_filter_window", "nmx_state_reset", "nmx_state_size",
     "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms",
+    "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
+    "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
 ]
 
 
@@ -119,6 +121,14 @@ class NmxLibrary:
         L.nmx_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nmx_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nmx_last_timing_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.nmx_norm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                      C.POINTER(C.c_void_p)]
+        L.nmx_norm_destroy.argtypes = [C.c_void_p]
+        L.nmx_norm_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        L.nmx_norm_reset.argtypes = [C.c_void_p]
+        L.nmx_norm_state_size.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.nmx_norm_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.nmx_norm_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         if L.nmx_abi_version() != NMX_ABI_VERSION:
             raise NmxError("libnmx ABI version mismatch")
 

@@ -6,6 +6,7 @@
 #include "nmx_k_bank.h"
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_bursts.h"
+#include "nmx_k_norm.h"
 #include "nmx_k_prep.h"
 #include "nmx_k_sharpwave.h"
 #include "nmx_k_timeosc.h"
@@ -37,6 +38,9 @@ extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_item
 extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s);
 __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
   nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
+}
+__global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
+  nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
   nmx_car_sample(A, (long long)blockIdx.x * 256 + threadIdx.x);
@@ -86,6 +90,10 @@ static void be_d2h_async(void* d, const void* s, size_t n, be_stream_t st) {
 static void be_h2d_2d_async(void* d, size_t dpitch, const void* s, size_t spitch, size_t width,
                             size_t height, be_stream_t st) {
   BE_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, st));
+}
+static void be_d2h_2d_async(void* d, size_t dpitch, const void* s, size_t spitch, size_t width,
+                            size_t height, be_stream_t st) {
+  BE_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, st));
 }
 static void be_memset_async(void* d, int v, size_t n, be_stream_t st) { BE_TRY(hipMemsetAsync(d, v, n, st)); }
 static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
@@ -207,6 +215,10 @@ static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_s
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
   hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+}
+static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
+  // one thread per column, one wave per workgroup: columns spread over as many CUs as possible
+  hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 255) / 256)), dim3(256), 0, s, A);

@@ -22,7 +22,7 @@ import numpy as np
 from . import channels as chmod
 from . import fir_design
 from .engine import HotPathEngine
-from .processing import FeatureNormalizer
+from .processing import DeviceFeatureNormalizer, FeatureNormalizer
 from .settings import NMSettings
 
 PREPROCESSOR_ORDER = ["preprocessing_filter", "notch_filter", "raw_resampling", "re_referencing",
@@ -94,12 +94,24 @@ class DataProcessor:
         self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                     device=device, window=window, lib=lib, dry_run=dry_run)
         self.keys = self.engine.keys
-        self.feature_normalizer = (FeatureNormalizer(st) if st.postprocessing.feature_normalization
-                                   else None)
-        if self.feature_normalizer is not None and not st.feature_normalization_settings.normalize_psd:
-            self.non_psd_indices = np.array([i for i, k in enumerate(self.keys) if "psd" not in k], dtype=int)
-        else:
-            self.non_psd_indices = None
+        self.feature_normalizer = None
+        self.non_psd_indices = None
+        self.device_normalizer = None
+        if st.postprocessing.feature_normalization:
+            fs = st.feature_normalization_settings
+            if not fs.normalize_psd:
+                self.non_psd_indices = np.array([i for i, k in enumerate(self.keys) if "psd" not in k], dtype=int)
+            if fs.normalization_method in DeviceFeatureNormalizer.METHODS and not dry_run:
+                # "mean" / "zscore" (default): one HIP scan per batch of hops; the column mask
+                # carries the "psd" exclusion (stream/data_processor.py:263-290)
+                mask = None
+                if self.non_psd_indices is not None:
+                    mask = np.zeros(len(self.keys), dtype=np.uint8)
+                    mask[self.non_psd_indices] = 1
+                self.device_normalizer = DeviceFeatureNormalizer(st, len(self.keys), colmask=mask,
+                                                                 device=device, lib=lib)
+            else:  # median / scikit-learn methods: host NumPy, hop by hop like the reference
+                self.feature_normalizer = FeatureNormalizer(st)
         # NaN policy: columns whose key contains the channel's new_name (substring, as the reference)
         self._nan_cols = [np.array([i for i, k in enumerate(self.keys) if ch in k], dtype=int)
                           for ch in self.ch_names_used]
@@ -107,6 +119,8 @@ class DataProcessor:
 
     # ------------------------------------------------------------------------------------
     def _postprocess_row(self, row: np.ndarray, nan_rows: np.ndarray) -> np.ndarray:
+        if self.device_normalizer is not None:
+            row = self.device_normalizer.process(row)
         if self.feature_normalizer is not None:
             if self.non_psd_indices is not None:
                 row = row.copy()
@@ -136,7 +150,27 @@ class DataProcessor:
         """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
         applied hop by hop because the normaliser is sequential)."""
         out, mask = self.engine.process_batch(data, starts, want_nan_mask=True)
+        return self.postprocess_batch(out, mask)
+
+    def postprocess_batch(self, out: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        """Normalisation + NaN policy for raw engine rows ``out[n, F]`` (hop order)."""
+        if self.device_normalizer is not None:
+            out = self.device_normalizer.process_batch(out)
         out = out.astype(np.float64)
         if self.feature_normalizer is None and not mask.any():
             return out
-        return np.stack([self._postprocess_row(out[i], mask[i]) for i in range(len(out))])
+        if self.feature_normalizer is None:
+            return self._apply_nan_policy(out, mask)
+        dn, self.device_normalizer = self.device_normalizer, None   # already applied above
+        try:
+            return np.stack([self._postprocess_row(out[i], mask[i]) for i in range(len(out))])
+        finally:
+            self.device_normalizer = dn
+
+    def _apply_nan_policy(self, rows: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        """Every key that contains the name of a channel whose window held a NaN := NaN (:297-306)."""
+        if mask.shape[1] != len(self.ch_names_used):
+            raise IndexError("boolean index did not match: NaN handling needs every channel used")
+        for ci in np.where(mask.any(axis=0))[0]:
+            rows[np.ix_(mask[:, ci], self._nan_cols[ci])] = np.nan
+        return rows

@@ -4,8 +4,10 @@
   ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
   Resampler     processing/resample.py:19-60    identity at ratio 1 (all BASELINE configs);
                                                 other ratios: NotImplementedError (MNE parity unpinned)
-  FeatureNormalizer processing/normalization.py:31-111 -- post-processing of the tiny per-hop
-                feature vector, sequential over hops; stays on the host (SURVEY 8f "next" #1).
+  FeatureNormalizer processing/normalization.py:31-111 -- host NumPy version (all methods incl.
+                the median / scikit-learn ones), one call per hop like the reference.
+  DeviceFeatureNormalizer  the same post-processing for the "mean" and "zscore" (default) methods as
+                a HIP scan over a whole batch of hops (libnmx nmx_norm_*, SURVEY 8f "next" #1).
 """
 
 from __future__ import annotations
@@ -124,3 +126,73 @@ class FeatureNormalizer:
             out = out.clip(min=-self.clip, max=self.clip)
         self.previous = self.previous[-self.num_samples_normalize + 1:]
         return np.nan_to_num(out)
+
+
+class DeviceFeatureNormalizer:
+    """processing/normalization.py:31-111 for normalization_method in {"mean", "zscore"} on the GPU.
+
+    ``process(row)`` keeps the reference's call shape (one feature vector per hop);
+    ``process_batch(rows)`` normalises ``rows[n_hops, n_features]`` with the same hop-by-hop
+    semantics in one kernel launch (rows may also be a device pointer, see ``process_device``).
+    """
+
+    METHODS = {"mean": 0, "zscore": 1}
+
+    def __init__(self, settings, n_features: int, colmask=None, device: int = 0, lib=None) -> None:
+        import ctypes as C
+
+        from ._lib import get_library
+
+        s = settings.feature_normalization_settings
+        if s.normalization_method not in self.METHODS:
+            raise ValueError(f"normalization_method {s.normalization_method!r} has no device implementation")
+        self.method = s.normalization_method
+        self.clip = float(s.clip) if s.clip else 0.0
+        self.num_samples_normalize = int(s.normalization_time_s * settings.sampling_rate_features_hz)
+        self.n_features = int(n_features)
+        self._lib = lib if lib is not None else get_library()
+        self._h = C.c_void_p()
+        mask = None
+        if colmask is not None:
+            mask = np.ascontiguousarray(colmask, dtype=np.uint8)
+            if mask.shape != (self.n_features,):
+                raise ValueError("colmask must have one entry per feature")
+        self._lib.check(self._lib.lib.nmx_norm_create(
+            int(device), self.n_features, self.METHODS[self.method], self.clip, self.num_samples_normalize,
+            mask.ctypes.data if mask is not None else None, C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.lib.nmx_norm_destroy(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+    def process_batch(self, rows: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.n_features).copy()
+        self._lib.check(self._lib.lib.nmx_norm_process(self._h, out.ctypes.data, self.n_features,
+                                                       out.shape[0], 0, None))
+        return out
+
+    def process_device(self, ptr: int, ld: int, n_rows: int, stream: int | None = None) -> None:
+        """In place on device memory ``float32[n_rows][ld]`` (asynchronous on ``stream``)."""
+        self._lib.check(self._lib.lib.nmx_norm_process(self._h, ptr, int(ld), int(n_rows), 1, stream))
+
+    def process(self, data: np.ndarray) -> np.ndarray:
+        return self.process_batch(np.asarray(data)[None])[0].astype(np.float64)
+
+    def reset(self) -> None:
+        self._lib.check(self._lib.lib.nmx_norm_reset(self._h))
+
+    def export_state(self) -> bytes:
+        import ctypes as C
+
+        n = C.c_int64()
+        self._lib.check(self._lib.lib.nmx_norm_state_size(self._h, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._lib.check(self._lib.lib.nmx_norm_state_export(self._h, buf, n.value))
+        return buf.raw
+
+    def import_state(self, state: bytes) -> None:
+        self._lib.check(self._lib.lib.nmx_norm_state_import(self._h, state, len(state)))

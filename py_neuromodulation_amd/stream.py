@@ -102,18 +102,13 @@ class Stream:
                 rows = self.data_processor.process_batch(data, starts)
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops
-                norm = self.data_processor.feature_normalizer
-                for p in procs.values():
-                    p.feature_normalizer = None
-                raw = np.empty((len(starts), len(keys)))
+                raw = np.empty((len(starts), len(keys)), dtype=np.float32)
                 masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
                 for w, p in procs.items():
                     sel = np.where(lens == w)[0]
                     o, m = p.engine.process_batch(data, starts[sel], want_nan_mask=True)
                     raw[sel], masks[sel] = o, m
-                self.data_processor.feature_normalizer = norm
-                rows = np.stack([self.data_processor._postprocess_row(raw[i], masks[i])
-                                 for i in range(len(starts))])
+                rows = self.data_processor.postprocess_batch(raw, masks)
         df = pd.DataFrame(rows, columns=keys)
         df["time"] = times
         tgt = self.channels[self.channels["target"] == 1]

@@ -16,6 +16,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank_w64.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bursts.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_norm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_timeosc.h"
@@ -34,6 +35,9 @@ static void be_memset_sync(void* d, int v, size_t n) { memset(d, v, n); }
 static void be_h2d_async(void* d, const void* s, size_t n, be_stream_t) { memcpy(d, s, n); }
 static void be_d2h_async(void* d, const void* s, size_t n, be_stream_t) { memcpy(d, s, n); }
 static void be_h2d_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, be_stream_t) {
+  for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+}
+static void be_d2h_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, be_stream_t) {
   for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
 }
 static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v, n); }
@@ -96,6 +100,9 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t) {
   for (long long t = 0; t < A.T; ++t) nmx_car_sample(A, t);
+}
+static void be_launch_norm(const NmxNormArgs& A, be_stream_t) {
+  for (int j = 0; j < A.n_cols; ++j) nmx_norm_column(A, j);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
   float sm[64];

@@ -360,3 +360,44 @@ def case_reference_property_tests(lib):
         features.FFT(bad, ch, sfreq)
     with pytest.raises(ValueError):
         NMSettings(fft_settings={"log_transform": "yes"})
+
+
+def case_feature_normalizer_batches(lib):
+    """nmx_norm_* (batch scan) == the reference's hop-by-hop Normalizer for "zscore" and "mean":
+    history carried across batches and through export/import, N - 1 trimming, NaN-aware statistics,
+    constant columns (std 0 -> 1), the untouched first row, clip, and the "psd" column mask.
+    Tolerance: statistics are float64 on both sides, values are fp32 -> 1e-5 rel / 2e-6 abs."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.processing import DeviceFeatureNormalizer
+
+    rng = np.random.default_rng(7)
+    n, F = 400, 37
+    rows = (rng.standard_normal((n, F)) * rng.uniform(0.01, 30, F) + rng.uniform(-50, 50, F)).astype(np.float32)
+    rows[:, 3] = 2.5                                   # constant column
+    rows[:, 4] = np.cumsum(np.abs(rows[:, 4])) + 1e4   # drifting, mean >> std
+    rows[rng.integers(0, n, 40), rng.integers(5, 12, 40)] = np.nan
+    rows[100:180, 12] = np.nan                         # a whole history window of NaNs (N = 50)
+    mask = np.ones(F, dtype=np.uint8)
+    mask[20:24] = 0
+    for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0)):
+        s = NMSettings.get_default()
+        s.sampling_rate_features_hz = 10
+        s.feature_normalization_settings.normalization_time_s = 5
+        s.feature_normalization_settings.normalization_method = method
+        s.feature_normalization_settings.clip = clip
+        ref = orc.FeatureNormalizer(s)
+        want = np.stack([ref.process(r.astype(np.float64)) for r in rows[:, mask == 1]])
+        dn = DeviceFeatureNormalizer(s, F, colmask=mask, lib=lib)
+        got = [dn.process_batch(rows[:1]), dn.process_batch(rows[1:130])]
+        state = dn.export_state()
+        dn2 = DeviceFeatureNormalizer(s, F, colmask=mask, lib=lib)
+        dn2.import_state(state)
+        got.append(dn2.process_batch(rows[130:131]))
+        got.append(dn2.process(rows[131])[None])       # the reference's one-vector call shape
+        got.append(dn2.process_batch(rows[132:]))
+        got = np.concatenate(got).astype(np.float64)
+        np.testing.assert_array_equal(got[:, mask == 0], rows[:, mask == 0].astype(np.float64))
+        np.testing.assert_allclose(got[:, mask == 1], want, rtol=1e-5, atol=2e-6, err_msg=f"{method} clip={clip}")
+        dn2.reset()
+        np.testing.assert_array_equal(dn2.process_batch(rows[:1]), rows[:1])

@@ -1,0 +1,75 @@
+"""The C-ABI boundary: libnmx.so builds, loads and exports every function include/nmx.h declares.
+
+No compute call is made here (there is no GPU in the CPU test tier); the entry points that must work
+without a device (version, device count, error string, argument validation) are exercised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import re
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def declared_functions() -> list[str]:
+    text = (ROOT / "include" / "nmx.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(nmx_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    path = g.build_lib()
+    return C.CDLL(str(path))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = declared_functions()
+    for must in ("nmx_plan_create", "nmx_process_batch", "nmx_process_window", "nmx_preprocess_window",
+                 "nmx_filter_window", "nmx_state_export", "nmx_norm_process", "nmx_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"libnmx.so lacks {missing}"
+
+
+def test_python_binding_lists_every_declared_symbol():
+    from py_neuromodulation_amd import _lib
+
+    assert sorted(_lib._EXPORTS) == declared_functions()
+
+
+def test_entry_points_that_need_no_device(lib):
+    lib.nmx_abi_version.restype = C.c_int
+    lib.nmx_device_count.restype = C.c_int
+    lib.nmx_last_error.restype = C.c_char_p
+    from py_neuromodulation_amd._lib import NMX_ABI_VERSION
+
+    assert lib.nmx_abi_version() == NMX_ABI_VERSION
+    assert lib.nmx_device_count() >= 0
+    # argument validation happens before any device work: error code + thread-local message
+    lib.nmx_plan_create.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.nmx_plan_create(None, None) < 0
+    assert lib.nmx_last_error()
+    lib.nmx_norm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+    h = C.c_void_p()
+    assert lib.nmx_norm_create(0, 0, 1, 3.0, 300, None, C.byref(h)) < 0    # n_cols must be positive
+    assert b"n_cols" in lib.nmx_last_error()
+
+
+def test_product_loader_has_no_cpu_fallback(tmp_path):
+    from py_neuromodulation_amd._lib import NmxError, NmxLibrary
+
+    with pytest.raises(NmxError):
+        NmxLibrary(tmp_path / "missing_libnmx.so")

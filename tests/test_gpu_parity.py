@@ -221,3 +221,7 @@ def test_odd_windows_and_spectra(gpu_lib):
 def test_reference_property_tests(gpu_lib):
     """Drop-in plugin classes (package loader, no lib injection) under the reference's property tests."""
     pc.case_reference_property_tests(gpu_lib)
+
+
+def test_feature_normalizer_batches(gpu_lib):
+    pc.case_feature_normalizer_batches(gpu_lib)

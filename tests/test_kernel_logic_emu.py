@@ -76,3 +76,7 @@ def test_ragged_float_sfreq_stream(emu_lib):
 
 def test_odd_windows_and_spectra(emu_lib):
     pc.case_odd_windows_and_spectra(emu_lib)
+
+
+def test_feature_normalizer_batches(emu_lib):
+    pc.case_feature_normalizer_batches(emu_lib)
