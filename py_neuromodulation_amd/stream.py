@@ -48,6 +48,7 @@ class Stream:
         self.device = device
         self._lib = lib  # None = the product library (libnmx.so); tests may inject a binding
         self.data = data
+        self.sess_right = None
         self.is_running = False
         # fail early like the reference (it builds a DataProcessor in __init__, :130)
         self.data_processor = self._make_processor(None)
@@ -74,7 +75,8 @@ class Stream:
         return data.to_numpy().transpose()
 
     def run(self, data=None, out_dir="", experiment_name: str = "sub", save_csv: bool = True,
-            return_df: bool = True, **unused):
+            return_df: bool = True, save_msgpack: bool = False, save_interval: int = 10,
+            delete_ind_batch_files_after_stream: bool = False, **unused):
         """Compute every hop of ``data`` and return the feature DataFrame."""
         import pandas as pd
 
@@ -115,10 +117,29 @@ class Stream:
         for idx, name in zip(tgt.index, tgt["name"].to_list()):
             df[name] = [float(data[idx, s + n - 1]) for s, n in zip(starts, lens)]
         self.is_running = False
+        # ---- output files, names and layouts of the reference (stream/stream.py:229,319-343,426-453)
+        writer = None
+        if save_msgpack:
+            from .file_writer import MsgPackFileWriter
+
+            writer = MsgPackFileWriter(name=experiment_name, out_dir=out_dir)
+            writer.insert_rows(df.columns, df.to_numpy(dtype=np.float64), save_interval=save_interval)
         if save_csv:
             out = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
             out.mkdir(parents=True, exist_ok=True)
             df.to_csv(out / f"{experiment_name}_FEATURES.csv", index=False)
-            self.settings.save(out_dir or Path.cwd(), experiment_name)
-            self.channels.to_csv(out / f"{experiment_name}_channels.csv", index=False)
+        if save_csv or save_msgpack:
+            self._save_after_stream(out_dir, experiment_name)
+        if writer is not None and delete_ind_batch_files_after_stream:
+            writer.delete_ind_files()
         return df if return_df else {}
+
+    # -- stream/stream.py:426-453, stream/data_processor.py:313-337 -----------------------------
+    def _save_after_stream(self, out_dir="", experiment_name: str = "sub") -> None:
+        from . import file_writer as fw
+
+        sidecar = {"original_fs": self.sfreq, "final_fs": self.data_processor.sfreq_raw,
+                   "sfreq": self.settings.sampling_rate_features_hz, "sess_right": self.sess_right}
+        fw.save_sidecar(sidecar, out_dir, experiment_name)
+        self.settings.save(out_dir or Path.cwd(), experiment_name)
+        fw.save_channels(self.channels, out_dir, experiment_name)

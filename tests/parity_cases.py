@@ -401,3 +401,58 @@ def case_feature_normalizer_batches(lib):
         np.testing.assert_allclose(got[:, mask == 1], want, rtol=1e-5, atol=2e-6, err_msg=f"{method} clip={clip}")
         dn2.reset()
         np.testing.assert_array_equal(dn2.process_batch(rows[:1]), rows[:1])
+
+
+def case_stream_output_files(lib, tmp_path):
+    """Stream.run writes the reference's artefacts (utils/file_writer.py:26-118, stream/stream.py:426-453):
+    {name}-{i}.msgpack per save interval, {name}_FEATURES.csv, _SIDECAR.json, _SETTINGS.yaml, _channels.csv."""
+    import json
+
+    import msgpack
+    import pandas as pd
+
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.file_writer import MsgPackFileWriter
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    for f in s.features.get_enabled():
+        setattr(s.features, f, False)
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.preprocessing = ["re_referencing"]
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((3, 4300))
+    st = Stream(sfreq=1000.0, data=data, settings=s, sampling_rate_features_hz=10, lib=lib)
+    df = st.run(data, out_dir=tmp_path, experiment_name="sub7", save_csv=True, save_msgpack=True, save_interval=10)
+    n = len(df)
+    assert n == 34
+    out = tmp_path / "sub7"
+    packs = sorted(out.glob("sub7-*.msgpack"), key=lambda p: int(p.stem.split("-")[1]))
+    assert len(packs) == (n + 9) // 10
+    with open(packs[0], "rb") as f:
+        first = msgpack.unpack(f)
+    assert isinstance(first, list) and len(first) == 10 and list(first[0].keys()) == list(df.columns)
+    assert all(isinstance(v, float) for v in first[0].values())
+    w = MsgPackFileWriter(name="sub7", out_dir=tmp_path)
+    w.idx = len(packs)
+    back = w.load_all()
+    assert list(back.columns) == list(df.columns)
+    np.testing.assert_array_equal(back.to_numpy(), df.to_numpy(dtype=np.float64))
+    csv = pd.read_csv(out / "sub7_FEATURES.csv")
+    assert list(csv.columns) == list(df.columns)
+    np.testing.assert_allclose(csv.to_numpy(), df.to_numpy(dtype=np.float64), rtol=1e-12, equal_nan=True)
+    side = json.loads((out / "sub7_SIDECAR.json").read_text())
+    assert side == {"original_fs": 1000.0, "final_fs": 1000.0, "sfreq": 10, "sess_right": None}
+    assert (out / "sub7_SETTINGS.yaml").exists()
+    ch = pd.read_csv(out / "sub7_channels.csv")
+    assert list(ch["name"]) == list(st.channels["name"])
+    # hop-by-hop interface of the writer (the reference's call shape)
+    w2 = MsgPackFileWriter(name="live", out_dir=tmp_path)
+    for i in range(3):
+        w2.insert_data({"a": i, "b": None})
+    w2.save()
+    w2.save_as_csv(save_all_combined=True)
+    assert pd.read_csv(tmp_path / "live" / "live_FEATURES.csv")["b"].tolist() == [0, 0, 0]
+    w2.delete_ind_files()
+    assert not list((tmp_path / "live").glob("*.msgpack"))

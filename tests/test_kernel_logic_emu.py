@@ -80,3 +80,7 @@ def test_odd_windows_and_spectra(emu_lib):
 
 def test_feature_normalizer_batches(emu_lib):
     pc.case_feature_normalizer_batches(emu_lib)
+
+
+def test_stream_output_files(emu_lib, tmp_path):
+    pc.case_stream_output_files(emu_lib, tmp_path)
