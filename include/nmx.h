@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 1
+#define NMX_ABI_VERSION 2
 
 /* error codes */
 #define NMX_OK 0
@@ -155,6 +155,13 @@ typedef struct {
   int32_t n_notch_taps;
   const double* ref_matrix; /* NULL = identity; [C][C_in] row-major, processing/rereference.py:52-100 */
   int32_t n_channels_in;    /* rows of the incoming data when ref_matrix is given */
+
+  /* Kalman smoothing of bandpass_activity (features/bandpower.py:147-163,188-189;
+   * filter/kalman_filter.py:45-78): white-noise-acceleration model, one 2-state filter per
+   * (channel, band) with bit `band` of bp_kalman_mask set, predict + update once per hop on the
+   * (log-)activity BEFORE nan_to_num.  0 = off.  State is part of nmx_state_*. */
+  uint32_t bp_kalman_mask;
+  double kalman_Tp, kalman_sigma_w, kalman_sigma_v;
 } nmx_plan_desc;
 
 typedef struct nmx_plan nmx_plan;

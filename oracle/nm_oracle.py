@@ -381,13 +381,37 @@ def design_bank(f_ranges, sfreq, filter_length=None, l_trans=4, h_trans=4) -> np
     return np.vstack(bank)
 
 
+class KalmanWNA:
+    """filter/kalman_filter.py:45-78 (white-noise-acceleration model) with the predict / update
+    steps of filter/kalman_filter_external.py:466-590 (filterpy, Joseph-form covariance)."""
+
+    def __init__(self, Tp: float, sigma_w: float, sigma_v: float) -> None:
+        self.x = np.array([0.0, 1.0])
+        self.F = np.array([[1.0, Tp], [0.0, 1.0]])
+        self.H = np.array([[1.0, 0.0]])
+        self.R = sigma_v
+        self.Q = np.array([[sigma_w**2 * Tp**3 / 3, sigma_w**2 * Tp**2 / 2],
+                           [sigma_w**2 * Tp**2 / 2, sigma_w**2 * Tp]])
+        self.P = np.cov([[1, 0], [0, 1]])
+
+    def step(self, z: float) -> float:
+        self.x = self.F @ self.x
+        self.P = self.F @ self.P @ self.F.T + self.Q
+        y = np.atleast_1d(z) - self.H @ self.x
+        PHT = self.P @ self.H.T
+        S = self.H @ PHT + self.R
+        K = PHT @ np.linalg.inv(S)
+        self.x = self.x + K @ y
+        I_KH = np.eye(2) - K @ self.H
+        self.P = I_KH @ self.P @ I_KH.T + (K * self.R) @ K.T
+        return self.x[0]
+
+
 class BandPower:
-    """features/bandpower.py:98-207 (Kalman smoothing is out of scope)."""
+    """features/bandpower.py:98-207 incl. the optional Kalman smoothing of the activity (:147-163)."""
 
     def __init__(self, settings, ch_names, sfreq, taps: np.ndarray | None = None) -> None:
         self.s = settings.bandpass_filter_settings
-        if getattr(self.s, "kalman_filter", False):
-            raise NotImplementedError("kalman_filter is out of scope")
         self.sfreq = sfreq
         self.ch_names = list(ch_names)
         bands = _band_items(settings)
@@ -397,6 +421,12 @@ class BandPower:
             int(np.floor(sfreq / 1000 * self.s.segment_lengths_ms[b])) for b in self.band_names
         ]
         self.feats = _enabled(self.s.bandpower_features)
+        self.kf = {}
+        if getattr(self.s, "kalman_filter", False):
+            ks = settings.kalman_filter_settings
+            for band in ks.frequency_bands:
+                for ch in self.ch_names:
+                    self.kf[f"{ch}_bandpass_activity_{band}"] = KalmanWNA(ks.Tp, ks.sigma_w, ks.sigma_v)
 
     def calc_feature(self, data):
         y = fir_bank_apply(data, self.taps)  # (C, B, W)
@@ -408,12 +438,15 @@ class BandPower:
                 act, mob, comp = hjorth_params(t)
                 if self.s.log_transform:
                     act = np.log10(act)
-                vals[bi] = {"activity": np.nan_to_num(act), "mobility": np.nan_to_num(mob),
-                            "complexity": np.nan_to_num(comp)}
+                vals[bi] = {"activity": act, "mobility": mob, "complexity": comp}
         for ci, ch in enumerate(self.ch_names):
             for bi, band in enumerate(self.band_names):
                 for f in self.feats:
-                    out[f"{ch}_bandpass_{f}_{band}"] = vals[bi][f][ci]
+                    key = f"{ch}_bandpass_{f}_{band}"
+                    v = vals[bi][f][ci]
+                    if f == "activity" and key in self.kf:   # before nan_to_num (:188-197)
+                        v = self.kf[key].step(v)
+                    out[key] = np.nan_to_num(v)
         return out
 
 

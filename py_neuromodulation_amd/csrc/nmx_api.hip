@@ -6,6 +6,7 @@
 #include "nmx_k_bank.h"
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_bursts.h"
+#include "nmx_k_kalman.h"
 #include "nmx_k_norm.h"
 #include "nmx_k_prep.h"
 #include "nmx_k_sharpwave.h"
@@ -38,6 +39,10 @@ extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_item
 extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s);
 __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
   nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
+}
+__global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
+  const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+  nmx_kalman_item(A, i / A.n_bands, i % A.n_bands);
 }
 __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
@@ -215,6 +220,10 @@ static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_s
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
   hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+}
+static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
+  const int n = A.n_channels * A.n_bands;
+  hipLaunchKernelGGL(nmx_kern_kalman, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A);
 }
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   // one thread per column, one wave per workgroup: columns spread over as many CUs as possible

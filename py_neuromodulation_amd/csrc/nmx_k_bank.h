@@ -45,6 +45,7 @@ struct NmxBankArgs {
   NmxFilterDev f[NMX_MAX_FILTERS_DEV];
   unsigned bp_features;  // bit0 activity, bit1 mobility, bit2 complexity
   int bp_log;
+  unsigned bp_kalman_mask;   // bit band: a Kalman scan follows -> store the raw (log-)activity
   NmxCols bp_cols;
   // Hilbert envelope (Bursts)
   int n_burst_bands;
@@ -135,7 +136,7 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
       if (NMX_TID == 0) {
         int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
         if (A.bp_features & 1u) {
-          out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act);
+          out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u);
           col += A.bp_cols.b_stride;
         }
         if (A.bp_features & 2u) {

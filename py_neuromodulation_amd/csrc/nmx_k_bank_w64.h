@@ -403,7 +403,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         NMX_LANE_LOOP {
           if (l == 0) {
             const int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
-            out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act);
+            out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u);
           }
         }
       } else {  // mobility / complexity need neighbours: go through LDS (natural order)
@@ -418,7 +418,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         nmx_hjorth(y + (W - F.bp_seglen), F.bp_seglen, red, 1, true, act, mob, comp);
         if (NMX_TID == 0) {
           int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
-          if (A.bp_features & 1u) { out_row[col] = nmx_nan_to_num(A.bp_log ? log10f(act) : act); col += A.bp_cols.b_stride; }
+          if (A.bp_features & 1u) { out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u); col += A.bp_cols.b_stride; }
           if (A.bp_features & 2u) { out_row[col] = nmx_nan_to_num(mob); col += A.bp_cols.b_stride; }
           if (A.bp_features & 4u) out_row[col] = nmx_nan_to_num(comp);
         }

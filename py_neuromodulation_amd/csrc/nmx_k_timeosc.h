@@ -28,6 +28,9 @@ NMX_DEV float nmx_var(int n, float* red, F f) {
 }
 
 NMX_DEV float nmx_nan_to_num(float v) { return nmx_clean(v); }
+// band-pass activity cell: nan_to_num'd (bandpower.py:197) unless a Kalman scan follows, which needs
+// the raw value (the reference filters before nan_to_num, bandpower.py:188-197)
+NMX_DEV float nmx_bp_activity(float v, unsigned raw) { return raw ? v : nmx_clean(v); }
 
 // Hjorth triple of a series y[0..n) in LDS, with the reference's nan_to_num placement.
 // mode 0 = hjorth_raw.py (complexity divides by the nan_to_num'ed mobility),

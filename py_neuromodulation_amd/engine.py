@@ -182,9 +182,14 @@ class HotPathEngine:
                 col += used
             elif f == "bandpass_filter":
                 bp = st.bandpass_filter_settings
-                if getattr(bp, "kalman_filter", False):
-                    raise NotImplementedError("kalman_filter is outside the accelerated hot path")
                 bfeats = _enabled(bp.bandpower_features)
+                if getattr(bp, "kalman_filter", False) and "activity" in bfeats:
+                    # bandpower.py:125-126,147-156: one filter per channel for every band of
+                    # kalman_filter_settings.frequency_bands (bands missing from
+                    # frequency_ranges_hz never match a feature name and stay unused)
+                    ks = st.kalman_filter_settings
+                    d.bp_kalman_mask = sum(1 << band_index[b] for b in ks.frequency_bands if b in band_index)
+                    d.kalman_Tp, d.kalman_sigma_w, d.kalman_sigma_v = float(ks.Tp), float(ks.sigma_w), float(ks.sigma_v)
                 d.bp_features = sum(1 << ["activity", "mobility", "complexity"].index(x) for x in bfeats)
                 d.bp_log_transform = int(bool(bp.log_transform))
                 nf = len(bfeats)

@@ -179,6 +179,9 @@ def _default_dict() -> dict:
                                    "HFA": 100},
             "bandpower_features": {"activity": True, "mobility": False, "complexity": False},
             "log_transform": True, "kalman_filter": False},
+        "kalman_filter_settings": {"Tp": 0.1, "sigma_w": 0.7, "sigma_v": 1.0,
+                                   "frequency_bands": ["theta", "alpha", "low_beta", "high_beta",
+                                                       "low_gamma", "high_gamma", "HFA"]},
         "bursts_settings": {"threshold": 75, "time_duration_s": 30,
                             "frequency_bands": ["low_beta", "high_beta"],
                             "burst_features": {"duration": True, "amplitude": True,

@@ -16,6 +16,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank_w64.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bursts.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_kalman.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_norm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
@@ -100,6 +101,10 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t) {
   for (long long t = 0; t < A.T; ++t) nmx_car_sample(A, t);
+}
+static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t) {
+  for (int c = 0; c < A.n_channels; ++c)
+    for (int b = 0; b < A.n_bands; ++b) nmx_kalman_item(A, c, b);
 }
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t) {
   for (int j = 0; j < A.n_cols; ++j) nmx_norm_column(A, j);

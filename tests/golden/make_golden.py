@@ -310,7 +310,43 @@ def case_notch():
     print("notch", [k for k in out])
 
 
+def case_bandpower_kalman():
+    """BandPower with kalman_filter over consecutive hops (bandpower.py:147-163,188-189): the
+    reference's own filterpy-derived KalmanFilter runs per (channel, band); "high_beta" is left out
+    of kalman_filter_settings.frequency_bands so filtered and unfiltered bands are mixed."""
+    sfreq, C, T = 1000, 2, 5000
+    s = nm.NMSettings.get_default().reset()
+    s.features.bandpass_filter = True
+    s.bandpass_filter_settings.kalman_filter = True
+    s.bandpass_filter_settings.bandpower_features.mobility = True
+    s.kalman_filter_settings.frequency_bands = ["theta", "alpha", "low_beta"]
+    s = s.validate()
+    rng = np.random.default_rng(21)
+    t = np.arange(T) / sfreq
+    amp = 1 + 0.9 * np.sin(2 * np.pi * 0.5 * t)
+    data = rng.standard_normal((C, T)) * 10 + 25 * amp * np.sin(2 * np.pi * 10 * t)
+    ch_names = [f"ch{i}" for i in range(C)]
+    bp = nm.features.BandPower(s, ch_names, sfreq)
+    gen = nm.stream.generator.RawDataGenerator(data, sfreq, s.sampling_rate_features_hz,
+                                               s.segment_length_features_ms)
+    rows, keys = [], None
+    for _, w in gen:
+        d = bp.calc_feature(w)
+        keys = list(d.keys())
+        rows.append([float(v) for v in d.values()])
+    out = {"settings_json": dump(s), "sfreq": sfreq, "data": data, "ch_names": np.array(ch_names),
+           "bandpass_taps": bp.bandpass_filter.filter_bank, "keys": np.array(keys),
+           "values": np.array(rows)}
+    np.savez_compressed(HERE / "bandpower_kalman.npz", **out)
+    print("bandpower_kalman", out["values"].shape)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
+        for name in sys.argv[1:]:
+            globals()["case_" + name]()
+        sys.exit(0)
+    case_bandpower_kalman()
     case_schedule()
     case_feat_1k()
     case_feat_2k()

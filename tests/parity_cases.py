@@ -456,3 +456,37 @@ def case_stream_output_files(lib, tmp_path):
     assert pd.read_csv(tmp_path / "live" / "live_FEATURES.csv")["b"].tolist() == [0, 0, 0]
     w2.delete_ind_files()
     assert not list((tmp_path / "live").glob("*.msgpack"))
+
+
+def case_bandpower_kalman_sequence(lib):
+    """41 consecutive hops of BandPower with kalman_filter (golden from the reference): the per
+    (channel, band) filter state carries across batches, single-window calls and export/import.
+    fp32 log-activity goes into a float64 filter: tolerance 1e-5 relative + 2e-6 absolute."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("bandpower_kalman")
+    s = settings_from_json(g["settings_json"])
+    ch = [str(c) for c in g["ch_names"]]
+    sfreq = float(g["sfreq"])
+    data = g["data"]
+    starts, _, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz,
+                                       s.segment_length_features_ms)
+    keys = [str(k) for k in g["keys"]]
+    want = g["values"]
+    eng = HotPathEngine(s, ch, sfreq, lib=lib, features=["bandpass_filter"])
+    assert eng.keys == keys
+    rows = [eng.process_batch(data, starts[:17])]
+    rows += [eng.process_window(data[:, a:a + eng.W])[None] for a in starts[17:20]]
+    state = eng.export_state()
+    eng2 = HotPathEngine(s, ch, sfreq, lib=lib, features=["bandpass_filter"])
+    eng2.import_state(state)
+    rows.append(eng2.process_batch(data, starts[20:]))
+    got = np.concatenate(rows)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+    # reset = fresh filters (x = [0, 1], P = cov([[1, 0], [0, 1]]))
+    eng2.reset_state()
+    np.testing.assert_allclose(eng2.process_batch(data, starts[:3]), want[:3], rtol=1e-5, atol=2e-6)
+    eng.close()
+    eng2.close()

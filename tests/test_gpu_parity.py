@@ -225,3 +225,7 @@ def test_reference_property_tests(gpu_lib):
 
 def test_feature_normalizer_batches(gpu_lib):
     pc.case_feature_normalizer_batches(gpu_lib)
+
+
+def test_bandpower_kalman_sequence(gpu_lib):
+    pc.case_bandpower_kalman_sequence(gpu_lib)

@@ -84,3 +84,7 @@ def test_feature_normalizer_batches(emu_lib):
 
 def test_stream_output_files(emu_lib, tmp_path):
     pc.case_stream_output_files(emu_lib, tmp_path)
+
+
+def test_bandpower_kalman_sequence(emu_lib):
+    pc.case_bandpower_kalman_sequence(emu_lib)
