@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 2
+#define NMX_ABI_VERSION 3
 
 /* error codes */
 #define NMX_OK 0
@@ -162,6 +162,13 @@ typedef struct {
    * (log-)activity BEFORE nan_to_num.  0 = off.  State is part of nmx_state_*. */
   uint32_t bp_kalman_mask;
   double kalman_Tp, kalman_sigma_w, kalman_sigma_v;
+
+  /* raw_resampling (processing/resample.py:19-60 -> mne.filter.resample, FFT method): every
+   * incoming window of raw_window samples is resampled by resample_ratio = new_sfreq / old_sfreq to
+   * `window` = round(ratio * raw_window) samples before notch / features; `sfreq` is the NEW rate.
+   * raw_window == 0: no resampling (incoming windows have `window` samples). */
+  int32_t raw_window;
+  double resample_ratio;
 } nmx_plan_desc;
 
 typedef struct nmx_plan nmx_plan;
@@ -191,7 +198,8 @@ int nmx_process_batch(nmx_plan* plan, const float* x, int64_t ldx, int64_t n_sam
 int nmx_process_window(nmx_plan* plan, const double* x, int64_t ldx, float* out,
                        uint8_t* nan_mask);
 
-/* Pre-processing only (NMPreprocessor.process): x[C_in][W] float64 host -> y[C][W] float64. */
+/* Pre-processing only (NMPreprocessor.process): x[C_in][W_in] float64 host -> y[C][W] float64
+ * (W_in = raw_window when the plan resamples, else W). */
 int nmx_preprocess_window(nmx_plan* plan, const double* x, int64_t ldx, double* y, int64_t ldy);
 
 /* FIR bank only (MNEFilter.filter_data): x[C][W] -> y[C][n_filters][W] float64 host. */

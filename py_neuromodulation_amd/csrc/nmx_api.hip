@@ -9,6 +9,7 @@
 #include "nmx_k_kalman.h"
 #include "nmx_k_norm.h"
 #include "nmx_k_prep.h"
+#include "nmx_k_resample.h"
 #include "nmx_k_sharpwave.h"
 #include "nmx_k_timeosc.h"
 
@@ -39,6 +40,10 @@ extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_item
 extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s);
 __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
   nmx_reref_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF_ROWS);
+}
+__global__ void __launch_bounds__(256) nmx_kern_resample(const NmxResampleArgs A) {
+  const int item = blockIdx.x;
+  nmx_resample_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
 }
 __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
   const int i = (int)(blockIdx.x * 64 + threadIdx.x);
@@ -159,6 +164,7 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_timeosc);
   be_allow_lds(nmx_kern_bank);
   be_allow_lds(nmx_kern_hilbert);
+  be_allow_lds(nmx_kern_resample);
   be_allow_lds(nmx_kern_burst_thr<32>);
   be_allow_lds(nmx_kern_burst_thr<64>);
   be_allow_lds(nmx_kern_burst_thr<128>);
@@ -220,6 +226,10 @@ static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_s
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
   hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+}
+static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+  be_init_once();
+  hipLaunchKernelGGL(nmx_kern_resample, dim3(n_items), dim3(nt), lds, s, A);
 }
 static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
   const int n = A.n_channels * A.n_bands;

@@ -33,7 +33,8 @@ class DataProcessor:
     def __init__(self, sfreq: float, settings, channels, coord_names=None, coord_list=None,
                  line_noise: float | None = None, path_grids=None, verbose: bool = True,
                  device: int = 0, window: int | None = None, lib=None,
-                 channel_subset=None, dry_run: bool = False) -> None:
+                 channel_subset=None, dry_run: bool = False,
+                 resample_features_at_new_rate: bool = False) -> None:
         self.settings = NMSettings.load(settings)
         self.channels = chmod.load_channels(channels)
         self.sfreq_features = self.settings.sampling_rate_features_hz
@@ -49,6 +50,7 @@ class DataProcessor:
 
         notch_taps = None
         R = None
+        resample_to = None
         for name in st.preprocessing:
             if name not in PREPROCESSOR_ORDER:
                 raise ValueError(f"Invalid preprocessing method '{name}'. Must be one of {PREPROCESSOR_ORDER}")
@@ -60,12 +62,18 @@ class DataProcessor:
                     raise ValueError("Either line_noise or freqs must be defined if notch_filter is activated.")
                 notch_taps = fir_design.notch_bank(self.sfreq_raw, line_noise)
             elif name == "raw_resampling":
-                if float(st.raw_resampling_settings.resample_freq_hz / self.sfreq_raw) != 1.0:
-                    raise NotImplementedError(
-                        "raw_resampling at a ratio != 1 is outside the accelerated path (parity "
-                        "unpinned vs MNE); set raw_resampling_settings.resample_freq_hz == sfreq. "
-                        "Note the reference keeps building features with the RAW rate "
-                        "(stream/data_processor.py:55,68,80).")
+                new_rate = float(st.raw_resampling_settings.resample_freq_hz)
+                if float(new_rate / self.sfreq_raw) != 1.0:
+                    if not resample_features_at_new_rate:
+                        raise NotImplementedError(
+                            "raw_resampling at a ratio != 1: the reference resamples every window but "
+                            "keeps building notch AND features with the RAW rate "
+                            "(stream/data_processor.py:55,68,80), i.e. all frequency axes are off by the "
+                            "ratio.  That behaviour is not reproduced.  Pass "
+                            "resample_features_at_new_rate=True for the consistent pipeline (notch at the "
+                            "raw rate, FFT resampling on the device, features at the new rate), or set "
+                            "raw_resampling_settings.resample_freq_hz == sfreq.")
+                    resample_to = new_rate
             elif name == "re_referencing":
                 R = chmod.reref_matrix(self.channels)
             else:
@@ -91,8 +99,14 @@ class DataProcessor:
                 full = np.eye(n_all)
             full = full[subset]
             names = [self.ch_names_used[i] for i in subset]
-        self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
-                                    device=device, window=window, lib=lib, dry_run=dry_run)
+        if resample_to is None:
+            self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
+                                        device=device, window=window, lib=lib, dry_run=dry_run)
+        else:   # `window` counts RAW samples (the generator cuts raw data)
+            self.engine = HotPathEngine(st, names, resample_to, ref_matrix=full, notch_taps=notch_taps,
+                                        device=device, lib=lib, dry_run=dry_run,
+                                        resample_from=self.sfreq_raw, raw_window=window)
+            self.sfreq_raw = resample_to
         self.keys = self.engine.keys
         self.feature_normalizer = None
         self.non_psd_indices = None

@@ -50,8 +50,14 @@ class HotPathEngine:
                  notch_taps: np.ndarray | None = None, device: int = 0,
                  lib: _lib.NmxLibrary | None = None, bank_taps: np.ndarray | None = None,
                  sharpwave_taps: Sequence[np.ndarray] | None = None,
-                 window: int | None = None, dry_run: bool = False) -> None:
-        """``dry_run=True`` only derives the plan description and the key list (no library, no
+                 window: int | None = None, dry_run: bool = False,
+                 resample_from: float | None = None, raw_window: int | None = None) -> None:
+        """``sfreq`` is the rate the features see.  ``resample_from`` = sampling rate of the incoming
+        windows when it differs (raw_resampling, processing/resample.py:19-60): incoming windows then
+        hold ``raw_window`` samples (default int(segment_length_features_ms / 1000 * resample_from)) and
+        are resampled on the device to ``window`` = round(ratio * raw_window) samples.
+
+        ``dry_run=True`` only derives the plan description and the key list (no library, no
         GPU) -- used to lay out the global column order when channels are sharded over GPUs."""
         self.lib = None if dry_run else (lib if lib is not None else _lib.get_library())
         self.settings = settings
@@ -66,6 +72,13 @@ class HotPathEngine:
         self.enabled = enabled
         # window samples as the generator cuts them (stream/generator.py:34-53)
         self.W = int(window) if window is not None else int(settings.segment_length_features_ms / 1000 * sfreq)
+        self.W_in, self.resample_ratio = self.W, 0.0
+        if resample_from is not None and float(resample_from) != self.sfreq:
+            self.resample_ratio = self.sfreq / float(resample_from)
+            self.W_in = (int(raw_window) if raw_window is not None
+                         else int(settings.segment_length_features_ms / 1000 * float(resample_from)))
+            if window is None:
+                self.W = int(round(self.resample_ratio * self.W_in))   # mne.filter.resample: final_len
         self._keep: list = []   # arrays referenced by the C struct
         self.keys: list[str] = []
         self.desc = self._build(ref_matrix, notch_taps, device, bank_taps, sharpwave_taps)
@@ -126,6 +139,9 @@ class HotPathEngine:
         d.device = int(device)
         d.n_channels = C_
         d.window = W
+        if self.resample_ratio:
+            d.raw_window = int(self.W_in)
+            d.resample_ratio = float(self.resample_ratio)
         d.sfreq = sfreq
         d.feat_hz = float(st.sampling_rate_features_hz)
         bands = [(name, (float(fr[0]), float(fr[1]))) for name, fr in st.frequency_ranges_hz.items()]
@@ -351,8 +367,8 @@ class HotPathEngine:
     def process_window(self, data: np.ndarray, want_nan_mask: bool = False):
         """data[C_in, W] (float64, may be a non-contiguous view) -> float32[n_outputs]."""
         data = np.asarray(data, dtype=np.float64)
-        if data.ndim != 2 or data.shape[0] != self.C_in or data.shape[1] != self.W:
-            raise ValueError(f"expected data of shape ({self.C_in}, {self.W}), got {data.shape}")
+        if data.ndim != 2 or data.shape[0] != self.C_in or data.shape[1] != self.W_in:
+            raise ValueError(f"expected data of shape ({self.C_in}, {self.W_in}), got {data.shape}")
         if data.strides[1] != 8:
             data = np.ascontiguousarray(data)
         out = np.empty(self.n_outputs, np.float32)
@@ -388,6 +404,8 @@ class HotPathEngine:
 
     def preprocess_window(self, data: np.ndarray) -> np.ndarray:
         data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.ndim != 2 or data.shape != (self.C_in, self.W_in):
+            raise ValueError(f"expected data of shape ({self.C_in}, {self.W_in}), got {data.shape}")
         y = np.empty((self.C, self.W), np.float64)
         self.lib.check(self.lib.lib.nmx_preprocess_window(self._plan, data.ctypes.data, data.shape[1],
                                                          y.ctypes.data, self.W))

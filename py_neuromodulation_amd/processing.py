@@ -2,8 +2,8 @@
 
   NotchFilter   filter/notch_filter.py:9-93     process(data[C, W]) -> data   (HIP FIR kernel)
   ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
-  Resampler     processing/resample.py:19-60    identity at ratio 1 (all BASELINE configs);
-                                                other ratios: NotImplementedError (MNE parity unpinned)
+  Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
+                                                algorithm, parity unpinned); identity at ratio 1
   FeatureNormalizer processing/normalization.py:31-111 -- host NumPy version (all methods incl.
                 the median / scikit-learn ones), one call per hop like the reference.
   DeviceFeatureNormalizer  the same post-processing for the "mean" and "zscore" (default) methods as
@@ -20,9 +20,13 @@ from .engine import HotPathEngine
 from .settings import NMSettings
 
 
-def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None):
+def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, resample_to=None):
     s = NMSettings.get_default()
     C = C_out if C_out is not None else C_in
+    if resample_to is not None:   # W raw samples at `sfreq` -> round(ratio * W) at `resample_to`
+        return HotPathEngine(s, [f"c{i}" for i in range(C)], resample_to, features=["return_raw"],
+                             notch_taps=notch_taps, ref_matrix=ref_matrix, resample_from=sfreq,
+                             raw_window=W, window=int(round(float(resample_to / sfreq) * W)))
     return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
                          notch_taps=notch_taps, ref_matrix=ref_matrix, window=W)
 
@@ -67,16 +71,24 @@ class ReReferencer:
 
 
 class Resampler:
+    """processing/resample.py:19-60: ``mne.filter.resample(data, up = new / old, down = 1)`` per window
+    (FFT method, reflect_limited padding) on the device; identity at ratio 1 like the reference."""
+
     def __init__(self, sfreq: float, resample_freq_hz: float, **kwargs) -> None:
+        self.sfreq = float(sfreq)
+        self.resample_freq_hz = float(resample_freq_hz)
         ratio = float(resample_freq_hz / sfreq)
         self.up = 0.0 if ratio == 1.0 else ratio
+        self._engines: dict = {}
 
     def process(self, data: np.ndarray) -> np.ndarray:
         if not self.up:
             return data
-        raise NotImplementedError(
-            "raw_resampling at a ratio != 1 is outside the accelerated path (MNE's resampler is "
-            "parity-unpinned, SURVEY.md 8c); set raw_resampling_settings.resample_freq_hz == sfreq")
+        data = np.asarray(data, dtype=np.float64)
+        if data.shape not in self._engines:
+            self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq,
+                                                    resample_to=self.resample_freq_hz)
+        return self._engines[data.shape].preprocess_window(data)
 
 
 class FeatureNormalizer:

@@ -25,7 +25,7 @@ class Stream:
     def __init__(self, sfreq: float, channels=None, data=None, settings=None,
                  line_noise: float | None = 50, sampling_rate_features_hz: float | None = None,
                  path_grids=None, coord_names=None, coord_list=None, verbose: bool = False,
-                 device: int = 0, lib=None) -> None:
+                 device: int = 0, lib=None, resample_features_at_new_rate: bool = False) -> None:
         self.settings = NMSettings.load(settings)
         if channels is None and data is not None:
             channels = chmod.get_default_channels_from_data(data)
@@ -46,6 +46,7 @@ class Stream:
         self.line_noise = line_noise
         self.verbose = verbose
         self.device = device
+        self._resample_new_rate = resample_features_at_new_rate
         self._lib = lib  # None = the product library (libnmx.so); tests may inject a binding
         self.data = data
         self.sess_right = None
@@ -56,7 +57,8 @@ class Stream:
     def _make_processor(self, window):
         return DataProcessor(sfreq=self.sfreq, settings=self.settings, channels=self.channels,
                              line_noise=self.line_noise, verbose=self.verbose, device=self.device,
-                             window=window, lib=self._lib)
+                             window=window, lib=self._lib,
+                             resample_features_at_new_rate=self._resample_new_rate)
 
     def _handle_data(self, data) -> np.ndarray:
         names_expected = self.channels["name"].to_list()

@@ -19,6 +19,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_kalman.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_norm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_resample.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_timeosc.h"
 
@@ -101,6 +102,10 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t) {
   for (long long t = 0; t < A.T; ++t) nmx_car_sample(A, t);
+}
+static void be_launch_resample(const NmxResampleArgs& A, int n_items, int, size_t lds, be_stream_t) {
+  std::vector<float> sm(lds / 4 + 16);
+  for (int it = 0; it < n_items; ++it) nmx_resample_item(A, it / A.n_channels, it % A.n_channels, sm.data());
 }
 static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t) {
   for (int c = 0; c < A.n_channels; ++c)

@@ -490,3 +490,85 @@ def case_bandpower_kalman_sequence(lib):
     np.testing.assert_allclose(eng2.process_batch(data, starts[:3]), want[:3], rtol=1e-5, atol=2e-6)
     eng.close()
     eng2.close()
+
+
+def case_resampler(lib):
+    """Resampler.process == the restated mne.filter.resample (oracle/mne_restated.py, PARITY UNPINNED
+    against MNE itself): down- and up-sampling, power-of-two and composite lengths, an odd resampled
+    length (full complex inverse), NaN cleaning, and the engine path notch -> resample -> features.
+    Tolerance: fp32 transforms of ~1e3..4e3 points on data of amplitude A: 2e-5 * A absolute."""
+    from oracle import mne_restated as mr
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings, fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.processing import Resampler
+
+    rng = np.random.default_rng(11)
+    for sf_old, sf_new, W in ((2000, 1000, 2000), (1000, 2000, 500), (2048, 1000, 2048), (4000, 1000, 4000),
+                              (1000, 250, 1000), (1375, 500, 1375), (1000, 1000, 300)):
+        t = np.arange(W) / sf_old
+        x = rng.standard_normal((3, W)) * 20 + 50 * np.sin(2 * np.pi * 11 * t) + rng.uniform(-300, 300, (3, 1))
+        rs = Resampler(sf_old, sf_new)
+        if rs.up:   # the class builds its engine lazily with the product library; inject `lib` here
+            rs._engines[x.shape] = HotPathEngine(
+                NMSettings.get_default(), [f"c{i}" for i in range(3)], sf_new, features=["return_raw"],
+                resample_from=sf_old, raw_window=W, window=int(round(sf_new / sf_old * W)), lib=lib)
+        got = rs.process(x)
+        want = mr.resample(x, up=sf_new / sf_old, down=1.0)
+        assert got.shape == want.shape == (3, int(round(sf_new / sf_old * W)))
+        amp = np.abs(x).max()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * amp, err_msg=f"{sf_old}->{sf_new}")
+    # engine path: 2 kHz windows, notch at the raw rate, resample to 1 kHz, features at 1 kHz
+    s = NMSettings.get_default()
+    for f in s.features.get_enabled():
+        setattr(s.features, f, False)
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.features.return_raw = True
+    s.postprocessing.feature_normalization = False
+    C, W = 2, 2000
+    T = W + 5 * 200
+    t = np.arange(T) / 2000
+    x = rng.standard_normal((C, T)) * 20 + 30 * np.sin(2 * np.pi * 50 * t) + 25 * np.sin(2 * np.pi * 17 * t)
+    x[0, 1200] = np.nan
+    notch = fir_design.notch_bank(2000.0, 50)
+    eng = HotPathEngine(s, ["a", "b"], 1000.0, resample_from=2000.0, notch_taps=notch, lib=lib)
+    assert (eng.W_in, eng.W) == (2000, 1000)
+    starts = np.arange(6) * 200
+    got, mask = eng.process_batch(x, starts, want_nan_mask=True)
+    assert mask[:, 0].tolist() == [a <= 1200 < a + W for a in starts] and not mask[:, 1].any()
+    feats = [orc.Hjorth(s, ["a", "b"], 1000.0), orc.Raw(s, ["a", "b"], 1000.0), orc.FFT(s, ["a", "b"], 1000.0)]
+    nf = orc.NotchFilter(2000.0, 50, taps=notch)
+    for i, a in enumerate(starts):
+        w = np.nan_to_num(x[:, a:a + W])
+        y = mr.resample(nf.process(w), up=0.5, down=1.0)
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(y))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, 1000.0,
+                                       float(np.abs(w).max()), 1000)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
+    # Stream level: the reference's raw-rate quirk is refused by default, the consistent pipeline is opt-in
+    import pytest
+
+    from py_neuromodulation_amd.stream import Stream
+
+    s.preprocessing = ["raw_resampling", "notch_filter", "re_referencing"]
+    xs = np.nan_to_num(x)
+    with pytest.raises(NotImplementedError):
+        Stream(sfreq=2000.0, data=xs, settings=s, lib=lib)
+    st = Stream(sfreq=2000.0, data=xs, settings=s, lib=lib, resample_features_at_new_rate=True)
+    df = st.run(xs, save_csv=False)
+    assert len(df) == 6 and st.data_processor.sfreq_raw == 1000.0
+    R = np.array([[1.0, -1.0], [-1.0, 1.0]])      # default channel table: common average of 2 channels
+    names = [k for k in df.columns if k != "time"]
+    for i, a in enumerate(starts):
+        y = R @ mr.resample(nf.process(xs[:, a:a + W]), up=0.5, down=1.0)
+        want = {}
+        for f in (orc.Hjorth(s, ["ch0_avgref", "ch1_avgref"], 1000.0), orc.Raw(s, ["ch0_avgref", "ch1_avgref"], 1000.0),
+                  orc.FFT(s, ["ch0_avgref", "ch1_avgref"], 1000.0)):
+            want.update(f.calc_feature(y))
+        n_bad, rep, _ = parity.compare(names, df.iloc[i][names].to_numpy(dtype=np.float64),
+                                       [want[k] for k in names], s, 1000.0, float(np.abs(xs).max()), 1000)
+        assert n_bad == 0, f"stream hop {i}\n{rep}"

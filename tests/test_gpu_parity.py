@@ -229,3 +229,7 @@ def test_feature_normalizer_batches(gpu_lib):
 
 def test_bandpower_kalman_sequence(gpu_lib):
     pc.case_bandpower_kalman_sequence(gpu_lib)
+
+
+def test_resampler(gpu_lib):
+    pc.case_resampler(gpu_lib)

@@ -88,3 +88,7 @@ def test_stream_output_files(emu_lib, tmp_path):
 
 def test_bandpower_kalman_sequence(emu_lib):
     pc.case_bandpower_kalman_sequence(emu_lib)
+
+
+def test_resampler(emu_lib):
+    pc.case_resampler(emu_lib)
