@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 3
+#define NMX_ABI_VERSION 4
 
 /* error codes */
 #define NMX_OK 0
@@ -69,6 +69,7 @@ enum { NMX_SWE_MEAN = 0, NMX_SWE_MEDIAN, NMX_SWE_MAX, NMX_SWE_MIN, NMX_SWE_VAR, 
 #define NMX_MAX_BANDS 16
 #define NMX_MAX_FILTERS 24
 #define NMX_MAX_SW_COMBOS 48
+#define NMX_MAX_PRE_FILTERS 4
 
 /* Where one feature family writes inside an output row of n_outputs floats:
  *   column = base + ch * ch_stride + a * a_stride + b * b_stride
@@ -169,6 +170,14 @@ typedef struct {
    * raw_window == 0: no resampling (incoming windows have `window` samples). */
   int32_t raw_window;
   double resample_ratio;
+
+  /* preprocessing_filter (processing/filter_preprocessing.py:44-94): up to NMX_MAX_PRE_FILTERS
+   * single FIRs applied one after the other to every incoming window, each as
+   * MNEFilter.filter_data = zero-padded "same" convolution (filter/mne_filter.py:82-128), BEFORE
+   * the notch (processing/data_preprocessor.py:9-15).  Taps designed on the host, odd length. */
+  int32_t n_pre_filters;
+  const double* pre_taps[4];
+  int32_t n_pre_taps[4];
 } nmx_plan_desc;
 
 typedef struct nmx_plan nmx_plan;

@@ -788,6 +788,36 @@ def reref_matrix(names, rereference, used, types, status) -> np.ndarray | None:
     return R[np.ix_(good, good)]
 
 
+class PreprocessingFilter:
+    """processing/filter_preprocessing.py:44-94: single-range MNEFilter objects applied one after
+    the other (each: zero-padded 'same' convolution, filter/mne_filter.py:82-128)."""
+
+    def __init__(self, settings, sfreq, taps=None) -> None:
+        pf = settings.preprocessing_filter
+        if taps is None:
+            enabled = pf.get_enabled()
+            ranges = [tuple(getattr(pf, f"{n}_settings")) for n in enabled
+                      if n not in ("lowpass_filter", "highpass_filter")]
+            if "lowpass_filter" in enabled:
+                ranges.append((None, pf.lowpass_filter_cutoff_hz))
+            if "highpass_filter" in enabled:
+                ranges.append((pf.highpass_filter_cutoff_hz, None))
+            taps = []
+            for lo, hi in ranges:
+                try:
+                    h = mne_restated.create_filter(None, sfreq, lo, hi, filter_length=int(sfreq - 1),
+                                                   l_trans_bandwidth=4, h_trans_bandwidth=4)
+                except ValueError:
+                    h = mne_restated.create_filter(None, sfreq, lo, hi)
+                taps.append(h)
+        self.taps = list(taps)
+
+    def process(self, data):
+        for h in self.taps:
+            data = fir_bank_apply(data, np.atleast_2d(h))[:, 0, :]
+        return data
+
+
 class Resampler:
     """processing/resample.py:19-60 (ratio 1 is a no-op; other ratios are parity-unpinned)."""
 

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 3
+NMX_ABI_VERSION = 4
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -66,6 +66,7 @@ class PlanDesc(C.Structure):
         ("bp_kalman_mask", C.c_uint32),
         ("kalman_Tp", C.c_double), ("kalman_sigma_w", C.c_double), ("kalman_sigma_v", C.c_double),
         ("raw_window", C.c_int32), ("resample_ratio", C.c_double),
+        ("n_pre_filters", C.c_int32), ("pre_taps", C.POINTER(C.c_double) * 4), ("n_pre_taps", C.c_int32 * 4),
     ]
 
 

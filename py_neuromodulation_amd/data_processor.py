@@ -51,6 +51,7 @@ class DataProcessor:
         notch_taps = None
         R = None
         resample_to = None
+        pre_taps = None
         for name in st.preprocessing:
             if name not in PREPROCESSOR_ORDER:
                 raise ValueError(f"Invalid preprocessing method '{name}'. Must be one of {PREPROCESSOR_ORDER}")
@@ -61,6 +62,8 @@ class DataProcessor:
                 if line_noise is None:
                     raise ValueError("Either line_noise or freqs must be defined if notch_filter is activated.")
                 notch_taps = fir_design.notch_bank(self.sfreq_raw, line_noise)
+            elif name == "preprocessing_filter":
+                pre_taps = fir_design.preprocessing_filter_bank(st.preprocessing_filter, self.sfreq_raw)
             elif name == "raw_resampling":
                 new_rate = float(st.raw_resampling_settings.resample_freq_hz)
                 if float(new_rate / self.sfreq_raw) != 1.0:
@@ -101,11 +104,12 @@ class DataProcessor:
             names = [self.ch_names_used[i] for i in subset]
         if resample_to is None:
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
-                                        device=device, window=window, lib=lib, dry_run=dry_run)
+                                        device=device, window=window, lib=lib, dry_run=dry_run,
+                                        pre_taps=pre_taps)
         else:   # `window` counts RAW samples (the generator cuts raw data)
             self.engine = HotPathEngine(st, names, resample_to, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, lib=lib, dry_run=dry_run,
-                                        resample_from=self.sfreq_raw, raw_window=window)
+                                        resample_from=self.sfreq_raw, raw_window=window, pre_taps=pre_taps)
             self.sfreq_raw = resample_to
         self.keys = self.engine.keys
         self.feature_normalizer = None

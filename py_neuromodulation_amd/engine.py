@@ -51,7 +51,8 @@ class HotPathEngine:
                  lib: _lib.NmxLibrary | None = None, bank_taps: np.ndarray | None = None,
                  sharpwave_taps: Sequence[np.ndarray] | None = None,
                  window: int | None = None, dry_run: bool = False,
-                 resample_from: float | None = None, raw_window: int | None = None) -> None:
+                 resample_from: float | None = None, raw_window: int | None = None,
+                 pre_taps: Sequence[np.ndarray] | None = None) -> None:
         """``sfreq`` is the rate the features see.  ``resample_from`` = sampling rate of the incoming
         windows when it differs (raw_resampling, processing/resample.py:19-60): incoming windows then
         hold ``raw_window`` samples (default int(segment_length_features_ms / 1000 * resample_from)) and
@@ -80,6 +81,9 @@ class HotPathEngine:
             if window is None:
                 self.W = int(round(self.resample_ratio * self.W_in))   # mne.filter.resample: final_len
         self._keep: list = []   # arrays referenced by the C struct
+        self._pre_taps = [np.asarray(t, dtype=np.float64) for t in (pre_taps or [])]
+        if len(self._pre_taps) > 4:
+            raise ValueError("at most 4 preprocessing_filter stages")
         self.keys: list[str] = []
         self.desc = self._build(ref_matrix, notch_taps, device, bank_taps, sharpwave_taps)
         self.n_outputs = len(self.keys)
@@ -142,6 +146,10 @@ class HotPathEngine:
         if self.resample_ratio:
             d.raw_window = int(self.W_in)
             d.resample_ratio = float(self.resample_ratio)
+        d.n_pre_filters = len(self._pre_taps)       # preprocessing_filter stages, before the notch
+        for i, t in enumerate(self._pre_taps):
+            d.pre_taps[i] = self._dptr(t)
+            d.n_pre_taps[i] = len(t)
         d.sfreq = sfreq
         d.feat_hz = float(st.sampling_rate_features_hz)
         bands = [(name, (float(fr[0]), float(fr[1]))) for name, fr in st.frequency_ranges_hz.items()]

@@ -10,6 +10,8 @@ the hot path:
                                                    transitions, auto-length fallback)
   auto_band_pass   features/sharpwaves.py:127-143 (auto transitions and length)
   notch_bank       filter/notch_filter.py:25-76   (band-stops at k * line_noise)
+  fir_filter / preprocessing_filter_bank   processing/filter_preprocessing.py:44-79 (single low-,
+                                                   high-, band-pass or band-stop filters)
 """
 
 from __future__ import annotations
@@ -138,3 +140,100 @@ def notch_bank(sfreq: float, line_noise: float, notch_width: float = 3.0,
     if np.any(np.abs(np.diff(gains, 2)) > 1):
         raise ValueError("Stop bands are not sufficiently separated.")
     return _sections(_odd(int(sfreq - 1)), edges / nyq, gains)
+
+
+def fir_filter(sfreq: float, l_freq: float | None, h_freq: float | None, filter_length: int | None = None,
+               l_trans: float | None = None, h_trans: float | None = None) -> np.ndarray:
+    """One zero-phase hamming FIR the way ``mne.filter.create_filter`` picks the response:
+    ``l_freq is None`` low-pass, ``h_freq is None`` high-pass, ``l_freq < h_freq`` band-pass,
+    ``l_freq > h_freq`` band-stop.  ``None`` transitions / length mean MNE's "auto"."""
+    sfreq = float(sfreq)
+    nyq = sfreq / 2.0
+    if l_freq is not None and float(l_freq) == 0.0:
+        l_freq = None
+    if l_freq is None and h_freq is None:
+        raise ValueError("all-pass filter requested")
+    if h_freq is not None and h_freq > nyq:
+        raise ValueError(f"h_freq ({h_freq}) must be below the Nyquist frequency {nyq}")
+
+    def auto_l(f):
+        return min(max(0.25 * f, 2.0), f)
+
+    def auto_h(f):
+        return min(max(0.25 * f, 2.0), nyq - f)
+
+    if l_freq is None:                       # low-pass
+        ht = auto_h(h_freq) if h_trans is None else float(h_trans)
+        if ht <= 0:
+            raise ValueError("transition bandwidths must be positive")
+        f_s = h_freq + ht
+        if f_s > nyq:
+            raise ValueError("Effective stop frequency too high")
+        n = _auto_length(sfreq, ht) if filter_length is None else _odd(int(filter_length))
+        edges, gains = [0.0, h_freq, f_s], [1, 1, 0]
+        if f_s != nyq:
+            edges.append(nyq)
+            gains.append(0)
+    elif h_freq is None:                     # high-pass
+        lt = auto_l(l_freq) if l_trans is None else float(l_trans)
+        if lt <= 0:
+            raise ValueError("transition bandwidths must be positive")
+        f_s = l_freq - lt
+        if f_s < 0:
+            raise ValueError("Filter specification invalid: lower stop frequency negative")
+        n = _auto_length(sfreq, lt) if filter_length is None else _odd(int(filter_length))
+        edges, gains = [f_s, l_freq, nyq], [0, 1, 1]
+        if f_s != 0:
+            edges.insert(0, 0.0)
+            gains.insert(0, 0)
+    elif l_freq < h_freq:                    # band-pass
+        return band_pass(sfreq, l_freq, h_freq, filter_length, l_trans, h_trans)
+    else:                                    # band-stop: pass below h_freq and above l_freq
+        lo, hi = float(h_freq), float(l_freq)
+        lt = auto_l(lo) if h_trans is None else float(h_trans)   # MNE swaps the roles (reverse=True)
+        ht = auto_h(hi) if l_trans is None else float(l_trans)
+        if lt <= 0 or ht <= 0:
+            raise ValueError("transition bandwidths must be positive")
+        if lo < 0:
+            raise ValueError("Filter specification invalid: lower stop frequency negative")
+        if hi > nyq:
+            raise ValueError("Effective band-stop frequency is too high")
+        n = _auto_length(sfreq, lt, ht) if filter_length is None else _odd(int(filter_length))
+        edges, gains = [lo, lo + lt, hi - ht, hi], [1, 0, 0, 1]
+        if edges[0] != 0:
+            edges.insert(0, 0.0)
+            gains.insert(0, 1)
+        if edges[-1] != nyq:
+            edges.append(nyq)
+            gains.append(1)
+    return _sections(n, np.asarray(edges, dtype=float) / nyq, np.asarray(gains))
+
+
+def mne_filter_single(sfreq: float, l_freq, h_freq, filter_length: float | None = None) -> np.ndarray:
+    """MNEFilter.__init__ for ONE range (filter/mne_filter.py:51-76): 4 Hz transitions and
+    int(filter_length) taps; on ValueError the same range with MNE's automatic transitions/length."""
+    if filter_length is None:
+        filter_length = sfreq - 1
+    try:
+        return fir_filter(sfreq, l_freq, h_freq, int(filter_length), 4.0, 4.0)
+    except ValueError:
+        return fir_filter(sfreq, l_freq, h_freq)
+
+
+def preprocessing_filter_bank(pf_settings, sfreq: float) -> list[np.ndarray]:
+    """Taps of PreprocessingFilter in application order (processing/filter_preprocessing.py:50-79):
+    the enabled ones of (bandstop_filter, bandpass_filter) in selector order -- their [lo, hi] range is
+    handed to create_filter as (l_freq, h_freq), so the default "bandstop" [100, 160] is in fact a
+    band-PASS, as in the reference -- then the low-pass, then the high-pass."""
+    enabled = pf_settings.get_enabled()
+    taps = []
+    for name in enabled:
+        if name in ("lowpass_filter", "highpass_filter"):
+            continue
+        rng = getattr(pf_settings, f"{name}_settings")
+        taps.append(mne_filter_single(sfreq, float(rng[0]), float(rng[1])))
+    if "lowpass_filter" in enabled:
+        taps.append(mne_filter_single(sfreq, None, float(pf_settings.lowpass_filter_cutoff_hz)))
+    if "highpass_filter" in enabled:
+        taps.append(mne_filter_single(sfreq, float(pf_settings.highpass_filter_cutoff_hz), None))
+    return taps

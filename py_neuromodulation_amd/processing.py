@@ -2,6 +2,7 @@
 
   NotchFilter   filter/notch_filter.py:9-93     process(data[C, W]) -> data   (HIP FIR kernel)
   ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
+  PreprocessingFilter processing/filter_preprocessing.py:44-94  chained single FIRs (HIP FIR kernel)
   Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
                                                 algorithm, parity unpinned); identity at ratio 1
   FeatureNormalizer processing/normalization.py:31-111 -- host NumPy version (all methods incl.
@@ -20,9 +21,13 @@ from .engine import HotPathEngine
 from .settings import NMSettings
 
 
-def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, resample_to=None):
+def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, resample_to=None,
+                pre_taps=None):
     s = NMSettings.get_default()
     C = C_out if C_out is not None else C_in
+    if pre_taps is not None:
+        return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
+                             pre_taps=pre_taps, window=W)
     if resample_to is not None:   # W raw samples at `sfreq` -> round(ratio * W) at `resample_to`
         return HotPathEngine(s, [f"c{i}" for i in range(C)], resample_to, features=["return_raw"],
                              notch_taps=notch_taps, ref_matrix=ref_matrix, resample_from=sfreq,
@@ -67,6 +72,24 @@ class ReReferencer:
             self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq,
                                                     ref_matrix=self.ref_matrix,
                                                     C_out=self.ref_matrix.shape[0])
+        return self._engines[data.shape].preprocess_window(data)
+
+
+class PreprocessingFilter:
+    """processing/filter_preprocessing.py:44-94: the enabled band / low- / high-pass FIRs applied one
+    after the other to the window (zero-padded "same" convolutions) on the device."""
+
+    def __init__(self, settings, sfreq: float) -> None:
+        self.sfreq = float(sfreq)
+        self.taps = fir_design.preprocessing_filter_bank(settings.preprocessing_filter, self.sfreq)
+        self._engines: dict = {}
+
+    def process(self, data: np.ndarray) -> np.ndarray:
+        if not self.taps:
+            return data
+        data = np.asarray(data, dtype=np.float64)
+        if data.shape not in self._engines:
+            self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq, pre_taps=self.taps)
         return self._engines[data.shape].preprocess_window(data)
 
 

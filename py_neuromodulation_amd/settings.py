@@ -165,6 +165,11 @@ def _default_dict() -> dict:
         "raw_resampling_settings": {"resample_freq_hz": 1000},
         "raw_normalization_settings": {"normalization_time_s": 30,
                                        "normalization_method": "zscore", "clip": 3},
+        "preprocessing_filter": {"bandstop_filter": True, "bandpass_filter": True,
+                                 "lowpass_filter": True, "highpass_filter": True,
+                                 "bandstop_filter_settings": [100, 160],
+                                 "bandpass_filter_settings": [3, 200],
+                                 "lowpass_filter_cutoff_hz": 200, "highpass_filter_cutoff_hz": 3},
         "postprocessing": {"feature_normalization": True, "project_cortex": False,
                            "project_subcortex": False},
         "feature_normalization_settings": {"normalization_time_s": 30,
@@ -199,7 +204,7 @@ def _default_dict() -> dict:
     }
 
 
-_SELECTOR_KEYS = {"features", "postprocessing", "bandpower_features", "burst_features",
+_SELECTOR_KEYS = {"features", "postprocessing", "preprocessing_filter", "bandpower_features", "burst_features",
                   "sharpwave_features"}
 
 
@@ -218,6 +223,9 @@ def _merge(base: dict, over: dict) -> dict:
 def _build(key: str, v: Any) -> Any:
     if key == "frequency_ranges_hz":
         return {str(k).replace(" ", "_"): FrequencyRange(x) for k, x in v.items()}
+    if key in ("bandstop_filter_settings", "bandpass_filter_settings") and (
+            isinstance(v, (list, tuple, FrequencyRange)) or (isinstance(v, dict) and "frequency_low_hz" in v)):
+        return FrequencyRange(v)   # preprocessing_filter ranges (the BandPower settings dict shares a name)
     if key == "filter_ranges_hz":
         return [FrequencyRange(x) for x in v]
     if key == "segment_lengths_ms":

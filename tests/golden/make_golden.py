@@ -341,12 +341,39 @@ def case_bandpower_kalman():
     print("bandpower_kalman", out["values"].shape)
 
 
+def case_preprocessing_filter():
+    """PreprocessingFilter.process (processing/filter_preprocessing.py:44-94) with the default four
+    filters and with a subset: reference glue (MNEFilter tiling + fftconvolve 'same', chained) over
+    the restated tap design; the taps are stored next to the output."""
+    sfreq = 1000
+    out = {"sfreq": sfreq}
+    for tag, mutate in (("all", lambda s: None),
+                        ("two", lambda s: (setattr(s.preprocessing_filter, "bandstop_filter", False),
+                                           setattr(s.preprocessing_filter, "highpass_filter", False)))):
+        s = nm.NMSettings.get_default()
+        mutate(s)
+        s.preprocessing = ["preprocessing_filter"]
+        s = s.validate()
+        pf = nm.processing.PreprocessingFilter(s, sfreq)
+        x = synth(3, 1000, sfreq, 31 + len(tag))
+        y = pf.process(x)
+        out[f"{tag}_settings_json"] = dump(s)
+        out[f"{tag}_x"] = x
+        out[f"{tag}_y"] = y
+        out[f"{tag}_n_filters"] = len(pf.filters)
+        for i, f in enumerate(pf.filters):
+            out[f"{tag}_taps_{i}"] = f.filter_bank[0]
+    np.savez_compressed(HERE / "preprocessing_filter.npz", **out)
+    print("preprocessing_filter", {k: np.shape(v) for k, v in out.items() if k.endswith("_y")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
             globals()["case_" + name]()
         sys.exit(0)
     case_bandpower_kalman()
+    case_preprocessing_filter()
     case_schedule()
     case_feat_1k()
     case_feat_2k()

@@ -572,3 +572,53 @@ def case_resampler(lib):
         n_bad, rep, _ = parity.compare(names, df.iloc[i][names].to_numpy(dtype=np.float64),
                                        [want[k] for k in names], s, 1000.0, float(np.abs(xs).max()), 1000)
         assert n_bad == 0, f"stream hop {i}\n{rep}"
+
+
+def case_preprocessing_filter(lib):
+    """PreprocessingFilter.process vs the reference golden (chained zero-padded FIRs, default four
+    stages incl. 1651-tap auto-length ones, and a two-stage subset) and inside the pipeline in front
+    of the notch.  Tolerance: fp32 FFT convolution of amplitude-A data, 2e-5 * A absolute per stage."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings, fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.processing import PreprocessingFilter
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("preprocessing_filter")
+    sfreq = float(g["sfreq"])
+    for tag in ("all", "two"):
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        x, want = g[f"{tag}_x"], g[f"{tag}_y"]
+        pf = PreprocessingFilter(s, sfreq)
+        assert len(pf.taps) == int(g[f"{tag}_n_filters"])
+        pf._engines[x.shape] = HotPathEngine(NMSettings.get_default(), [f"c{i}" for i in range(x.shape[0])], sfreq,
+                                             features=["return_raw"], pre_taps=pf.taps, window=x.shape[1], lib=lib)
+        got = pf.process(x)
+        amp = np.abs(x).max()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * amp * len(pf.taps), err_msg=tag)
+    # in the pipeline: preprocessing_filter -> notch -> features (batch of hops)
+    s = NMSettings.get_default()
+    for f in s.features.get_enabled():
+        setattr(s.features, f, False)
+    s.features.raw_hjorth = True
+    s.features.linelength = True
+    s.postprocessing.feature_normalization = False
+    rng = np.random.default_rng(5)
+    C, W, T = 2, 1000, 1500
+    t = np.arange(T) / sfreq
+    x = rng.standard_normal((C, T)) * 20 + 30 * np.sin(2 * np.pi * 50 * t) + 40 * np.sin(2 * np.pi * 130 * t) + 200
+    taps = fir_design.preprocessing_filter_bank(s.preprocessing_filter, sfreq)
+    notch = fir_design.notch_bank(sfreq, 50)
+    eng = HotPathEngine(s, ["a", "b"], sfreq, notch_taps=notch, pre_taps=taps, lib=lib)
+    starts = np.arange(6) * 100
+    got = eng.process_batch(x, starts)
+    opf, onf = orc.PreprocessingFilter(s, sfreq, taps=taps), orc.NotchFilter(sfreq, 50, taps=notch)
+    for i, a in enumerate(starts):
+        y = onf.process(opf.process(x[:, a:a + W]))
+        want = {}
+        for f in (orc.Hjorth(s, ["a", "b"], sfreq), orc.LineLength(s, ["a", "b"], sfreq)):
+            want.update(f.calc_feature(y))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq,
+                                       float(np.abs(x).max()), W)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()

@@ -233,3 +233,7 @@ def test_bandpower_kalman_sequence(gpu_lib):
 
 def test_resampler(gpu_lib):
     pc.case_resampler(gpu_lib)
+
+
+def test_preprocessing_filter(gpu_lib):
+    pc.case_preprocessing_filter(gpu_lib)

@@ -92,3 +92,7 @@ def test_bandpower_kalman_sequence(emu_lib):
 
 def test_resampler(emu_lib):
     pc.case_resampler(emu_lib)
+
+
+def test_preprocessing_filter(emu_lib):
+    pc.case_preprocessing_filter(emu_lib)
