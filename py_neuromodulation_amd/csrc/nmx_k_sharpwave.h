@@ -46,6 +46,7 @@ struct NmxSharpArgs {
   NmxCols np_cols;    // num_peaks (between mode), a = filter
   int has_num_peaks;
   int dbg_skip;          // experiment switch (0 in production)
+  int dense_ok;          // distances <= 10 and only mean / max / min estimators: register-resident path
   int fast_estimators;   // all pairs are mean/max/min of loop-free per-trough quantities
   // LDS carve (float offsets): z[W] | emax,emin,selP,selT,lf,rt (u16[pm]) | st (u8[2 pm]) | vals | res | red
   int off_z, off_emax, off_emin, off_selp, off_selt, off_lf, off_rt, off_st, off_vals, off_res, off_red;
@@ -255,6 +256,114 @@ NMX_DEV void nmx_select2(const float* z, NmxSelProb* P) {
   NMX_SYNC();
 }
 
+// ---- dense (register-resident) selection + pairing ------------------------------------------------
+// When a window has at most 64 maxima and 64 minima (the usual case: 5-80 Hz content at 1 kHz gives
+// ~60) lane j OWNS extremum j of each kind: neighbours come from cross-lane shuffles, the keep /
+// undecided sets of the distance suppression are 64-bit ballots, ranks are mbcnt -- no loops over
+// lists, no per-element exec-mask branches (the generic list code below cost ~2 300 VALU + 2 000
+// SALU instructions per item and the kernel is instruction-issue bound).  Same-kind extrema are
+// >= 2 samples apart, so with distance <= 10 only the 4 nearest neighbours on each side can matter.
+#ifndef NMX_HOST_EMU
+NMX_DEV unsigned nmx_win_left(unsigned long long K, int lane) {   // bit (4 - d) <- lane - d, d = 1..4
+  return (unsigned)(lane >= 4 ? (K >> (lane - 4)) : (K << (4 - lane))) & 0xFu;
+}
+NMX_DEV unsigned nmx_win_right(unsigned long long K, int lane) {  // bit (d - 1) <- lane + d
+  return lane < 63 ? (unsigned)(K >> (lane + 1)) & 0xFu : 0u;
+}
+// SciPy _select_by_peak_distance as a fixed point: an extremum is removed iff a higher-priority
+// neighbour inside the distance is kept, kept iff all of them are removed (hl / hr: those neighbours)
+NMX_DEV unsigned long long nmx_dense_fixpoint(bool valid, unsigned hl, unsigned hr, int lane) {
+  int s = !valid ? 2 : ((hl | hr) == 0u ? 1 : 0);
+  for (;;) {
+    const unsigned long long K = __ballot(s == 1), U = __ballot(s == 0);
+    if (U == 0ull) return K;
+    const unsigned kl = nmx_win_left(K, lane), kr = nmx_win_right(K, lane);
+    const unsigned ul = nmx_win_left(U, lane), ur = nmx_win_right(U, lane);
+    if (s == 0) {
+      const bool removed = ((kl & hl) | (kr & hr)) != 0u;
+      const bool wait = ((ul & hl) | (ur & hr)) != 0u;
+      s = removed ? 2 : (wait ? 0 : 1);
+    }
+  }
+}
+
+struct NmxDenseSel {
+  int pmax, pmin;             // this lane's maximum / minimum position
+  // keep masks: [0] maxima @ distance_peaks, [1] minima @ distance_troughs  (polarity 0)
+  //             [2] minima @ distance_peaks, [3] maxima @ distance_troughs  (polarity 1)
+  unsigned long long K[4];
+};
+
+NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16* emin, int n_max, int n_min,
+                              int dp, int dt, NmxDenseSel& D) {
+  const int lane = NMX_TID;
+  const bool vmax = lane < n_max, vmin = lane < n_min;
+  const int pmax = vmax ? (int)emax[lane] : 0, pmin = vmin ? (int)emin[lane] : 0;
+  const float qmax = vmax ? z[pmax] : 0.f, qmin = vmin ? -z[pmin] : 0.f;   // priorities (heights)
+  const int md = dp > dt ? dp : dt;
+  unsigned hl0 = 0, hr0 = 0, hl1 = 0, hr1 = 0, hl2 = 0, hr2 = 0, hl3 = 0, hr3 = 0;
+#pragma unroll
+  for (int d = 1; d <= 4; ++d) {
+    const int aL = __shfl_up(pmax, d), aR = __shfl_down(pmax, d), bL = __shfl_up(pmin, d), bR = __shfl_down(pmin, d);
+    const bool maxL = vmax && lane >= d, maxR = vmax && lane + d < n_max;
+    const bool minL = vmin && lane >= d, minR = vmin && lane + d < n_min;
+    const int gaL = pmax - aL, gaR = aR - pmax, gbL = pmin - bL, gbR = bR - pmin;
+    if (!__any((maxL && gaL < md) || (maxR && gaR < md) || (minL && gbL < md) || (minR && gbR < md))) break;
+    const float qaL = __shfl_up(qmax, d), qaR = __shfl_down(qmax, d), qbL = __shfl_up(qmin, d), qbR = __shfl_down(qmin, d);
+    const unsigned bl = 1u << (4 - d), br = 1u << (d - 1);
+    // strictly higher on the left, higher-or-equal on the right: equal heights -> the later one wins
+    const bool hAL = maxL && qaL > qmax, hAR = maxR && qaR >= qmax;
+    const bool hBL = minL && qbL > qmin, hBR = minR && qbR >= qmin;
+    hl0 |= (hAL && gaL < dp) ? bl : 0u; hr0 |= (hAR && gaR < dp) ? br : 0u;
+    hl3 |= (hAL && gaL < dt) ? bl : 0u; hr3 |= (hAR && gaR < dt) ? br : 0u;
+    hl1 |= (hBL && gbL < dt) ? bl : 0u; hr1 |= (hBR && gbR < dt) ? br : 0u;
+    hl2 |= (hBL && gbL < dp) ? bl : 0u; hr2 |= (hBR && gbR < dp) ? br : 0u;
+  }
+  D.pmax = pmax; D.pmin = pmin;
+  D.K[0] = nmx_dense_fixpoint(vmax, hl0, hr0, lane);
+  D.K[1] = nmx_dense_fixpoint(vmin, hl1, hr1, lane);
+  D.K[2] = nmx_dense_fixpoint(vmin, hl2, hr2, lane);
+  D.K[3] = nmx_dense_fixpoint(vmax, hl3, hr3, lane);
+}
+
+// compaction of the kept peaks / troughs into selP / selT, pairing (sharpwaves.py:347-374) and the
+// (left, right) peak lists; returns the same quantities as the generic code path
+NMX_DEV void nmx_dense_pair(unsigned long long KP, int ppos, unsigned long long KT, int tpos,
+                            nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
+                            int* nTr_out, int* n_pairs_out, int* first_valid_out, int* nT_out) {
+  const int lane = NMX_TID;
+  const unsigned lane_lo = (unsigned)lane;
+  (void)lane_lo;
+  const int rP = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(KP >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)KP, 0u));
+  const int rT = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(KT >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)KT, 0u));
+  if ((KP >> lane) & 1ull) selP[rP] = (nmx_u16)ppos;
+  if ((KT >> lane) & 1ull) selT[rT] = (nmx_u16)tpos;
+  NMX_SYNC();
+  const int nPk = __popcll(KP), nTr = __popcll(KT);
+  int lo = 0;   // number of kept peaks before this lane's trough (nPk <= 64: 7 bisection steps)
+  const bool has_t = lane < nTr;
+  const int t = has_t ? (int)selT[lane] : 0;
+#pragma unroll
+  for (int step = 64; step > 0; step >>= 1) {
+    const int idx = lo + step;
+    lo = (idx <= nPk && (int)selP[idx <= nPk ? idx - 1 : 0] < t) ? idx : lo;
+  }
+  const unsigned long long L0 = __ballot(has_t && lo == 0), Vm = __ballot(has_t && lo > 0 && lo < nPk);
+  const int first_valid = __popcll(L0), n_pairs = __popcll(Vm);
+  const int lastv = Vm ? 63 - __clzll((long long)Vm) : 0;
+  const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
+  const int src = first_valid + lane;
+  const int lo_p = __shfl(lo, src < 64 ? src : 63);
+  if (lane < n_pairs) {
+    rt[lane] = selP[lo_p];
+    lf[lane] = selP[lo_p - 1];
+  }
+  NMX_SYNC();
+  *nTr_out = nTr; *n_pairs_out = n_pairs; *first_valid_out = first_valid;
+  *nT_out = last_excl > first_valid ? last_excl - first_valid : 0;
+}
+#endif
+
 // ---- estimators --------------------------------------------------------------------------------
 NMX_DEV float nmx_sw_estimate(int est, const float* v, int n, float* red) {
   if (n == 0) return 0.f;  // sharpwaves.py:294: empty -> 0
@@ -303,21 +412,40 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
+#ifndef NMX_HOST_EMU
+  // wave-uniform: the register-resident path applies (else the generic list code below)
+  const bool dense = A.dense_ok && n_max <= 64 && n_min <= 64 && !(A.dbg_skip & 1);
+  NmxDenseSel D;
+  if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
+#endif
   for (int pol = 0; pol < 2; ++pol) {
     if ((pol == 0 && !A.est_peaks) || (pol == 1 && !A.est_troughs)) continue;
     const float sgn = pol == 0 ? 1.f : -1.f;   // "Trough" analysis runs on -y
     // peaks of sgn*z with distance_peaks, troughs (= peaks of -sgn*z) with distance_troughs
+    int nTr = 0, n_pairs = 0, first_valid = 0, nT = 0;
+#ifndef NMX_HOST_EMU
+    if (dense) {
+      if (A.dbg_skip & 4) { ++pol_slot; continue; }
+      nmx_dense_pair(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin,
+                     pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax,
+                     selP, selT, lf, rt, &nTr, &n_pairs, &first_valid, &nT);
+    } else
+#endif
+    {
     NmxSelProb P[2];
     P[0].pos = pol == 0 ? emax : emin; P[0].n = pol == 0 ? n_max : n_min; P[0].sgn = sgn;
     P[0].dist = A.dist_peaks; P[0].st = st; P[0].out = selP; P[0].n_out = 0;
     P[1].pos = pol == 0 ? emin : emax; P[1].n = pol == 0 ? n_min : n_max; P[1].sgn = -sgn;
     P[1].dist = A.dist_troughs; P[1].st = st + A.pm; P[1].out = selT; P[1].n_out = 0;
     if (A.dbg_skip & 1) { P[0].n_out = 0; P[1].n_out = 0; } else nmx_select2(z, P);
-    const int nPk = P[0].n_out, nTr = P[1].n_out;
+    if (A.dbg_skip & 4) { ++pol_slot; continue; }
+    const int nPk = P[0].n_out;
+    nTr = P[1].n_out;
     const nmx_u16* pk = selP;
     const nmx_u16* tr = selT;
     // pairing (sharpwaves.py:347-374): ptr = first peak at or after the trough
-    int n_leftinv = 0, lastv = 0, n_pairs = 0;
+    int n_leftinv = 0, lastv = 0;
+    n_pairs = 0;
     for (int i = NMX_TID; i < nTr; i += NMX_NT) {
       const int t = tr[i];
       int lo = 0;   // number of peaks before t: branch-free bisection (nPk <= 1024)
@@ -337,10 +465,9 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
       lastv = (int)nmx_block_max((float)lastv, red);
     }
     NMX_SYNC();
-    const int first_valid = n_leftinv;
+    first_valid = n_leftinv;
     const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
-    const int nT = last_excl > first_valid ? last_excl - first_valid : 0;
-    const nmx_u16* trv = tr + first_valid;  // trough list after the reference's slice
+    nT = last_excl > first_valid ? last_excl - first_valid : 0;
     // pointer -> (left, right) peak positions; rt first (lf[] holds the pointers)
     for (int p = NMX_TID; p < n_pairs; p += NMX_NT) rt[p] = pk[lf[first_valid + p]];
     NMX_SYNC();
@@ -360,6 +487,8 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
 #endif
     }
     NMX_SYNC();
+    }
+    const nmx_u16* trv = selT + first_valid;  // trough list after the reference's slice
     const int nPT = (n_pairs == nT) ? n_pairs : 0;  // arrays that broadcast pairs with troughs
     if (NMX_TID == 0) res[2 * A.n_combos + pol] = (float)nT;
 #ifndef NMX_HOST_EMU

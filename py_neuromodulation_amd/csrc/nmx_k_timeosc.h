@@ -27,6 +27,11 @@ NMX_DEV float nmx_var(int n, float* red, F f) {
   return nmx_block_sum(q, red) / (float)n;
 }
 
+// radix-10 static plans (500 = 10 10 5: three LDS passes instead of four) measured slower here at
+// 128 threads/item (3.8 vs 3.4 ms) and equal at 64: off
+#ifndef NMX_TIMEOSC_R10
+#define NMX_TIMEOSC_R10 false
+#endif
 NMX_DEV float nmx_nan_to_num(float v) { return nmx_clean(v); }
 // band-pass activity cell: nan_to_num'd (bandpower.py:197) unless a Kalman scan follows, which needs
 // the raw value (the reference filters before nan_to_num, bandpower.py:188-197)
@@ -118,7 +123,7 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
 // real transform of the packed / windowed segment already sitting in `bufB` (as n/2 complex,
 // or n complex with zero imaginary part when O.complex_full); returns pointer to Z
 NMX_DEV float2* nmx_osc_fft(const NmxOsc& O, float2* bufA, float2* bufB) {
-  return nmx_fft_auto<-1>(O.fft, bufB, bufA, bufB);
+  return nmx_fft_auto<-1, NMX_TIMEOSC_R10>(O.fft, bufB, bufA, bufB);
 }
 
 NMX_DEV float2 nmx_osc_bin(const NmxOsc& O, const float2* Z, int k) {
