@@ -50,6 +50,7 @@ struct NmxBankW64Args {
   const float* Hs[NMX_MAX_FILTERS_DEV];   // A_k = (a + b) - (a - b) sin(th_k)
   const float* Hd[NMX_MAX_FILTERS_DEV];   // B_k = (a - b) cos(th_k)
   float* yb_out;          // burst bands: filtered series [n_windows][C][Bb][W] (Hilbert kernel input)
+  const float* twl;       // NMX_W64_TWL_FLOATS floats: per-lane twiddles of passes B and C (persistent kernel)
   int off_Z, off_X, off_red, lds_floats;
 };
 
@@ -122,36 +123,8 @@ NMX_UNROLL
 #undef NMX_SWAP
 }
 
-// per-lane twiddle registers (forward sign; the inverse conjugates on the fly).  Only a few
-// exact table values are kept; the rest are products with compile-time constants or of at most
-// three table values (<= 3 ulp), which keeps the kernel at ~2 waves/SIMD worth of VGPRs.
-struct NmxW64Tw {
-  nmx_c2 b1, b2, b4, b8;  // pass B: exp(-2 pi i r k / 256), k = lane % 16, r = 1, 2, 4, 8
-  nmx_c2 c1, c2, c3;      // pass C: exp(-2 pi i r lane / 1024), r = 1, 2, 3
-};
-
-NMX_DEV void nmx_w64_load_tw(NmxW64Tw& T, const NmxFft& f, int lane) {
-  const int k = lane & 15;
-  T.b1 = nmx_to_c2(f.tw[4 * k]); T.b2 = nmx_to_c2(f.tw[8 * k]); T.b4 = nmx_to_c2(f.tw[16 * k]);
-  T.b8 = nmx_to_c2(f.tw[(32 * k) & 1023]);
-  T.c1 = nmx_to_c2(f.tw[lane]); T.c2 = nmx_to_c2(f.tw[2 * lane]); T.c3 = nmx_to_c2(f.tw[3 * lane]);
-}
-
 template <int DIR>
 NMX_DEV nmx_c2 nmx_twd(nmx_c2 t) { return DIR > 0 ? nmx_mk2(t.x, -t.y) : t; }
-
-// exp(-2 pi i m / 32), m = 0..15 (split twiddle of point lane + 64 r is s0 * this[r])
-#define NMX_C32(m) nmx_mk2(nmx_c32_re[m], nmx_c32_im[m])
-static constexpr float nmx_c32_re[16] = {
-    1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
-    0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f, -0.19509032201612825f,
-    -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
-    -0.92387953251128674f, -0.98078528040323043f};
-static constexpr float nmx_c32_im[16] = {
-    -0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f,
-    -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f, -1.0f, -0.98078528040323043f,
-    -0.92387953251128674f, -0.83146961230254524f, -0.70710678118654752f, -0.55557023301960218f,
-    -0.38268343236508977f, -0.19509032201612825f};
 
 // padded physical index of the pass-A output buffer
 NMX_DEV int nmx_w64_pad(int idx) { return idx + (idx >> 4); }
@@ -166,43 +139,54 @@ NMX_DEV void nmx_w64_passA(nmx_c2* v, nmx_c2* X, int lane) {
   NMX_UNROLL
   for (int r = 0; r < 16; ++r) Xo[r] = v[r];
 }
-template <int DIR>
-NMX_DEV void nmx_w64_passB_load(nmx_c2* v, const nmx_c2* X, const NmxW64Tw& T, int lane) {
-  const nmx_c2* Xi = X + lane + (lane >> 4);  // pad(lane + 64 r) = lane + lane/16 + 68 r
-  NMX_UNROLL
-  for (int r = 0; r < 16; ++r) v[r] = Xi[68 * r];
-  {
-    const nmx_c2 w1 = nmx_twd<DIR>(T.b1), w2 = nmx_twd<DIR>(T.b2), w4 = nmx_twd<DIR>(T.b4), w8 = nmx_twd<DIR>(T.b8);
-    const nmx_c2 w3 = nmx_cmul(w1, w2), w5 = nmx_cmul(w1, w4), w6 = nmx_cmul(w2, w4), w9 = nmx_cmul(w1, w8);
-    const nmx_c2 w10 = nmx_cmul(w2, w8), w12 = nmx_cmul(w4, w8);
-    v[1] = nmx_cmul(v[1], w1); v[2] = nmx_cmul(v[2], w2); v[3] = nmx_cmul(v[3], w3);
-    v[4] = nmx_cmul(v[4], w4); v[5] = nmx_cmul(v[5], w5); v[6] = nmx_cmul(v[6], w6);
-    v[7] = nmx_cmul(v[7], nmx_cmul(w3, w4)); v[8] = nmx_cmul(v[8], w8); v[9] = nmx_cmul(v[9], w9);
-    v[10] = nmx_cmul(v[10], w10); v[11] = nmx_cmul(v[11], nmx_cmul(w3, w8)); v[12] = nmx_cmul(v[12], w12);
-    v[13] = nmx_cmul(v[13], nmx_cmul(w5, w8)); v[14] = nmx_cmul(v[14], nmx_cmul(w6, w8));
-    v[15] = nmx_cmul(v[15], nmx_cmul(w3, w12));
-  }
-  nmx_dft16<DIR>(v);
-}
 NMX_DEV void nmx_w64_passB_store(const nmx_c2* v, nmx_c2* X, int lane) {
   nmx_c2* Xo = X + (lane >> 4) * 256 + (lane & 15);
 NMX_UNROLL
   for (int r = 0; r < 16; ++r) Xo[16 * r] = v[r];
 }
+// Twiddles come from a table (LDS copy in the persistent kernels, L2 otherwise): exact values
+// instead of products of a few base values, no twiddle registers, and none of the compile-time
+// constants that v_pk_* instructions cannot take as literals (they spilled the scalar registers).
+//   twB[(r - 1) * 16 + k] = exp(-2 pi i r k / 256),            r = 1..15, k = lane % 16
+//   twC[((r - 1) * 4 + t) * 64 + lane] = exp(-2 pi i r (lane + 64 t) / 1024), r = 1..3, t = 0..3
+#define NMX_W64_TWB_N (15 * 16)
+#define NMX_W64_TWC_N (12 * 64)
+#define NMX_W64_TWL_FLOATS (2 * (NMX_W64_TWB_N + NMX_W64_TWC_N))
 template <int DIR>
-NMX_DEV void nmx_w64_passC(nmx_c2* v, const nmx_c2* X, const NmxW64Tw& T, int lane) {
+NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twB, int lane) {
+  const nmx_c2* Xi = X + lane + (lane >> 4);
+  NMX_UNROLL
+  for (int r = 0; r < 16; ++r) v[r] = Xi[68 * r];
+  const nmx_c2* tw = twB + (lane & 15);
+  NMX_UNROLL
+  for (int r = 1; r < 16; ++r) v[r] = nmx_cmul(v[r], nmx_twd<DIR>(tw[16 * (r - 1)]));
+  nmx_dft16<DIR>(v);
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passC_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
+  const nmx_c2* tw = twC + lane;
 NMX_UNROLL
   for (int t = 0; t < 4; ++t) {
     const nmx_c2* Xi = X + lane;
     nmx_c2 a0 = Xi[64 * t], a1 = Xi[64 * t + 256], a2 = Xi[64 * t + 512], a3 = Xi[64 * t + 768];
-    // exp(-2 pi i r (lane + 64 t) / 1024) = c_r * exp(-2 pi i r t / 16) (compile-time constant)
-    a1 = nmx_cmul(a1, nmx_twd<DIR>(nmx_cmul(T.c1, NMX_C32((2 * t) & 15))));
-    a2 = nmx_cmul(a2, nmx_twd<DIR>(nmx_cmul(T.c2, NMX_C32((4 * t) & 15))));
-    a3 = nmx_cmul(a3, nmx_twd<DIR>(t == 3 ? nmx_cmul(T.c3, nmx_mk2(-nmx_c32_re[2], -nmx_c32_im[2]))
-                                          : nmx_cmul(T.c3, NMX_C32((6 * t) & 15))));
+    a1 = nmx_cmul(a1, nmx_twd<DIR>(tw[64 * t]));
+    a2 = nmx_cmul(a2, nmx_twd<DIR>(tw[64 * (4 + t)]));
+    a3 = nmx_cmul(a3, nmx_twd<DIR>(tw[64 * (8 + t)]));
     nmx_dft4<DIR>(a0, a1, a2, a3);
     v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
   }
+}
+
+// tail-range mask of a register that straddles the band-pass segment boundary: kept out of line so
+// that the compiler does not if-convert it into 16 x 2 lane predicates (64-bit masks that were
+// spilling the scalar register file); it runs for at most two registers per pass
+#ifdef NMX_HOST_EMU
+#define NMX_NOINLINE static
+#else
+#define NMX_NOINLINE __device__ __attribute__((noinline))
+#endif
+NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
+  return nmx_mk2((2 * m >= lo && 2 * m < hi) ? val.x : 0.f, (2 * m + 1 >= lo && 2 * m + 1 < hi) ? val.y : 0.f);
 }
 
 // wave reductions (single-wave workgroup)
@@ -232,8 +216,10 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
                      (A.starts ? nmx_uniform_ll(A.starts[w]) : 0ll);
   nmx_c2 v[NMX_LANES][16];
   nmx_c2 zr[NMX_LANES][16];   // forward transform Z, kept in registers: zr[4 t + r] = Z[l + 64 t + 256 r]
-  NmxW64Tw T[NMX_LANES];
-  NMX_LANE_LOOP { nmx_w64_load_tw(T[NMX_LI], A.fft, l); }
+  // twiddle table: LDS copy in the persistent kernels, the same values from global memory (L2)
+  // otherwise -- every variant computes bit-identical results
+  const nmx_c2* twB = TAB ? (const nmx_c2*)(tab + (size_t)A.n_filters * 2 * NMX_W64_N) : (const nmx_c2*)AA.twl;
+  const nmx_c2* twC = twB + NMX_W64_TWB_N;
 
   // ---- forward: window -> registers (packed complex, lane-consecutive) -> pass A ------------
   if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
@@ -307,13 +293,13 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   NMX_WSYNC();  // (pad_mode 1: everyone has read xs before X is overwritten)
   NMX_LANE_LOOP { nmx_w64_passA<-1>(v[NMX_LI], X, l); }
   NMX_WSYNC();
-  NMX_LANE_LOOP { nmx_w64_passB_load<-1>(v[NMX_LI], X, T[NMX_LI], l); }
+  NMX_LANE_LOOP { nmx_w64_passB_load_lds<-1>(v[NMX_LI], X, twB, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP {
     nmx_c2* vv = v[NMX_LI];
-    nmx_w64_passC<-1>(vv, X, T[NMX_LI], l);
+    nmx_w64_passC_lds<-1>(vv, X, twC, l);
     NMX_UNROLL
     for (int i = 0; i < 16; ++i) zr[NMX_LI][i] = vv[i];
   }
@@ -347,11 +333,11 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       nmx_w64_passA<+1>(vv, X, l);
     }
     NMX_WSYNC();
-    NMX_LANE_LOOP { nmx_w64_passB_load<+1>(v[NMX_LI], X, T[NMX_LI], l); }
+    NMX_LANE_LOOP { nmx_w64_passB_load_lds<+1>(v[NMX_LI], X, twB, l); }
     NMX_WSYNC();
     NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
     NMX_WSYNC();
-    NMX_LANE_LOOP { nmx_w64_passC<+1>(v[NMX_LI], X, T[NMX_LI], l); }
+    NMX_LANE_LOOP { nmx_w64_passC_lds<+1>(v[NMX_LI], X, twC, l); }
     // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
 
     if (F.bp_seglen > 0) {
@@ -372,9 +358,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
             if (2 * mb >= lo && 2 * mb + 127 < hi) {
               acc = nmx_cadd(acc, val);
             } else {
-              const int m = l + mb;
-              acc = nmx_cadd(acc, nmx_mk2((2 * m >= lo && 2 * m < hi) ? val.x : 0.f,
-                                          (2 * m + 1 >= lo && 2 * m + 1 < hi) ? val.y : 0.f));
+              acc = nmx_cadd(acc, nmx_w64_range_mask(val, l + mb, lo, hi));
             }
           }
           part[NMX_LI] = acc.x + acc.y;
@@ -390,10 +374,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
             const int mb = 64 * (i >> 2) + 256 * (i & 3);
             if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
             nmx_c2 d = nmx_csub(v[NMX_LI][i], mean2);
-            if (!(2 * mb >= lo && 2 * mb + 127 < hi)) {
-              const int m = l + mb;
-              d = nmx_mk2((2 * m >= lo && 2 * m < hi) ? d.x : 0.f, (2 * m + 1 >= lo && 2 * m + 1 < hi) ? d.y : 0.f);
-            }
+            if (!(2 * mb >= lo && 2 * mb + 127 < hi)) d = nmx_w64_range_mask(d, l + mb, lo, hi);
             acc = nmx_c2_fma(d, d, acc);
           }
           part[NMX_LI] = acc.x + acc.y;

@@ -5,6 +5,8 @@
 // (NMX_W64_VARIANT, default chosen from measurements -- see DESIGN.md).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "nmx_k_bank_w64.h"
 
 #ifndef NMX_W64_NAME
@@ -34,7 +36,8 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // Persistent variant: one workgroup of `nw` waves per CU; the A/B tables of all filters are
 // staged in LDS once per workgroup (instead of being re-fetched from L2 for every item: 27 % of
 // the kernel's time), then every wave walks its own items with wave-local fences only.
-__global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
                                                                                      int n_items, int x_floats) {
   float* tab = nmx_smem_w64;
   const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
@@ -42,36 +45,77 @@ __global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_bank_w64
     const int fi = i / (2 * n), k = i - fi * 2 * n;
     tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
   }
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
   __syncthreads();
   // readfirstlane: the wave index is wave-uniform, but only this tells the compiler (item-derived
   // addresses, descriptors and branches then live in SGPRs)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-  float* mine = nmx_smem_w64 + tab_floats + wave * x_floats;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
     nmx_bank_w64_item<0, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
 }
 
+// same structure for the notch (odd-reflected window, one filter)
+__global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
+                                                                                                 int n_items, int x_floats) {
+  float* tab = nmx_smem_w64;
+  const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
+  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
+    const int fi = i / (2 * n), k = i - fi * 2 * n;
+    tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
+  }
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
+#pragma nounroll
+  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
+    nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+}
+
 extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu,
                                                        hipStream_t s) {
   // returns 0 when the configuration does not fit the persistent kernel (caller falls back)
-  if (A->b.pad_mode != 0 || (A->b.bp_features & 6u)) return 0;
+  if (A->b.bp_features & 6u) return 0;
+  const bool notch = A->b.pad_mode != 0;
   const int x_floats = A->lds_floats;            // per-wave exchange tile (+ scratch)
   const int tab_floats = A->b.n_filters * 2 * NMX_W64_N;
-  int nw = (160 * 1024 / 4 - tab_floats) / x_floats;
-  if (nw > NMX_W64P_WAVES) nw = NMX_W64P_WAVES;
-  if (nw < NMX_W64P_WAVES) return 0;
+  if (!A->twl) return 0;
+  static int want_bank = 0, notch_on = 1;
+  if (!want_bank) {
+    const char* v = getenv("NMX_W64P_WAVES");
+    want_bank = (v && atoi(v) == 11) ? 11 : 8;
+    const char* u = getenv("NMX_W64P_NOTCH");
+    notch_on = (u && u[0] == '1');   // measured slower than one wave per workgroup (1.58 vs 1.30 ms)
+  }
+  if (notch && !notch_on) return 0;
+  const int want = notch ? NMX_W64P_WAVES : want_bank;
+  int nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats;
+  if (nw > want) nw = want;
+  if (nw < want) return 0;
   static bool once = false;
   if (!once) {
     once = true;
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME),
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const size_t lds = (size_t)(tab_floats + nw * x_floats) * 4;
+  const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + nw * x_floats) * 4;
   int grid = n_cu > 0 ? n_cu : 256;
   if (grid * nw > n_items) grid = (n_items + nw - 1) / nw;
-  hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
-                     n_items, x_floats);
+  if (notch)
+    hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
+                       n_items, x_floats);
+  else if (nw == 11)
+    hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11>, dim3(grid), dim3(64 * nw), lds, s, *A,
+                       n_items, x_floats);
+  else
+    hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8>, dim3(grid), dim3(64 * nw), lds, s, *A,
+                       n_items, x_floats);
   return 1;
 }
 

@@ -19,6 +19,12 @@ in fp32, the reference in float64:
     level (Rayleigh statistics: ~1 bin in 10^4) carries a 1e-5..1e-3 error in log10.  Such
     conditioning outliers (err <= 2e-3, at most 1 per 500 compared log-spectral entries, minimum
     2 per call -- overlapping bands share bins) are tolerated and counted; everything else must meet 1e-5.
+  * sharp-wave decision flips: find_peaks' distance suppression and the trough/peak pairing are
+    discrete decisions on the filtered series; where two extrema inside the distance have heights
+    within fp32 rounding the kept one -- and with it a max/mean over a different trough set -- can
+    differ.  Perturbing the INPUT of the float64 oracle by 3e-7 relative flips such a value itself
+    (seen on 1 of 4096 entries of the 256-channel test: -3.7525 <-> -0.5093).  At most one such
+    outlier per 1000 compared sharp-wave entries is tolerated (none in tests with < 1000 entries).
   * degenerate rows (all-zero / constant input): spectral bins that are exactly 0 in exact
     arithmetic are rounding noise (1e-16 in float64, 1e-8 in fp32); log10 of noise is not
     comparable and those entries are skipped; +-inf / nan_to_num'ed +-huge values must agree in
@@ -81,6 +87,8 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, burst_sla
     worst: dict[str, float] = {}
     n_log = 0
     outliers = []
+    n_sw = 0
+    sw_flips = []
     for k, g, w in zip(keys, got, want):
         g, w = float(g), float(w)
         if skip is not None and skip(k):
@@ -102,10 +110,16 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, burst_sla
         if not ok and is_log and err <= 2e-3:
             outliers.append((k, g, w))   # near-null-bin conditioning (module docstring)
             continue
+        n_sw += fam == "sharpwave"
+        if not ok and fam == "sharpwave":
+            sw_flips.append((k, g, w))   # discrete decision flip (module docstring), bounded below
+            continue
         if not ok:
             bad.append((k, g, w))
     if len(outliers) > max(2, n_log // 500):   # (two overlapping bands can share the one bad bin)
         bad.extend(outliers)
+    if len(sw_flips) > n_sw // 1000:
+        bad.extend(sw_flips)
     report = "\n".join(f"  {k}: got {g!r} want {w!r}" for k, g, w in bad[:15])
     return len(bad), report, worst
 
