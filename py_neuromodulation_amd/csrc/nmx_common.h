@@ -31,6 +31,11 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 // load at the top of every item) and every "block" reduction collapses to its wave part
 #define NMX_TID ((int)(threadIdx.x & 63))
 #define NMX_NT 64
+#elif defined(NMX_BLOCK_FIXED)
+// translation units whose kernels are always launched with NMX_BLOCK_FIXED threads: grid-stride loops
+// over compile-time lengths get compile-time trip counts (less loop control on the scalar unit)
+#define NMX_TID ((int)threadIdx.x)
+#define NMX_NT NMX_BLOCK_FIXED
 #else
 #define NMX_TID ((int)threadIdx.x)
 #define NMX_NT ((int)blockDim.x)
@@ -42,6 +47,8 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #define NMX_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #ifdef NMX_NT_FIXED
 #define NMX_SYNC() NMX_WAVE_FENCE()
+#elif defined(NMX_BLOCK_FIXED)
+#define NMX_SYNC() __syncthreads()
 #else
 #define NMX_SYNC()                                   \
   do {                                               \

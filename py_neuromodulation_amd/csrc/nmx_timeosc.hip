@@ -1,0 +1,44 @@
+// nmx_timeosc.hip -- the time / oscillatory and Hilbert kernels at their default launch width, compiled with
+// -DNMX_BLOCK_FIXED=128: NMX_NT is a constant, so the grid-stride loops of the statically planned
+// transforms and of the fused scans have compile-time trip counts.  nmx_api.hip keeps the
+// run-time-width version for other widths (NMX_NT_TIMEOSC, windows > 1024 samples).
+#ifndef NMX_BLOCK_FIXED
+#error "compile with -DNMX_BLOCK_FIXED=128"
+#endif
+#include <hip/hip_runtime.h>
+
+#include "nmx_k_bank_w64.h"
+#include "nmx_k_timeosc.h"
+
+extern __shared__ __attribute__((aligned(16))) float nmx_smem_to[];
+
+__global__ void __launch_bounds__(NMX_BLOCK_FIXED) nmx_kern_timeosc_fixed(const NmxTimeOscArgs A) {
+  const int item = blockIdx.x;
+  nmx_time_osc_item(A, item / A.n_channels, item % A.n_channels, nmx_smem_to);
+}
+
+__global__ void __launch_bounds__(NMX_BLOCK_FIXED) nmx_kern_hilbert_fixed(const NmxHilbertArgs A) {
+  nmx_hilbert_item(A, (long long)blockIdx.x, nmx_smem_to);
+}
+
+extern "C" int nmx_timeosc_fixed_width(void) { return NMX_BLOCK_FIXED; }
+
+extern "C" void nmx_hilbert_fixed_launch(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)nmx_kern_hilbert_fixed, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  }
+  hipLaunchKernelGGL(nmx_kern_hilbert_fixed, dim3((unsigned)n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+}
+
+extern "C" void nmx_timeosc_fixed_launch(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)nmx_kern_timeosc_fixed, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  }
+  hipLaunchKernelGGL(nmx_kern_timeosc_fixed, dim3(n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+}
