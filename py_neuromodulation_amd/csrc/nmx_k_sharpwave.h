@@ -257,106 +257,184 @@ NMX_DEV void nmx_select2(const float* z, NmxSelProb* P) {
 }
 
 // ---- dense (register-resident) selection + pairing ------------------------------------------------
-// When a window has at most 64 maxima and 64 minima (the usual case: 5-80 Hz content at 1 kHz gives
-// ~60) lane j OWNS extremum j of each kind: neighbours come from cross-lane shuffles, the keep /
-// undecided sets of the distance suppression are 64-bit ballots, ranks are mbcnt -- no loops over
-// lists, no per-element exec-mask branches (the generic list code below cost ~2 300 VALU + 2 000
-// SALU instructions per item and the kernel is instruction-issue bound).  Same-kind extrema are
-// >= 2 samples apart, so with distance <= 10 only the 4 nearest neighbours on each side can matter.
+// When a window has at most 128 maxima and 128 minima (white noise band-limited to 80 Hz at 1 kHz
+// gives ~62 of each) every lane OWNS extremum `lane` (slot 0) and `64 + lane` (slot 1) of each kind:
+// neighbours come from cross-lane rotations, the keep / undecided sets of the distance suppression
+// are pairs of 64-bit ballots, ranks are mbcnt -- no loops over lists, no per-element exec-mask
+// branches (the generic list code below costs ~2 300 VALU + 2 000 SALU instructions per item and
+// the kernel is instruction-issue bound).  Same-kind extrema are >= 2 samples apart, so with
+// distance <= 10 only the 4 nearest neighbours on each side can matter.
 #ifndef NMX_HOST_EMU
-NMX_DEV unsigned nmx_win_left(unsigned long long K, int lane) {   // bit (4 - d) <- lane - d, d = 1..4
-  return (unsigned)(lane >= 4 ? (K >> (lane - 4)) : (K << (4 - lane))) & 0xFu;
+struct NmxMask128 { unsigned long long a, b; };   // elements 0..63, 64..127
+
+NMX_DEV unsigned nmx_bit128(const NmxMask128& K, int e) {   // element e of the set; 0 outside [0, 128)
+  const unsigned long long w = e < 64 ? K.a : K.b;
+  return ((unsigned)e < 128u) ? (unsigned)((w >> (e & 63)) & 1ull) : 0u;
 }
-NMX_DEV unsigned nmx_win_right(unsigned long long K, int lane) {  // bit (d - 1) <- lane + d
-  return lane < 63 ? (unsigned)(K >> (lane + 1)) & 0xFu : 0u;
+// bits (4 - d) <- element e - d and bits (d - 1) <- element e + d, d = 1..4
+NMX_DEV void nmx_win128(const NmxMask128& K, int e, unsigned* wl, unsigned* wr) {
+  unsigned l = 0, r = 0;
+#pragma unroll
+  for (int d = 1; d <= 4; ++d) {
+    l |= nmx_bit128(K, e - d) << (4 - d);
+    r |= nmx_bit128(K, e + d) << (d - 1);
+  }
+  *wl = l; *wr = r;
 }
+
 // SciPy _select_by_peak_distance as a fixed point: an extremum is removed iff a higher-priority
 // neighbour inside the distance is kept, kept iff all of them are removed (hl / hr: those neighbours)
-NMX_DEV unsigned long long nmx_dense_fixpoint(bool valid, unsigned hl, unsigned hr, int lane) {
-  int s = !valid ? 2 : ((hl | hr) == 0u ? 1 : 0);
+NMX_DEV NmxMask128 nmx_dense_fixpoint(const bool* valid, const unsigned* hl, const unsigned* hr, int lane) {
+  int s0 = !valid[0] ? 2 : ((hl[0] | hr[0]) == 0u ? 1 : 0);
+  int s1 = !valid[1] ? 2 : ((hl[1] | hr[1]) == 0u ? 1 : 0);
   for (;;) {
-    const unsigned long long K = __ballot(s == 1), U = __ballot(s == 0);
-    if (U == 0ull) return K;
-    const unsigned kl = nmx_win_left(K, lane), kr = nmx_win_right(K, lane);
-    const unsigned ul = nmx_win_left(U, lane), ur = nmx_win_right(U, lane);
-    if (s == 0) {
-      const bool removed = ((kl & hl) | (kr & hr)) != 0u;
-      const bool wait = ((ul & hl) | (ur & hr)) != 0u;
-      s = removed ? 2 : (wait ? 0 : 1);
+    NmxMask128 K, U;
+    K.a = __ballot(s0 == 1); K.b = __ballot(s1 == 1);
+    U.a = __ballot(s0 == 0); U.b = __ballot(s1 == 0);
+    if ((U.a | U.b) == 0ull) return K;
+    unsigned kl, kr, ul, ur;
+    if (s0 == 0) {
+      nmx_win128(K, lane, &kl, &kr);
+      nmx_win128(U, lane, &ul, &ur);
+      const bool removed = ((kl & hl[0]) | (kr & hr[0])) != 0u, wait = ((ul & hl[0]) | (ur & hr[0])) != 0u;
+      s0 = removed ? 2 : (wait ? 0 : 1);
+    }
+    if (s1 == 0) {
+      nmx_win128(K, 64 + lane, &kl, &kr);
+      nmx_win128(U, 64 + lane, &ul, &ur);
+      const bool removed = ((kl & hl[1]) | (kr & hr[1])) != 0u, wait = ((ul & hl[1]) | (ur & hr[1])) != 0u;
+      s1 = removed ? 2 : (wait ? 0 : 1);
     }
   }
 }
 
 struct NmxDenseSel {
-  int pmax, pmin;             // this lane's maximum / minimum position
+  int pmax[2], pmin[2];       // this lane's maxima / minima positions (slot 0, slot 1)
   // keep masks: [0] maxima @ distance_peaks, [1] minima @ distance_troughs  (polarity 0)
   //             [2] minima @ distance_peaks, [3] maxima @ distance_troughs  (polarity 1)
-  unsigned long long K[4];
+  NmxMask128 K[4];
 };
+
+// neighbours at element distance d of both slots: rotations by d lanes wrap slot 0 into slot 1
+template <typename T>
+NMX_DEV void nmx_dense_nb(const T* v, int d, int lane, T* left, T* right) {
+  const T a_dn = __shfl(v[0], (lane - d) & 63), b_dn = __shfl(v[1], (lane - d) & 63);
+  const T a_up = __shfl(v[0], (lane + d) & 63), b_up = __shfl(v[1], (lane + d) & 63);
+  left[0] = a_dn;                          // element lane - d          (valid when lane >= d)
+  left[1] = lane >= d ? b_dn : a_dn;       // element 64 + lane - d
+  right[0] = lane + d < 64 ? a_up : b_up;  // element lane + d
+  right[1] = b_up;                         // element 64 + lane + d     (valid when lane + d < 64)
+}
 
 NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16* emin, int n_max, int n_min,
                               int dp, int dt, NmxDenseSel& D) {
   const int lane = NMX_TID;
-  const bool vmax = lane < n_max, vmin = lane < n_min;
-  const int pmax = vmax ? (int)emax[lane] : 0, pmin = vmin ? (int)emin[lane] : 0;
-  const float qmax = vmax ? z[pmax] : 0.f, qmin = vmin ? -z[pmin] : 0.f;   // priorities (heights)
+  bool vmax[2], vmin[2];
+  float qmax[2], qmin[2];   // priorities (heights)
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int e = 64 * sl + lane;
+    vmax[sl] = e < n_max; vmin[sl] = e < n_min;
+    D.pmax[sl] = vmax[sl] ? (int)emax[e] : 0;
+    D.pmin[sl] = vmin[sl] ? (int)emin[e] : 0;
+    qmax[sl] = vmax[sl] ? z[D.pmax[sl]] : 0.f;
+    qmin[sl] = vmin[sl] ? -z[D.pmin[sl]] : 0.f;
+  }
   const int md = dp > dt ? dp : dt;
-  unsigned hl0 = 0, hr0 = 0, hl1 = 0, hr1 = 0, hl2 = 0, hr2 = 0, hl3 = 0, hr3 = 0;
+  unsigned hl[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, hr[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
   for (int d = 1; d <= 4; ++d) {
-    const int aL = __shfl_up(pmax, d), aR = __shfl_down(pmax, d), bL = __shfl_up(pmin, d), bR = __shfl_down(pmin, d);
-    const bool maxL = vmax && lane >= d, maxR = vmax && lane + d < n_max;
-    const bool minL = vmin && lane >= d, minR = vmin && lane + d < n_min;
-    const int gaL = pmax - aL, gaR = aR - pmax, gbL = pmin - bL, gbR = bR - pmin;
-    if (!__any((maxL && gaL < md) || (maxR && gaR < md) || (minL && gbL < md) || (minR && gbR < md))) break;
-    const float qaL = __shfl_up(qmax, d), qaR = __shfl_down(qmax, d), qbL = __shfl_up(qmin, d), qbR = __shfl_down(qmin, d);
+    int aL[2], aR[2], bL[2], bR[2];
+    nmx_dense_nb(D.pmax, d, lane, aL, aR);
+    nmx_dense_nb(D.pmin, d, lane, bL, bR);
+    bool maxL[2], maxR[2], minL[2], minR[2], any = false;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int e = 64 * sl + lane;
+      maxL[sl] = vmax[sl] && e >= d; maxR[sl] = vmax[sl] && e + d < n_max;
+      minL[sl] = vmin[sl] && e >= d; minR[sl] = vmin[sl] && e + d < n_min;
+      any |= (maxL[sl] && D.pmax[sl] - aL[sl] < md) || (maxR[sl] && aR[sl] - D.pmax[sl] < md) ||
+             (minL[sl] && D.pmin[sl] - bL[sl] < md) || (minR[sl] && bR[sl] - D.pmin[sl] < md);
+    }
+    if (!__any(any)) break;   // wave-uniform: farther neighbours are farther away
+    float qaL[2], qaR[2], qbL[2], qbR[2];
+    nmx_dense_nb(qmax, d, lane, qaL, qaR);
+    nmx_dense_nb(qmin, d, lane, qbL, qbR);
     const unsigned bl = 1u << (4 - d), br = 1u << (d - 1);
-    // strictly higher on the left, higher-or-equal on the right: equal heights -> the later one wins
-    const bool hAL = maxL && qaL > qmax, hAR = maxR && qaR >= qmax;
-    const bool hBL = minL && qbL > qmin, hBR = minR && qbR >= qmin;
-    hl0 |= (hAL && gaL < dp) ? bl : 0u; hr0 |= (hAR && gaR < dp) ? br : 0u;
-    hl3 |= (hAL && gaL < dt) ? bl : 0u; hr3 |= (hAR && gaR < dt) ? br : 0u;
-    hl1 |= (hBL && gbL < dt) ? bl : 0u; hr1 |= (hBR && gbR < dt) ? br : 0u;
-    hl2 |= (hBL && gbL < dp) ? bl : 0u; hr2 |= (hBR && gbR < dp) ? br : 0u;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      // strictly higher on the left, higher-or-equal on the right: equal heights -> the later one wins
+      const bool hAL = maxL[sl] && qaL[sl] > qmax[sl], hAR = maxR[sl] && qaR[sl] >= qmax[sl];
+      const bool hBL = minL[sl] && qbL[sl] > qmin[sl], hBR = minR[sl] && qbR[sl] >= qmin[sl];
+      const int gaL = D.pmax[sl] - aL[sl], gaR = aR[sl] - D.pmax[sl];
+      const int gbL = D.pmin[sl] - bL[sl], gbR = bR[sl] - D.pmin[sl];
+      hl[0][sl] |= (hAL && gaL < dp) ? bl : 0u; hr[0][sl] |= (hAR && gaR < dp) ? br : 0u;
+      hl[3][sl] |= (hAL && gaL < dt) ? bl : 0u; hr[3][sl] |= (hAR && gaR < dt) ? br : 0u;
+      hl[1][sl] |= (hBL && gbL < dt) ? bl : 0u; hr[1][sl] |= (hBR && gbR < dt) ? br : 0u;
+      hl[2][sl] |= (hBL && gbL < dp) ? bl : 0u; hr[2][sl] |= (hBR && gbR < dp) ? br : 0u;
+    }
   }
-  D.pmax = pmax; D.pmin = pmin;
-  D.K[0] = nmx_dense_fixpoint(vmax, hl0, hr0, lane);
-  D.K[1] = nmx_dense_fixpoint(vmin, hl1, hr1, lane);
-  D.K[2] = nmx_dense_fixpoint(vmin, hl2, hr2, lane);
-  D.K[3] = nmx_dense_fixpoint(vmax, hl3, hr3, lane);
+  D.K[0] = nmx_dense_fixpoint(vmax, hl[0], hr[0], lane);
+  D.K[1] = nmx_dense_fixpoint(vmin, hl[1], hr[1], lane);
+  D.K[2] = nmx_dense_fixpoint(vmin, hl[2], hr[2], lane);
+  D.K[3] = nmx_dense_fixpoint(vmax, hl[3], hr[3], lane);
+}
+
+NMX_DEV int nmx_mbcnt64(unsigned long long m) {   // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 // compaction of the kept peaks / troughs into selP / selT, pairing (sharpwaves.py:347-374) and the
 // (left, right) peak lists; returns the same quantities as the generic code path
-NMX_DEV void nmx_dense_pair(unsigned long long KP, int ppos, unsigned long long KT, int tpos,
+NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const NmxMask128& KT, const int* tpos,
                             nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
                             int* nTr_out, int* n_pairs_out, int* first_valid_out, int* nT_out) {
   const int lane = NMX_TID;
-  const unsigned lane_lo = (unsigned)lane;
-  (void)lane_lo;
-  const int rP = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(KP >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)KP, 0u));
-  const int rT = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(KT >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)KT, 0u));
-  if ((KP >> lane) & 1ull) selP[rP] = (nmx_u16)ppos;
-  if ((KT >> lane) & 1ull) selT[rT] = (nmx_u16)tpos;
+  const int nPa = __popcll(KP.a), nTa = __popcll(KT.a);
+  const int nPk = nPa + __popcll(KP.b), nTr = nTa + __popcll(KT.b);
+  if ((KP.a >> lane) & 1ull) selP[nmx_mbcnt64(KP.a)] = (nmx_u16)ppos[0];
+  if ((KP.b >> lane) & 1ull) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
+  if ((KT.a >> lane) & 1ull) selT[nmx_mbcnt64(KT.a)] = (nmx_u16)tpos[0];
+  if ((KT.b >> lane) & 1ull) selT[nTa + nmx_mbcnt64(KT.b)] = (nmx_u16)tpos[1];
   NMX_SYNC();
-  const int nPk = __popcll(KP), nTr = __popcll(KT);
-  int lo = 0;   // number of kept peaks before this lane's trough (nPk <= 64: 7 bisection steps)
-  const bool has_t = lane < nTr;
-  const int t = has_t ? (int)selT[lane] : 0;
+  // number of kept peaks before each of this lane's troughs (nPk <= 128: 8 bisection steps)
+  int lo[2];
+  unsigned long long L0[2], Vm[2];
 #pragma unroll
-  for (int step = 64; step > 0; step >>= 1) {
-    const int idx = lo + step;
-    lo = (idx <= nPk && (int)selP[idx <= nPk ? idx - 1 : 0] < t) ? idx : lo;
+  for (int sl = 0; sl < 2; ++sl) {
+    const int i = 64 * sl + lane;
+    const bool has_t = i < nTr;
+    const int t = has_t ? (int)selT[i] : 0;
+    int l = 0;
+#pragma unroll
+    for (int step = 128; step > 0; step >>= 1) {
+      const int idx = l + step;
+      l = (idx <= nPk && (int)selP[idx <= nPk ? idx - 1 : 0] < t) ? idx : l;
+    }
+    lo[sl] = l;
+    L0[sl] = __ballot(has_t && l == 0);
+    Vm[sl] = __ballot(has_t && l > 0 && l < nPk);
+    if (has_t) lf[i] = (nmx_u16)l;   // temporarily the pointer (gathered below)
   }
-  const unsigned long long L0 = __ballot(has_t && lo == 0), Vm = __ballot(has_t && lo > 0 && lo < nPk);
-  const int first_valid = __popcll(L0), n_pairs = __popcll(Vm);
-  const int lastv = Vm ? 63 - __clzll((long long)Vm) : 0;
+  const int first_valid = __popcll(L0[0]) + __popcll(L0[1]);
+  const int n_pairs = __popcll(Vm[0]) + __popcll(Vm[1]);
+  const int lastv = Vm[1] ? 127 - __clzll((long long)Vm[1]) : (Vm[0] ? 63 - __clzll((long long)Vm[0]) : 0);
   const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
-  const int src = first_valid + lane;
-  const int lo_p = __shfl(lo, src < 64 ? src : 63);
-  if (lane < n_pairs) {
-    rt[lane] = selP[lo_p];
-    lf[lane] = selP[lo_p - 1];
+  NMX_SYNC();
+  int lp[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int p = 64 * sl + lane;
+    lp[sl] = p < n_pairs ? (int)lf[first_valid + p] : 1;
+  }
+  NMX_SYNC();   // lf[] is overwritten with the left peaks only after every pointer was read
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int p = 64 * sl + lane;
+    if (p < n_pairs) {
+      rt[p] = selP[lp[sl]];
+      lf[p] = selP[lp[sl] - 1];
+    }
   }
   NMX_SYNC();
   *nTr_out = nTr; *n_pairs_out = n_pairs; *first_valid_out = first_valid;
@@ -414,7 +492,7 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
 #ifndef NMX_HOST_EMU
   // wave-uniform: the register-resident path applies (else the generic list code below)
-  const bool dense = A.dense_ok && n_max <= 64 && n_min <= 64 && !(A.dbg_skip & 1);
+  const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128 && !(A.dbg_skip & 1);
   NmxDenseSel D;
   if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
 #endif
