@@ -1,7 +1,7 @@
 // nmx_device.h -- device building blocks: block reductions, LDS Stockham FFT (mixed radix
 // 2/3/4/5 + generic prime), real<->complex split, estimator helpers.
 // Hardware mapping (gfx950): one workgroup = one item, data staged in LDS (160 KiB/CU),
-// 64-lane wave reductions through __shfl_xor (DPP / ds_swizzle), cross-wave via LDS.
+// 64-lane wave reductions on the DPP path (nmx_wave_reduce), cross-wave via LDS.
 #pragma once
 
 #include "nmx_common.h"
@@ -24,10 +24,30 @@ NMX_DEV float nmx_block_min(float v, float*) { return v; }
 NMX_DEV int nmx_block_sum_i(int v, float*) { return v; }
 NMX_DEV int nmx_block_or(int v, float*) { return v; }
 #else
+// Wave reduction on the VALU data-parallel-primitive path: four in-row butterflies (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror), then row_bcast:15 / row_bcast:31 fold the four rows into lanes
+// 48..63, and v_readlane(63) hands the result to every lane through an SGPR.  Six VALU instructions
+// and NO LDS traffic, where a __shfl_xor butterfly is six ds_bpermute round trips (the kernels here
+// keep the LDS pipe ~50 % busy).  `ident` is the identity of `op` (lanes outside a row mask read it).
 template <typename T, typename Op>
-NMX_DEV T nmx_block_reduce(T v, float* red, Op op) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+NMX_DEV T nmx_wave_reduce(T v, T ident, Op op) {
+  static_assert(sizeof(T) == 4, "32-bit values");
+#define NMX_DPP(ctrl, rmask)                                                                             \
+  __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), \
+                                                    ctrl, rmask, 0xf, false))
+  v = op(v, NMX_DPP(0xB1, 0xf));    // quad_perm [1,0,3,2]
+  v = op(v, NMX_DPP(0x4E, 0xf));    // quad_perm [2,3,0,1]
+  v = op(v, NMX_DPP(0x141, 0xf));   // row_half_mirror
+  v = op(v, NMX_DPP(0x140, 0xf));   // row_mirror
+  v = op(v, NMX_DPP(0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+  v = op(v, NMX_DPP(0x143, 0xc));   // row_bcast:31 into rows 2 and 3
+#undef NMX_DPP
+  return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <typename T, typename Op>
+NMX_DEV T nmx_block_reduce(T v, T ident, float* red, Op op) {
+  v = nmx_wave_reduce(v, ident, op);
   const int nw = (NMX_NT + 63) >> 6;
   if (nw == 1) return v;
   __syncthreads();
@@ -38,20 +58,20 @@ NMX_DEV T nmx_block_reduce(T v, float* red, Op op) {
   return t;
 }
 NMX_DEV float nmx_block_sum(float v, float* red) {
-  return nmx_block_reduce(v, red, [](float a, float b) { return a + b; });
+  return nmx_block_reduce(v, 0.f, red, [](float a, float b) { return a + b; });
 }
 // NaN-propagating max/min (np.max semantics): fmaxf would drop NaNs
 NMX_DEV float nmx_block_max(float v, float* red) {
-  return nmx_block_reduce(v, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); });
+  return nmx_block_reduce(v, -INFINITY, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); });
 }
 NMX_DEV float nmx_block_min(float v, float* red) {
-  return nmx_block_reduce(v, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); });
+  return nmx_block_reduce(v, INFINITY, red, [](float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); });
 }
 NMX_DEV int nmx_block_sum_i(int v, float* red) {
-  return nmx_block_reduce(v, red, [](int a, int b) { return a + b; });
+  return nmx_block_reduce(v, 0, red, [](int a, int b) { return a + b; });
 }
 NMX_DEV int nmx_block_or(int v, float* red) {
-  return nmx_block_reduce(v, red, [](int a, int b) { return a | b; });
+  return nmx_block_reduce(v, 0, red, [](int a, int b) { return a | b; });
 }
 #endif
 
@@ -64,12 +84,7 @@ NMX_DEV void nmx_block_sum_n(float*, float*) {}
 template <int N>
 NMX_DEV void nmx_block_sum_n(float* v, float* red) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float t = v[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    v[i] = t;
-  }
+  for (int i = 0; i < N; ++i) v[i] = nmx_wave_reduce(v[i], 0.f, [](float a, float b) { return a + b; });
   const int nw = (NMX_NT + 63) >> 6;
   if (nw == 1) return;
   __syncthreads();

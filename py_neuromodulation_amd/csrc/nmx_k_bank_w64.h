@@ -194,10 +194,8 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 #define NMX_W64_REDUCE_SUM(acc_array, result)      \
   { float s_ = 0.f; for (int l = 0; l < 64; ++l) s_ += acc_array[l]; result = s_; }
 #else
-#define NMX_W64_REDUCE_SUM(acc_array, result)                                  \
-  { float s_ = acc_array[0];                                                   \
-    for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_);             \
-    result = s_; }
+#define NMX_W64_REDUCE_SUM(acc_array, result) \
+  { result = nmx_wave_reduce(acc_array[0], 0.f, [](float a_, float b_) { return a_ + b_; }); }
 #endif
 
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)

@@ -605,12 +605,11 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
             acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_nanmax(acc, v) : nmx_nanmin(acc, v));
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float t2 = __shfl_xor(acc, o);
-          acc = e == NMX_SWE_MEAN ? acc + t2 : (e == NMX_SWE_MAX ? nmx_nanmax(acc, t2) : nmx_nanmin(acc, t2));
-          cnt += __shfl_xor(cnt, o);
-        }
+        // wave-uniform estimator: one DPP reduction for the value, one for the count
+        if (e == NMX_SWE_MEAN) acc = nmx_wave_reduce(acc, 0.f, [](float a, float b) { return a + b; });
+        else if (e == NMX_SWE_MAX) acc = nmx_wave_reduce(acc, -INFINITY, [](float a, float b) { return nmx_nanmax(a, b); });
+        else acc = nmx_wave_reduce(acc, INFINITY, [](float a, float b) { return nmx_nanmin(a, b); });
+        cnt = nmx_wave_reduce(cnt, 0, [](int a, int b) { return a + b; });
         if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
       }
     } else
