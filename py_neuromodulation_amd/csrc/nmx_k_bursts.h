@@ -361,30 +361,55 @@ NMX_DEV double nmx_wave_excl_sum_d(double v, double* total) { *total = v; return
 // exclusive "latest" scan: carries (pos, val) of the lane with the largest pos before me
 NMX_DEV void nmx_wave_excl_latest(int& pos, double& val) { pos = -1; val = 0.0; }
 #else
-NMX_DEV double nmx_wave_excl_sum_d(double v, double* total) {
-  const int lane = threadIdx.x & 63;
-  double inc = v;
-  for (int o = 1; o < 64; o <<= 1) {
-    const double t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
+// DPP scans (no LDS round trips): Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then
+// row_bcast:15 / row_bcast:31 carry the row aggregates forward; a double moves as two dwords
+NMX_DEV double nmx_dpp_d(double v, double ident, int ctrl_sel) {
+  const long long vb = __builtin_bit_cast(long long, v), ib = __builtin_bit_cast(long long, ident);
+  int lo = (int)(vb & 0xffffffffll), hi = (int)(vb >> 32);
+  const int ilo = (int)(ib & 0xffffffffll), ihi = (int)(ib >> 32);
+  switch (ctrl_sel) {   // compile-time after inlining: DPP controls are instruction immediates
+    case 0: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x111, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x112, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x114, 0xf, 0xf, false); break;
+    case 3: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x118, 0xf, 0xf, false); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x142, 0xa, 0xf, false); break;
+    case 5: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x143, 0xc, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x138, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x138, 0xf, 0xf, false); break;  // wave_shr:1
   }
-  *total = __shfl(inc, 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+NMX_DEV int nmx_dpp_i(int v, int ident, int ctrl_sel) {
+  switch (ctrl_sel) {
+    case 0: return __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false);
+    case 1: return __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false);
+    case 3: return __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false);
+    case 4: return __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false);
+    case 5: return __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(ident, v, 0x138, 0xf, 0xf, false);
+  }
+}
+NMX_DEV double nmx_wave_excl_sum_d(double v, double* total) {
+  double inc = v;
+#pragma unroll
+  for (int st = 0; st < 6; ++st) inc += nmx_dpp_d(inc, 0.0, st);
+  const long long b = __builtin_bit_cast(long long, inc);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  *total = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
   return inc - v;
 }
 NMX_DEV void nmx_wave_excl_latest(int& pos, double& val) {
-  const int lane = threadIdx.x & 63;
   int p = pos;
   double v = val;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int tp = __shfl_up(p, o);
-    const double tv = __shfl_up(v, o);
-    if (lane >= o && tp > p) { p = tp; v = tv; }
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    const int tp = nmx_dpp_i(p, -1, st);
+    const double tv = nmx_dpp_d(v, 0.0, st);
+    if (tp > p) { p = tp; v = tv; }
   }
-  // shift to exclusive
-  const int ep = __shfl_up(p, 1);
-  const double ev = __shfl_up(v, 1);
-  pos = lane == 0 ? -1 : ep;
-  val = lane == 0 ? 0.0 : ev;
+  // shift to exclusive (wave_shr:1; lane 0 reads the identity)
+  pos = nmx_dpp_i(p, -1, 6);
+  val = nmx_dpp_d(v, 0.0, 6);
 }
 #endif
 

@@ -58,15 +58,19 @@ struct NmxSharpArgs {
 NMX_DEV int nmx_wave_excl_sum_i(int v, int* total) { *total = v; return 0; }
 NMX_DEV int nmx_wave_any(int v) { return v; }
 #else
+// exclusive prefix sum over the wave on the DPP path: Hillis-Steele inside each row of 16
+// (row_shr 1, 2, 4, 8), then row_bcast:15 / row_bcast:31 carry the row totals forward
 NMX_DEV int nmx_wave_excl_sum_i(int v, int* total) {
-  const int lane = threadIdx.x & 63;
   int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
-  }
-  *total = __shfl(inc, 63);
+#define NMX_DPP_I(ctrl, rmask) __builtin_amdgcn_update_dpp(0, inc, ctrl, rmask, 0xf, false)
+  inc += NMX_DPP_I(0x111, 0xf);   // row_shr:1
+  inc += NMX_DPP_I(0x112, 0xf);   // row_shr:2
+  inc += NMX_DPP_I(0x114, 0xf);   // row_shr:4
+  inc += NMX_DPP_I(0x118, 0xf);   // row_shr:8
+  inc += NMX_DPP_I(0x142, 0xa);   // row_bcast:15
+  inc += NMX_DPP_I(0x143, 0xc);   // row_bcast:31
+#undef NMX_DPP_I
+  *total = __builtin_amdgcn_readlane(inc, 63);
   return inc - v;
 }
 NMX_DEV int nmx_wave_any(int v) { return __any(v); }
