@@ -390,7 +390,7 @@ NMX_DEV int nmx_mbcnt64(unsigned long long m) {   // set bits of m below this la
 
 // compaction of the kept peaks / troughs into selP / selT, pairing (sharpwaves.py:347-374) and the
 // (left, right) peak lists; returns the same quantities as the generic code path
-NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const NmxMask128& KT, const int* tpos,
+NMX_DEV void nmx_dense_pair_bisect(const NmxMask128& KP, const int* ppos, const NmxMask128& KT, const int* tpos,
                             nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
                             int* nTr_out, int* n_pairs_out, int* first_valid_out, int* nT_out) {
   const int lane = NMX_TID;
@@ -423,6 +423,82 @@ NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const NmxMask
   const int first_valid = __popcll(L0[0]) + __popcll(L0[1]);
   const int n_pairs = __popcll(Vm[0]) + __popcll(Vm[1]);
   const int lastv = Vm[1] ? 127 - __clzll((long long)Vm[1]) : (Vm[0] ? 63 - __clzll((long long)Vm[0]) : 0);
+  const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
+  NMX_SYNC();
+  int lp[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int p = 64 * sl + lane;
+    lp[sl] = p < n_pairs ? (int)lf[first_valid + p] : 1;
+  }
+  NMX_SYNC();   // lf[] is overwritten with the left peaks only after every pointer was read
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int p = 64 * sl + lane;
+    if (p < n_pairs) {
+      rt[p] = selP[lp[sl]];
+      lf[p] = selP[lp[sl] - 1];
+    }
+  }
+  NMX_SYNC();
+  *nTr_out = nTr; *n_pairs_out = n_pairs; *first_valid_out = first_valid;
+  *nT_out = last_excl > first_valid ? last_excl - first_valid : 0;
+}
+// set bits of K at element indices < r, r in [0, 128]
+NMX_DEV int nmx_popc_below128(const NmxMask128& K, int r) {
+  const unsigned long long ma = r >= 64 ? ~0ull : ((1ull << r) - 1ull);
+  const int rb = r - 64;
+  const unsigned long long mb = rb <= 0 ? 0ull : (rb >= 64 ? ~0ull : ((1ull << rb) - 1ull));
+  return __popcll(K.a & ma) + __popcll(K.b & mb);
+}
+
+// Pairing without searching: maxima and minima of a sequence alternate, so the number of RAW peaks
+// before raw trough e is e or e + 1 (whichever kind comes first) and the number of KEPT peaks before
+// it is a popcount of the keep mask below that index.  The alternation is verified against the raw
+// lists (two independent LDS reads per trough); if it ever fails the bisection version runs instead.
+NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const nmx_u16* rawP, int n_rawP,
+                            const NmxMask128& KT, const int* tpos, int n_rawT,
+                            nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
+                            int* nTr_out, int* n_pairs_out, int* first_valid_out, int* nT_out) {
+  const int lane = NMX_TID;
+  const int off = (n_rawP > 0 && n_rawT > 0 && __builtin_amdgcn_readfirstlane(ppos[0]) <
+                                                   __builtin_amdgcn_readfirstlane(tpos[0])) ? 1 : 0;
+  int lo[2];
+  bool ok = true;
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int e = 64 * sl + lane;
+    const int r = e + off;
+    const bool has = e < n_rawT;
+    if (has) {
+      const int t = tpos[sl];
+      const bool in = r <= n_rawP;
+      const int before = (in && r > 0) ? (int)rawP[r - 1] : -1;
+      const int after = (in && r < n_rawP) ? (int)rawP[r] : 0x7fffffff;
+      ok = ok && in && before < t && t < after;
+    }
+    lo[sl] = nmx_popc_below128(KP, r);
+  }
+  if (!__all(ok)) {   // wave-uniform; never seen on real or synthetic data
+    nmx_dense_pair_bisect(KP, ppos, KT, tpos, selP, selT, lf, rt, nTr_out, n_pairs_out, first_valid_out, nT_out);
+    return;
+  }
+  const int nPa = __popcll(KP.a), nTa = __popcll(KT.a);
+  const int nPk = nPa + __popcll(KP.b), nTr = nTa + __popcll(KT.b);
+  if ((KP.a >> lane) & 1ull) selP[nmx_mbcnt64(KP.a)] = (nmx_u16)ppos[0];
+  if ((KP.b >> lane) & 1ull) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
+  const bool k0 = (KT.a >> lane) & 1ull, k1 = (KT.b >> lane) & 1ull;
+  if (k0) { const int rk = nmx_mbcnt64(KT.a); selT[rk] = (nmx_u16)tpos[0]; lf[rk] = (nmx_u16)lo[0]; }
+  if (k1) { const int rk = nTa + nmx_mbcnt64(KT.b); selT[rk] = (nmx_u16)tpos[1]; lf[rk] = (nmx_u16)lo[1]; }
+  const unsigned long long L0a = __ballot(k0 && lo[0] == 0), L0b = __ballot(k1 && lo[1] == 0);
+  NmxMask128 Vm;
+  Vm.a = __ballot(k0 && lo[0] > 0 && lo[0] < nPk);
+  Vm.b = __ballot(k1 && lo[1] > 0 && lo[1] < nPk);
+  const int first_valid = __popcll(L0a) + __popcll(L0b);
+  const int n_pairs = __popcll(Vm.a) + __popcll(Vm.b);
+  // compacted index of the last valid trough = kept troughs up to and including its raw element - 1
+  const int hv = Vm.b ? 127 - __clzll((long long)Vm.b) : (Vm.a ? 63 - __clzll((long long)Vm.a) : -1);
+  const int lastv = hv >= 0 ? nmx_popc_below128(KT, hv + 1) - 1 : 0;
   const int last_excl = (lastv + 1) < nTr ? (lastv + 1) : nTr;
   NMX_SYNC();
   int lp[2];
@@ -508,8 +584,9 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
 #ifndef NMX_HOST_EMU
     if (dense) {
       if (A.dbg_skip & 4) { ++pol_slot; continue; }
-      nmx_dense_pair(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin,
-                     pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax,
+      nmx_dense_pair(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin, pol == 0 ? emax : emin,
+                     pol == 0 ? n_max : n_min,
+                     pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax, pol == 0 ? n_min : n_max,
                      selP, selT, lf, rt, &nTr, &n_pairs, &first_valid, &nT);
     } else
 #endif
