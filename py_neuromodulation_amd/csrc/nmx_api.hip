@@ -186,9 +186,14 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds
 }
 extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
-extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t);
-extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t);
-static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s) {
+extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
+extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
+extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
+                                           hipStream_t s);
+// returns true when the sharp-wave analysis ran inside the bank kernel (`sharp` given and the
+// persistent variant was used); the caller then only launches the fallback over the flagged items
+static bool be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s,
+                               const NmxSharpArgs* sharp = nullptr) {
   static int variant = -1;
   if (variant < 0) {
     const char* v = getenv("NMX_W64_VARIANT");
@@ -204,11 +209,17 @@ static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
       n_cu = prop.multiProcessorCount;
   }
   if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
-    if ((variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s) : nmx_w64p_launch_scalar(&A, n_items, n_cu, s)))
-      return;
+    const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)
+                                : nmx_w64p_launch_scalar(&A, n_items, n_cu, s, sharp);
+    if (rc) return rc == 2;
   }
   if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
   else nmx_w64_launch_scalar(&A, n_items, lds, s);
+  return false;
+}
+static void be_launch_sharp_todo(const NmxSharpArgs& A, int n_items, size_t lds, const unsigned char* todo, be_stream_t s) {
+  be_init_once();
+  nmx_wave_launch_sharp_todo(&A, n_items, lds, todo, s);
 }
 extern "C" void nmx_hilbert_fixed_launch(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s);
 static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt, size_t lds, be_stream_t s) {

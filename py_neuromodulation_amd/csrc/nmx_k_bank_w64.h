@@ -25,6 +25,7 @@
 #pragma once
 
 #include "nmx_k_bank.h"
+#include "nmx_k_sharpwave.h"
 
 #ifdef NMX_HOST_EMU
 #define NMX_UNROLL
@@ -51,6 +52,10 @@ struct NmxBankW64Args {
   const float* Hd[NMX_MAX_FILTERS_DEV];   // B_k = (a - b) cos(th_k)
   float* yb_out;          // burst bands: filtered series [n_windows][C][Bb][W] (Hilbert kernel input)
   const float* twl;       // NMX_W64_TWL_FLOATS floats: per-lane twiddles of passes B and C (persistent kernel)
+  // fused sharp-wave analysis (persistent kernel): list offsets inside the exchange tile (floats,
+  // the series itself sits at 0) and the per-(item, filter) flag "needs the generic kernel"
+  int fz_emax, fz_emin, fz_selt, fz_lf, fz_rt, fz_selp, fz_res;
+  unsigned char* sw_todo;
   int off_Z, off_X, off_red, lds_floats;
 };
 
@@ -201,8 +206,9 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
 // TAB = 1: the A/B tables of all filters sit in LDS at `tab` ([filter][A[n], B[n]]), staged once
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
-template <int PAD, int TAB, int MC>
-NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab) {
+template <int PAD, int TAB, int MC, int FUSE = 0>
+NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
+                                  const NmxSharpArgs* S = nullptr) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
   c = nmx_uniform_i(c);
   const NmxBankArgs& A = AA.b;
@@ -403,9 +409,34 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         }
       }
     }
+    // ---- fused sharp-wave analysis: the series goes registers -> LDS, never to HBM ---------------
+    bool sw_done = false;
+#ifndef NMX_HOST_EMU
+    if (FUSE && PAD == 0 && F.sw_index >= 0) {
+      const int l = (int)(threadIdx.x & 63);
+      float* zf = (float*)X;   // pass C has consumed the exchange tile
+      NMX_WSYNC();
+      NMX_UNROLL
+      for (int i = 0; i < 16; ++i) {
+        const int m = l + 64 * (i >> 2) + 256 * (i & 3);
+        if (2 * m + 1 < W) ((nmx_c2*)zf)[m] = v[0][i];
+        else if (2 * m < W) zf[2 * m] = v[0][i].x;
+      }
+      NMX_WSYNC();
+      NmxSharpLds L;
+      L.z = zf;
+      L.emax = (nmx_u16*)(zf + AA.fz_emax); L.emin = (nmx_u16*)(zf + AA.fz_emin);
+      L.selT = (nmx_u16*)(zf + AA.fz_selt); L.lf = (nmx_u16*)(zf + AA.fz_lf);
+      L.rt = (nmx_u16*)(zf + AA.fz_rt); L.selP = (nmx_u16*)(zf + AA.fz_selp);
+      L.st = nullptr; L.vals = nullptr; L.res = zf + AA.fz_res; L.red = nullptr;
+      sw_done = nmx_sharp_body(*S, L, w, c, F.sw_index, true);
+      if (l == 0) AA.sw_todo[((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index] = sw_done ? 0 : 1;
+      NMX_WSYNC();
+    }
+#endif
     // ---- filtered series to HBM (lane-consecutive) ---------------------------------------------
     if (PAD == 0) {
-      float* dsw = F.sw_index >= 0
+      float* dsw = (F.sw_index >= 0 && !sw_done)
           ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
       float* dyb = F.burst_index >= 0
           ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;

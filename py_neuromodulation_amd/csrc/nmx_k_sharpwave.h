@@ -549,22 +549,39 @@ NMX_DEV float nmx_sw_pair(int est, float a, float b) {
 }
 
 // one WAVE per (window, channel, filter)
-NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* smem) {
-  float* z = smem + A.off_z;
-  nmx_u16* emax = (nmx_u16*)(smem + A.off_emax);
-  nmx_u16* emin = (nmx_u16*)(smem + A.off_emin);
-  nmx_u16* selP = (nmx_u16*)(smem + A.off_selp);
-  nmx_u16* selT = (nmx_u16*)(smem + A.off_selt);
-  nmx_u16* lf = (nmx_u16*)(smem + A.off_lf);
-  nmx_u16* rt = (nmx_u16*)(smem + A.off_rt);
-  unsigned char* st = (unsigned char*)(smem + A.off_st);
-  float* vals = smem + A.off_vals;
-  float* res = smem + A.off_res;   // [2][n_combos] + [2] num_peaks
-  float* red = smem + A.off_red;
+// LDS working set of one item (pointers, so that the analysis can also run inside the FIR-bank
+// kernel on the freshly filtered series: see nmx_k_bank_w64.h)
+struct NmxSharpLds {
+  float* z;                                       // [W] series
+  nmx_u16 *emax, *emin, *selP, *selT, *lf, *rt;   // index lists
+  unsigned char* st;                              // selection state (generic path only)
+  float *vals, *res, *red;
+};
+
+NMX_DEV NmxSharpLds nmx_sharp_layout(const NmxSharpArgs& A, float* smem) {
+  NmxSharpLds L;
+  L.z = smem + A.off_z;
+  L.emax = (nmx_u16*)(smem + A.off_emax);
+  L.emin = (nmx_u16*)(smem + A.off_emin);
+  L.selP = (nmx_u16*)(smem + A.off_selp);
+  L.selT = (nmx_u16*)(smem + A.off_selt);
+  L.lf = (nmx_u16*)(smem + A.off_lf);
+  L.rt = (nmx_u16*)(smem + A.off_rt);
+  L.st = (unsigned char*)(smem + A.off_st);
+  L.vals = smem + A.off_vals;
+  L.res = smem + A.off_res;   // [2][n_combos] + [2] num_peaks
+  L.red = smem + A.off_red;
+  return L;
+}
+
+// Analysis of the series in L.z.  dense_only: the caller provides lists for 128 entries only; returns
+// false (nothing written) when the window needs the generic list code.
+NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, int c, int fi, bool dense_only) {
+  float* z = L.z;
+  nmx_u16 *emax = L.emax, *emin = L.emin, *selP = L.selP, *selT = L.selT, *lf = L.lf, *rt = L.rt;
+  unsigned char* st = L.st;
+  float *vals = L.vals, *res = L.res, *red = L.red;
   const int W = A.W;
-  const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
-  nmx_stage_row(src, W, [=](int i, float v) { z[i] = v; });
-  NMX_SYNC();
   int n_max = 0, n_min = 0;
   if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min);
   float* row = A.out + (long long)w * A.n_outputs;
@@ -573,6 +590,7 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
 #ifndef NMX_HOST_EMU
   // wave-uniform: the register-resident path applies (else the generic list code below)
   const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128 && !(A.dbg_skip & 1);
+  if (dense_only && !dense) return false;
   NmxDenseSel D;
   if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
 #endif
@@ -785,4 +803,15 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
       row[A.np_cols.base + c * A.np_cols.ch_stride + fi * A.np_cols.a_stride] =
           0.5f * (res[2 * A.n_combos] + res[2 * A.n_combos + 1]);
   }
+  return true;
+}
+
+NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* smem) {
+  const NmxSharpLds L = nmx_sharp_layout(A, smem);
+  const int W = A.W;
+  const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
+  float* z = L.z;
+  nmx_stage_row(src, W, [=](int i, float v) { z[i] = v; });
+  NMX_SYNC();
+  nmx_sharp_body(A, L, w, c, fi, false);
 }

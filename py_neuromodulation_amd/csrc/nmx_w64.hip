@@ -36,9 +36,10 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // Persistent variant: one workgroup of `nw` waves per CU; the A/B tables of all filters are
 // staged in LDS once per workgroup (instead of being re-fetched from L2 for every item: 27 % of
 // the kernel's time), then every wave walks its own items with wave-local fences only.
-template <int WAVES>
+template <int WAVES, int FUSE>
 __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
-                                                                                     int n_items, int x_floats) {
+                                                                                     int n_items, int x_floats,
+                                                                                     const NmxSharpArgs S) {
   float* tab = nmx_smem_w64;
   const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
   for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W
   float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<0, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+    nmx_bank_w64_item<0, 1, 0, FUSE>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
 }
 
 // same structure for the notch (odd-reflected window, one filter)
@@ -74,8 +75,9 @@ __global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_notch_w6
     nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
 }
 
+// sharp != nullptr: run the sharp-wave analysis inside the kernel (returns 2 in that case)
 extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu,
-                                                       hipStream_t s) {
+                                                       hipStream_t s, const NmxSharpArgs* sharp) {
   // returns 0 when the configuration does not fit the persistent kernel (caller falls back)
   if (A->b.bp_features & 6u) return 0;
   const bool notch = A->b.pad_mode != 0;
@@ -97,9 +99,11 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   static bool once = false;
   if (!once) {
     once = true;
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -110,12 +114,19 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   if (notch)
     hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
                        n_items, x_floats);
-  else if (nw == 11)
-    hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11>, dim3(grid), dim3(64 * nw), lds, s, *A,
-                       n_items, x_floats);
-  else
-    hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8>, dim3(grid), dim3(64 * nw), lds, s, *A,
-                       n_items, x_floats);
+  else if (sharp && nw == 8) {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
+                       n_items, x_floats, *sharp);
+    return 2;
+  } else {
+    static const NmxSharpArgs none{};
+    if (nw == 11)
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+                         n_items, x_floats, none);
+    else
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+                         n_items, x_floats, none);
+  }
   return 1;
 }
 

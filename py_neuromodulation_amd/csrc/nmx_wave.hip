@@ -31,6 +31,28 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
 }
 
+// items the fused bank kernel could not finish (more than 128 extrema of a kind): generic list code.
+// Persistent waves walk the flag array; on the bench workload no flag is ever set.
+__global__ void __launch_bounds__(64) nmx_kern_sharp_todo(const NmxSharpArgs A, int n_items, const unsigned char* todo) {
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (!todo[item]) continue;
+    const int fi = item % A.n_filters, r = item / A.n_filters;
+    nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave);
+    NMX_SYNC();
+  }
+}
+
+extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
+                                           hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)nmx_kern_sharp_todo, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int grid = n_items < 256 * 14 ? n_items : 256 * 14;
+  hipLaunchKernelGGL(nmx_kern_sharp_todo, dim3(grid), dim3(64), lds, s, *A, n_items, todo);
+}
+
 static int waves_per_wg(size_t lds_one) {
   static int k = 0;
   if (!k) {
