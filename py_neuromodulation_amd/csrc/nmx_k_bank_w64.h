@@ -494,7 +494,7 @@ struct NmxHilbertArgs {
   NmxFft hil_r;     // complex length W/2 (W even) or W (odd)
   NmxFft hil_c;     // complex length W
   int hil_full;
-  int off_a, off_b, lds_floats;
+  int off_a, off_b, off_y, lds_floats;
 };
 
 NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* smem) {
@@ -502,31 +502,50 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
   float2* bufB = (float2*)(smem + A.off_b);
   const int W = A.W, Wh = W >> 1;
   const float* src = A.y + item * W;
-  if (A.hil_full) {
-    nmx_stage_row(src, W, [=](int i, float v) { bufB[i] = make_float2(v, 0.f); });
-  } else {
+  float* dst = A.env + item * W;
+  if (!A.hil_full) {
+    // Even W.  The analytic signal of a real series is y + i H[y]; its real part IS y, and H[y] is real:
+    // H[y] = irfft(Z), Z[k] = -i Y[k] (0 < k < W/2), Z[0] = Z[W/2] = 0 (scipy.signal.hilbert weights
+    // the DC and Nyquist bins by 1: they only reach the real part).  So ONE half-length complex
+    // transform each way instead of a half-length forward plus a full-length complex inverse.
+    float* ys = smem + A.off_y;
     float* pk = (float*)bufB;   // packed complex: (x[2i], x[2i+1])
-    nmx_stage_row(src, W, [=](int i, float v) { pk[i] = v; });
+    nmx_stage_row(src, W, [=](int i, float v) { pk[i] = v; ys[i] = v; });
+    NMX_SYNC();
+    const float2* Zy = nmx_fft_auto<-1, true>(A.hil_r, bufB, bufA, bufB);
+    float2* Yb = (Zy == bufA) ? bufB : bufA;     // Hermitian half Y[0 .. W/2]
+    for (int k = NMX_TID; k <= Wh; k += NMX_NT) Yb[k] = nmx_rfft_bin(Zy, A.hil_r.twr, Wh, k);
+    NMX_SYNC();
+    float2* Pre = (Yb == bufA) ? bufB : bufA;    // overwrites Zy
+    for (int k = NMX_TID; k < Wh; k += NMX_NT) {
+      const float2 yk = Yb[k], yn = Yb[Wh - k];
+      const float2 xk = k == 0 ? make_float2(0.f, 0.f) : make_float2(yk.y, -yk.x);    // -i Y[k]
+      const float2 xn = k == 0 ? make_float2(0.f, 0.f) : make_float2(yn.y, -yn.x);    // -i Y[W/2 - k]
+      Pre[k] = nmx_irfft_pre(xk, xn, A.hil_r.twr[k]);
+    }
+    NMX_SYNC();
+    const float* ht = (const float*)nmx_fft_auto<+1, true>(A.hil_r, Pre, Yb, Pre);   // W * H[y], natural order
+    const float invW = 1.f / (float)W;
+    for (int i = NMX_TID; i < W; i += NMX_NT) {
+      const float re = ys[i], im = ht[i] * invW;
+      dst[i] = sqrtf(re * re + im * im);
+    }
+    return;
   }
+  // odd W: full-length complex transforms
+  nmx_stage_row(src, W, [=](int i, float v) { bufB[i] = make_float2(v, 0.f); });
   NMX_SYNC();
   const float2* Zy = nmx_fft_auto<-1, true>(A.hil_r, bufB, bufA, bufB);
   float2* Ab = (Zy == bufA) ? bufB : bufA;
   const float invW = 1.f / (float)W;
-  // one-sided spectrum; Zy (W/2 points) and Ab (W points) live in different buffers
   for (int k = NMX_TID; k < W; k += NMX_NT) {
     float2 val = make_float2(0.f, 0.f);
-    if (A.hil_full) {
-      if (k == 0) val = Zy[0];
-      else if (k <= (W - 1) / 2) val = make_float2(2.f * Zy[k].x, 2.f * Zy[k].y);
-    } else if (k <= Wh) {
-      val = nmx_rfft_bin(Zy, A.hil_r.twr, Wh, k);
-      if (k != 0 && k != Wh) val = make_float2(2.f * val.x, 2.f * val.y);
-    }
+    if (k == 0) val = Zy[0];
+    else if (k <= (W - 1) / 2) val = make_float2(2.f * Zy[k].x, 2.f * Zy[k].y);
     Ab[k] = make_float2(val.x * invW, val.y * invW);
   }
   NMX_SYNC();
   float2* Zbuf = (Ab == bufA) ? bufB : bufA;
   const float2* an = nmx_fft_auto<+1, true>(A.hil_c, Ab, Zbuf, Ab);
-  float* dst = A.env + item * W;
   for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
 }
