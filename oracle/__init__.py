@@ -7,8 +7,9 @@ the HIP path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 
 Pinning status (see DESIGN.md section "Oracle"):
   * everything computed with NumPy/SciPy in the reference (FFT/Welch/STFT band power,
-    Hjorth, Raw, LineLength, FIR-bank apply, BandPower, Bursts, SharpwaveAnalyzer,
-    ReReferencer, window schedule, NaN policy, FeatureNormalizer) is PINNED: the
+    Hjorth, Raw, LineLength, FIR-bank apply, BandPower incl. Kalman smoothing, Bursts,
+    SharpwaveAnalyzer, ReReferencer, PreprocessingFilter glue, window schedule, NaN policy,
+    FeatureNormalizer) is PINNED: the
     goldens in ``tests/golden/`` were produced by importing the reference itself
     (``tests/golden/make_golden.py``) and ``tests/test_oracle_golden.py`` checks this
     restatement against them.
