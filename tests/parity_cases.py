@@ -622,3 +622,49 @@ def case_preprocessing_filter(lib):
                                        float(np.abs(x).max()), W)
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def case_config5_30khz_512pt(lib):
+    """BASELINE config[4] shape at reduced channel count: 30 kHz, 512-sample windows, hop 30 samples
+    (1 kHz feature rate), bands up to 7 kHz -- driven through the sample-based `window=` argument (the
+    reference cannot express 512 samples: windowlength_ms is an integer).  FFT / STFT / Hjorth /
+    LineLength / Raw / band-pass power (29 999-tap designs truncated to their live centre) / sharp
+    waves vs the oracle.  Welch and bursts are excluded: at this rate the reference itself degenerates
+    (nperseg = sfreq > W; samples_overlap = int(sfreq * seg_s / feat_hz) = 0)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    base = NMSettings.get_default().to_dict()
+    base["frequency_ranges_hz"] = {"gamma": [60, 200], "HFA": [200, 500], "MUA": [500, 3000], "spike": [3000, 7000]}
+    s = NMSettings(**base)
+    for f in s.features.get_enabled():
+        setattr(s.features, f, False)
+    for f in ("fft", "stft", "raw_hjorth", "linelength", "return_raw", "bandpass_filter", "sharpwave_analysis"):
+        setattr(s.features, f, True)
+    s.sampling_rate_features_hz = 1000
+    s.segment_length_features_ms = 17
+    s.fft_settings.windowlength_ms = 17
+    s.stft_settings.windowlength_ms = 17
+    s.bandpass_filter_settings.segment_lengths_ms = {"gamma": 17, "HFA": 10, "MUA": 5, "spike": 3}
+    # (a 60-500 Hz sharp-wave range is 60x oversampled here: neighbouring samples of the filtered
+    # series differ by less than the fp32 error of the convolution and extrema move by a sample)
+    s.sharpwave_analysis_settings.filter_ranges_hz = [[500, 3000], [1000, 7000]]
+    s = NMSettings(**s.to_dict())
+    sfreq, C, W, hop, nh = 30000.0, 6, 512, 30, 24
+    rng = np.random.default_rng(0)
+    T = W + (nh - 1) * hop
+    t = np.arange(T) / sfreq
+    x = rng.standard_normal((C, T)) * 30 + 40 * np.sin(2 * np.pi * 900 * t) + rng.uniform(-100, 100, (C, 1))
+    ch = [f"c{i}" for i in range(C)]
+    eng = HotPathEngine(s, ch, sfreq, lib=lib, window=W)
+    got = eng.process_batch(x, np.arange(nh) * hop)
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in eng.enabled]
+    for i in range(nh):
+        w = x[:, i * hop:i * hop + W]
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(w))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 200.0, W)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()

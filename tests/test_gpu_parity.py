@@ -237,3 +237,7 @@ def test_resampler(gpu_lib):
 
 def test_preprocessing_filter(gpu_lib):
     pc.case_preprocessing_filter(gpu_lib)
+
+
+def test_config5_30khz_512pt(gpu_lib):
+    pc.case_config5_30khz_512pt(gpu_lib)

@@ -96,3 +96,7 @@ def test_resampler(emu_lib):
 
 def test_preprocessing_filter(emu_lib):
     pc.case_preprocessing_filter(emu_lib)
+
+
+def test_config5_30khz_512pt(emu_lib):
+    pc.case_config5_30khz_512pt(emu_lib)
