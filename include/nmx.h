@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 4
+#define NMX_ABI_VERSION 5
 
 /* error codes */
 #define NMX_OK 0
@@ -178,6 +178,15 @@ typedef struct {
   int32_t n_pre_filters;
   const double* pre_taps[4];
   int32_t n_pre_taps[4];
+
+  /* raw_normalization (processing/normalization.py:31-116, type "raw"), the last pre-processor:
+   * method 0 = off, 1 = mean ((x - mean) / mean), 2 = zscore ((x - mean) / std, std 0 -> 1);
+   * statistics per channel over the first window + the last raw_norm_add = int(sfreq / feat_hz)
+   * samples of every later window, history trimmed to raw_norm_n - 1 samples
+   * (raw_norm_n = int(normalization_time_s * sfreq)); clip <= 0: none.  Stateful (nmx_state_*). */
+  int32_t raw_norm_method;
+  int32_t raw_norm_n, raw_norm_add;
+  float raw_norm_clip;
 } nmx_plan_desc;
 
 typedef struct nmx_plan nmx_plan;

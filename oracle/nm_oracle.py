@@ -836,6 +836,42 @@ class Resampler:
 # --------------------------------------------------------------------------------------
 
 
+class RawNormalizer:
+    """processing/normalization.py:31-116 with type "raw": history = the first window plus the last
+    int(sfreq / feat_hz) samples of every later window, statistics over it incl. the current tail,
+    trimmed to N - 1 = int(normalization_time_s * sfreq) - 1 samples afterwards."""
+
+    def __init__(self, sfreq, settings) -> None:
+        rs = settings.raw_normalization_settings
+        self.method = rs.normalization_method
+        self.clip = rs.clip
+        self.add = int(sfreq / settings.sampling_rate_features_hz)
+        self.n = int(rs.normalization_time_s * sfreq)
+        self.prev = np.empty((0, 0))
+
+    def process(self, data):
+        if self.prev.size == 0:
+            self.prev = data.T
+            return data
+        cur = data.T
+        self.prev = np.vstack((self.prev, cur[-self.add:]))
+        has_nan = np.any(np.isnan(sum(self.prev)))
+        mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)
+        std = (np.nanstd if has_nan else np.std)(self.prev, axis=0)
+        std[std == 0] = 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if self.method == "mean":
+                out = (cur - mean) / mean
+            elif self.method == "zscore":
+                out = (cur - mean) / std
+            else:
+                raise NotImplementedError(self.method)
+        if self.clip:
+            out = out.clip(min=-self.clip, max=self.clip)
+        self.prev = self.prev[-self.n + 1:]
+        return np.nan_to_num(out).T
+
+
 class FeatureNormalizer:
     """processing/normalization.py:31-111 for mean / median / zscore / zscore-median."""
 

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 4
+NMX_ABI_VERSION = 5
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -67,6 +67,8 @@ class PlanDesc(C.Structure):
         ("kalman_Tp", C.c_double), ("kalman_sigma_w", C.c_double), ("kalman_sigma_v", C.c_double),
         ("raw_window", C.c_int32), ("resample_ratio", C.c_double),
         ("n_pre_filters", C.c_int32), ("pre_taps", C.POINTER(C.c_double) * 4), ("n_pre_taps", C.c_int32 * 4),
+        ("raw_norm_method", C.c_int32), ("raw_norm_n", C.c_int32), ("raw_norm_add", C.c_int32),
+        ("raw_norm_clip", C.c_float),
     ]
 
 

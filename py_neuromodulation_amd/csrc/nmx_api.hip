@@ -9,6 +9,7 @@
 #include "nmx_k_kalman.h"
 #include "nmx_k_norm.h"
 #include "nmx_k_prep.h"
+#include "nmx_k_rawnorm.h"
 #include "nmx_k_resample.h"
 #include "nmx_k_sharpwave.h"
 #include "nmx_k_timeosc.h"
@@ -47,6 +48,12 @@ __global__ void __launch_bounds__(256) nmx_kern_reref(const NmxRerefArgs A) {
 __global__ void __launch_bounds__(256) nmx_kern_resample(const NmxResampleArgs A) {
   const int item = blockIdx.x;
   nmx_resample_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
+}
+__global__ void __launch_bounds__(64) nmx_kern_rawnorm_stats(const NmxRawNormArgs A) {
+  nmx_rawnorm_stats_item(A, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(256) nmx_kern_rawnorm_apply(const NmxRawNormArgs A) {
+  nmx_rawnorm_apply(A, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
   const int i = (int)(blockIdx.x * 64 + threadIdx.x);
@@ -251,6 +258,11 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
 static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   hipLaunchKernelGGL(nmx_kern_resample, dim3(n_items), dim3(nt), lds, s, A);
+}
+static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_rawnorm_stats, dim3(A.n_channels), dim3(64), 0, s, A);
+  const long long n = (long long)A.n_windows * A.n_channels * A.W;
+  hipLaunchKernelGGL(nmx_kern_rawnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
 }
 static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
   const int n = A.n_channels * A.n_bands;

@@ -52,6 +52,7 @@ class DataProcessor:
         R = None
         resample_to = None
         pre_taps = None
+        raw_norm = None
         for name in st.preprocessing:
             if name not in PREPROCESSOR_ORDER:
                 raise ValueError(f"Invalid preprocessing method '{name}'. Must be one of {PREPROCESSOR_ORDER}")
@@ -79,6 +80,12 @@ class DataProcessor:
                     resample_to = new_rate
             elif name == "re_referencing":
                 R = chmod.reref_matrix(self.channels)
+            elif name == "raw_normalization":
+                rs = st.raw_normalization_settings
+                rate = resample_to if resample_to is not None else self.sfreq_raw
+                # normalization.py:52-58: add_samples = int(sfreq / feat_hz), N = int(time_s * sfreq)
+                raw_norm = (rs.normalization_method, rs.clip, int(rs.normalization_time_s * rate),
+                            int(rate / st.sampling_rate_features_hz))
             else:
                 raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY 8f)")
         C = len(self.feature_idx)
@@ -105,11 +112,12 @@ class DataProcessor:
         if resample_to is None:
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, window=window, lib=lib, dry_run=dry_run,
-                                        pre_taps=pre_taps)
+                                        pre_taps=pre_taps, raw_norm=raw_norm)
         else:   # `window` counts RAW samples (the generator cuts raw data)
             self.engine = HotPathEngine(st, names, resample_to, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, lib=lib, dry_run=dry_run,
-                                        resample_from=self.sfreq_raw, raw_window=window, pre_taps=pre_taps)
+                                        resample_from=self.sfreq_raw, raw_window=window, pre_taps=pre_taps,
+                                        raw_norm=raw_norm)
             self.sfreq_raw = resample_to
         self.keys = self.engine.keys
         self.feature_normalizer = None

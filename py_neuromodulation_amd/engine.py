@@ -52,7 +52,8 @@ class HotPathEngine:
                  sharpwave_taps: Sequence[np.ndarray] | None = None,
                  window: int | None = None, dry_run: bool = False,
                  resample_from: float | None = None, raw_window: int | None = None,
-                 pre_taps: Sequence[np.ndarray] | None = None) -> None:
+                 pre_taps: Sequence[np.ndarray] | None = None,
+                 raw_norm: tuple | None = None) -> None:
         """``sfreq`` is the rate the features see.  ``resample_from`` = sampling rate of the incoming
         windows when it differs (raw_resampling, processing/resample.py:19-60): incoming windows then
         hold ``raw_window`` samples (default int(segment_length_features_ms / 1000 * resample_from)) and
@@ -81,6 +82,7 @@ class HotPathEngine:
             if window is None:
                 self.W = int(round(self.resample_ratio * self.W_in))   # mne.filter.resample: final_len
         self._keep: list = []   # arrays referenced by the C struct
+        self._raw_norm = raw_norm   # (method "mean" | "zscore", clip, N samples, add samples)
         self._pre_taps = [np.asarray(t, dtype=np.float64) for t in (pre_taps or [])]
         if len(self._pre_taps) > 4:
             raise ValueError("at most 4 preprocessing_filter stages")
@@ -146,6 +148,13 @@ class HotPathEngine:
         if self.resample_ratio:
             d.raw_window = int(self.W_in)
             d.resample_ratio = float(self.resample_ratio)
+        if self._raw_norm is not None:              # raw_normalization, last pre-processor
+            method, clip, n_hist, add = self._raw_norm
+            if method not in ("mean", "zscore"):
+                raise NotImplementedError(f"raw_normalization method {method!r} has no device implementation")
+            d.raw_norm_method = {"mean": 1, "zscore": 2}[method]
+            d.raw_norm_clip = float(clip) if clip else 0.0
+            d.raw_norm_n, d.raw_norm_add = int(n_hist), int(add)
         d.n_pre_filters = len(self._pre_taps)       # preprocessing_filter stages, before the notch
         for i, t in enumerate(self._pre_taps):
             d.pre_taps[i] = self._dptr(t)

@@ -3,6 +3,7 @@
   NotchFilter   filter/notch_filter.py:9-93     process(data[C, W]) -> data   (HIP FIR kernel)
   ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
   PreprocessingFilter processing/filter_preprocessing.py:44-94  chained single FIRs (HIP FIR kernel)
+  RawNormalizer processing/normalization.py:113-116  mean / zscore of the raw window against its history
   Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
                                                 algorithm, parity unpinned); identity at ratio 1
   FeatureNormalizer processing/normalization.py:31-111 -- host NumPy version (all methods incl.
@@ -22,9 +23,12 @@ from .settings import NMSettings
 
 
 def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, resample_to=None,
-                pre_taps=None):
+                pre_taps=None, raw_norm=None):
     s = NMSettings.get_default()
     C = C_out if C_out is not None else C_in
+    if raw_norm is not None:
+        return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
+                             raw_norm=raw_norm, window=W)
     if pre_taps is not None:
         return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
                              pre_taps=pre_taps, window=W)
@@ -91,6 +95,27 @@ class PreprocessingFilter:
         if data.shape not in self._engines:
             self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq, pre_taps=self.taps)
         return self._engines[data.shape].preprocess_window(data)
+
+
+class RawNormalizer:
+    """processing/normalization.py:113-116 (Normalizer with type "raw") for the "mean" and "zscore"
+    methods on the device; stateful like the reference (one instance = one stream)."""
+
+    def __init__(self, sfreq: float, settings, **kwargs) -> None:
+        rs = settings.raw_normalization_settings
+        self.sfreq = float(sfreq)
+        self._spec = (rs.normalization_method, rs.clip, int(rs.normalization_time_s * sfreq),
+                      int(sfreq / settings.sampling_rate_features_hz))
+        if rs.normalization_method not in ("mean", "zscore"):
+            raise NotImplementedError(f"raw_normalization method {rs.normalization_method!r} has no device "
+                                      "implementation")
+        self._engine = None
+
+    def process(self, data: np.ndarray) -> np.ndarray:
+        data = np.asarray(data, dtype=np.float64)
+        if self._engine is None:
+            self._engine = _pre_engine(data.shape[0], data.shape[1], self.sfreq, raw_norm=self._spec)
+        return self._engine.preprocess_window(data)
 
 
 class Resampler:

@@ -367,6 +367,30 @@ def case_preprocessing_filter():
     print("preprocessing_filter", {k: np.shape(v) for k, v in out.items() if k.endswith("_y")})
 
 
+def case_raw_normalizer():
+    """RawNormalizer.process over consecutive windows (processing/normalization.py:31-116, type "raw"):
+    zscore and mean, a short history (0.5 s) so that the N - 1 trim is exercised, clip on/off."""
+    sfreq, C, T = 1000, 2, 2200
+    out = {"sfreq": sfreq, "stride": 4}   # every 4th sample of each output window is stored
+    data = synth(C, T, sfreq, 41)
+    out["data"] = data
+    for tag, method, clip in (("zscore", "zscore", 3), ("mean", "mean", 3), ("zscore_noclip", "zscore", 0)):
+        s = nm.NMSettings.get_default()
+        s.raw_normalization_settings.normalization_time_s = 0.5
+        s.raw_normalization_settings.normalization_method = method
+        s.raw_normalization_settings.clip = clip
+        s.preprocessing = ["raw_normalization"]
+        s = s.validate()
+        rn = nm.processing.RawNormalizer(sfreq, s)
+        gen = nm.stream.generator.RawDataGenerator(data, sfreq, s.sampling_rate_features_hz,
+                                                   s.segment_length_features_ms)
+        rows = [np.array(rn.process(np.array(w, dtype=np.float64))) for _, w in gen]
+        out[f"{tag}_settings_json"] = dump(s)
+        out[f"{tag}_y"] = np.stack(rows)[:, :, ::4]
+    np.savez_compressed(HERE / "raw_normalizer.npz", **out)
+    print("raw_normalizer", {k: np.shape(v) for k, v in out.items() if k.endswith("_y")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -374,6 +398,7 @@ if __name__ == "__main__":
         sys.exit(0)
     case_bandpower_kalman()
     case_preprocessing_filter()
+    case_raw_normalizer()
     case_schedule()
     case_feat_1k()
     case_feat_2k()

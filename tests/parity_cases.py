@@ -668,3 +668,56 @@ def case_config5_30khz_512pt(lib):
         n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 200.0, W)
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def case_raw_normalizer(lib):
+    """raw_normalization vs the reference golden (13 consecutive windows, 0.5 s history so the N - 1
+    trim acts, zscore / mean / no clip): window-by-window through the drop-in class, as one batch with
+    state carried through export/import, and in front of features.  Values are z-scores of fp32 data
+    against float64 statistics: 1e-5 relative + 2e-6 absolute."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.processing import RawNormalizer
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("raw_normalizer")
+    sfreq, data, st = float(g["sfreq"]), g["data"], int(g["stride"])
+    C = data.shape[0]
+    for tag in ("zscore", "mean", "zscore_noclip"):
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz,
+                                              s.segment_length_features_ms)
+        want = g[f"{tag}_y"]
+        rn = RawNormalizer(sfreq, s)
+        rn._engine = HotPathEngine(NMSettings.get_default(), [f"c{i}" for i in range(C)], sfreq,
+                                   features=["return_raw"], raw_norm=rn._spec, window=1000, lib=lib)
+        for i, (a, b) in enumerate(zip(starts, ends)):
+            y = rn.process(data[:, a:b])
+            np.testing.assert_allclose(y[:, ::st], want[i], rtol=1e-5, atol=2e-6, err_msg=f"{tag} hop {i}")
+    # batch + state: the normalised LAST sample of each window is the return_raw feature
+    s = settings_from_json(g["zscore_settings_json"])
+    starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    spec = ("zscore", 3, int(0.5 * sfreq), int(sfreq / s.sampling_rate_features_hz))
+    mk = lambda: HotPathEngine(NMSettings.get_default(), [f"c{i}" for i in range(C)], sfreq,   # noqa: E731
+                               features=["return_raw", "raw_hjorth"], raw_norm=spec, window=1000, lib=lib)
+    ref = orc.RawNormalizer(sfreq, s)
+    hj, rw = orc.Hjorth(s, [f"c{i}" for i in range(C)], sfreq), orc.Raw(s, [f"c{i}" for i in range(C)], sfreq)
+    rows = []
+    for a, b in zip(starts, ends):
+        y = ref.process(data[:, a:b])
+        d = hj.calc_feature(y)
+        d.update(rw.calc_feature(y))
+        rows.append(d)
+    e1 = mk()
+    got = [e1.process_batch(data, starts[:5])]
+    e2 = mk()
+    e2.import_state(e1.export_state())
+    got.append(e2.process_batch(data, starts[5:]))
+    got = np.concatenate(got)
+    for i in range(len(starts)):
+        np.testing.assert_allclose(got[i], [rows[i][k] for k in e1.keys], rtol=2e-5, atol=5e-6, err_msg=f"hop {i}")
+    e2.reset_state()
+    np.testing.assert_allclose(e2.process_batch(data, starts[:2]), got[:2], rtol=1e-6, atol=1e-7)
+    e1.close()
+    e2.close()

@@ -241,3 +241,7 @@ def test_preprocessing_filter(gpu_lib):
 
 def test_config5_30khz_512pt(gpu_lib):
     pc.case_config5_30khz_512pt(gpu_lib)
+
+
+def test_raw_normalizer(gpu_lib):
+    pc.case_raw_normalizer(gpu_lib)

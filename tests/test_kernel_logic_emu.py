@@ -100,3 +100,7 @@ def test_preprocessing_filter(emu_lib):
 
 def test_config5_30khz_512pt(emu_lib):
     pc.case_config5_30khz_512pt(emu_lib)
+
+
+def test_raw_normalizer(emu_lib):
+    pc.case_raw_normalizer(emu_lib)
