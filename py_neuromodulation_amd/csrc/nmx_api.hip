@@ -224,6 +224,11 @@ static bool be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
   else nmx_w64_launch_scalar(&A, n_items, lds, s);
   return false;
 }
+extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s);
+static void be_launch_sharp_dense(const NmxSharpArgs& A, int n_items, be_stream_t s) {
+  be_init_once();
+  nmx_wave_launch_sharp_dense(&A, n_items, s);
+}
 static void be_launch_sharp_todo(const NmxSharpArgs& A, int n_items, size_t lds, const unsigned char* todo, be_stream_t s) {
   be_init_once();
   nmx_wave_launch_sharp_todo(&A, n_items, lds, todo, s);

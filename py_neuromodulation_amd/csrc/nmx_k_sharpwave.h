@@ -52,6 +52,10 @@ struct NmxSharpArgs {
   int off_z, off_emax, off_emin, off_selp, off_selt, off_lf, off_rt, off_st, off_vals, off_res, off_red;
   int pm;           // capacity of the index lists (W / 2 + 2)
   int lds_floats;
+  // dense-first launch (small LDS footprint, more waves per CU): 128-entry lists, overflowing items
+  // are flagged in `todo` and redone by the generic kernel with the full layout above
+  int dz_emax, dz_emin, dz_selt, dz_lf, dz_rt, dz_selp, dz_res, dz_lds_floats;
+  unsigned char* todo;
 };
 
 #ifdef NMX_HOST_EMU
@@ -131,7 +135,8 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
 // Device version: the per-lane chunk (<= 64 samples) is classified without branches into two
 // bitmasks (a divergent `if` costs several scalar instructions and the CU has one scalar unit);
 // only plateau starts -- rare -- take a branch.  Bit k = extremum whose (plateau) start is i0 + k.
-NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min) {
+NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min,
+                         int cap = 0x7fffffff) {
   const int n_idx = W - 2;
   const int chunk = n_idx > 0 ? (n_idx + NMX_NT - 1) / NMX_NT : 0;
   const int i0 = 1 + NMX_TID * chunk;
@@ -167,7 +172,8 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
     int ahead = i + 1;
     const float cur = z[i];
     while (ahead < W - 1 && z[ahead] == cur) ++ahead;
-    emax[bmax++] = (nmx_u16)((i + ahead - 1) >> 1);
+    if (bmax < cap) emax[bmax] = (nmx_u16)((i + ahead - 1) >> 1);   // counts stay exact past `cap`
+    ++bmax;
   }
   while (mmin) {
     const int i = i0 + __ffsll((long long)mmin) - 1;
@@ -175,7 +181,8 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
     int ahead = i + 1;
     const float cur = z[i];
     while (ahead < W - 1 && z[ahead] == cur) ++ahead;
-    emin[bmin++] = (nmx_u16)((i + ahead - 1) >> 1);
+    if (bmin < cap) emin[bmin] = (nmx_u16)((i + ahead - 1) >> 1);
+    ++bmin;
   }
   NMX_SYNC();
 }
@@ -583,7 +590,12 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   float *vals = L.vals, *res = L.res, *red = L.red;
   const int W = A.W;
   int n_max = 0, n_min = 0;
+#ifdef NMX_HOST_EMU
   if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min);
+#else
+  // dense_only callers provide lists for 128 entries: longer ones are counted, not stored
+  if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min, dense_only ? 128 : 0x7fffffff);
+#endif
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
@@ -815,3 +827,22 @@ NMX_DEV void nmx_sharp_item(const NmxSharpArgs& A, int w, int c, int fi, float* 
   NMX_SYNC();
   nmx_sharp_body(A, L, w, c, fi, false);
 }
+
+#ifndef NMX_HOST_EMU
+// dense-first variant: compact LDS layout, no list fallback in this launch
+NMX_DEV void nmx_sharp_item_dense(const NmxSharpArgs& A, int w, int c, int fi, long long item, float* smem) {
+  NmxSharpLds L;
+  L.z = smem;
+  L.emax = (nmx_u16*)(smem + A.dz_emax); L.emin = (nmx_u16*)(smem + A.dz_emin);
+  L.selT = (nmx_u16*)(smem + A.dz_selt); L.lf = (nmx_u16*)(smem + A.dz_lf);
+  L.rt = (nmx_u16*)(smem + A.dz_rt); L.selP = (nmx_u16*)(smem + A.dz_selp);
+  L.st = nullptr; L.vals = nullptr; L.res = smem + A.dz_res; L.red = nullptr;
+  const int W = A.W;
+  const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
+  float* z = L.z;
+  nmx_stage_row(src, W, [=](int i, float v) { z[i] = v; });
+  NMX_SYNC();
+  const bool done = nmx_sharp_body(A, L, w, c, fi, true);
+  if (NMX_TID == 0) A.todo[item] = done ? 0 : 1;
+}
+#endif

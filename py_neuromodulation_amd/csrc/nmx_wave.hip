@@ -31,6 +31,17 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
 }
 
+// dense-first launch: compact LDS layout (more waves per CU); overflowing items are flagged
+__global__ void __launch_bounds__(64) nmx_kern_sharp_dense(const NmxSharpArgs A, int n_items) {
+  const int item = blockIdx.x;
+  const int fi = item % A.n_filters, r = item / A.n_filters;
+  nmx_sharp_item_dense(A, r / A.n_channels, r % A.n_channels, fi, (long long)item, nmx_smem_wave);
+}
+
+extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s) {
+  hipLaunchKernelGGL(nmx_kern_sharp_dense, dim3(n_items), dim3(64), (size_t)A->dz_lds_floats * 4, s, *A, n_items);
+}
+
 // items the fused bank kernel could not finish (more than 128 extrema of a kind): generic list code.
 // Persistent waves walk the flag array; on the bench workload no flag is ever set.
 __global__ void __launch_bounds__(64) nmx_kern_sharp_todo(const NmxSharpArgs A, int n_items, const unsigned char* todo) {

@@ -78,6 +78,7 @@ static bool be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
   return false;   // the fused sharp-wave path is device only
 }
 static void be_launch_sharp_todo(const NmxSharpArgs&, int, size_t, const unsigned char*, be_stream_t) {}
+static void be_launch_sharp_dense(const NmxSharpArgs&, int, be_stream_t) {}
 static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
   for (long long it = 0; it < n_items; ++it) nmx_hilbert_item(A, it, sm.data());
