@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(256) nmx_kern_hilbert(const NmxHilbertArgs A) 
 }
 template <int CH>
 __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs A) {
+  // the sequential threshold walk sits on the critical path of the overlapped schedule: its few waves
+  // win issue arbitration against the throughput kernels that share the CU
+  __builtin_amdgcn_s_setprio(3);
   const int item = blockIdx.x;
   nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
 }
