@@ -183,8 +183,16 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<128>);
 }
 
+extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
+  static int scan_ok = -1;
+  if (scan_ok < 0) { const char* v = getenv("NMX_SCAN_KERNEL"); scan_ok = !(v && v[0] == '0'); }
+  // no oscillatory feature: the register-resident scan (one wave per window, no LDS)
+  if (scan_ok && !A.fft.enabled && !A.welch.enabled && !A.stft.enabled && A.W <= 1024 && A.W >= 3) {
+    nmx_wave_launch_scan(&A, n_items, s);
+    return;
+  }
   static int fixed_ok = -1;
   if (fixed_ok < 0) { const char* v = getenv("NMX_TIMEOSC_FIXED"); fixed_ok = !(v && v[0] == '0'); }
   if (fixed_ok && nt == nmx_timeosc_fixed_width()) { nmx_timeosc_fixed_launch(&A, n_items, lds, s); return; }

@@ -113,6 +113,14 @@ NMX_DEV float nmx_clean(float v) {
   return v;
 }
 
+#ifndef NMX_HOST_EMU
+// NaN -> 0, +-inf -> +-FLT_MAX without branches
+NMX_DEV float nmx_clean_bl(float v) {
+  v = (v != v) ? 0.f : v;
+  return __builtin_amdgcn_fmed3f(v, -3.402823466e+38f, 3.402823466e+38f);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // row staging (global -> LDS)
 // ---------------------------------------------------------------------------------------

@@ -81,11 +81,6 @@ typedef __amdgpu_buffer_rsrc_t nmx_rsrc;
 NMX_DEV nmx_rsrc nmx_make_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
-// NaN -> 0, +-inf -> +-FLT_MAX without branches
-NMX_DEV float nmx_clean_bl(float v) {
-  v = (v != v) ? 0.f : v;
-  return __builtin_amdgcn_fmed3f(v, -3.402823466e+38f, 3.402823466e+38f);
-}
 #endif
 
 // 4-point DFT, DIR = -1 forward / +1 inverse

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "nmx_k_bursts.h"
+#include "nmx_k_scan.h"
 #include "nmx_k_sharpwave.h"
 
 extern __shared__ __attribute__((aligned(16))) float nmx_smem_wave[];
@@ -29,6 +30,21 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   if (item >= n_items) return;
   const int fi = item % A.n_filters, r = item / A.n_filters;
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
+}
+
+// register-resident scan (Hjorth / Raw / LineLength only): four waves per workgroup, no LDS
+__global__ void __launch_bounds__(256) nmx_kern_scan(const NmxTimeOscArgs A, int n_items, int n_windows, int order) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;
+  if (order) nmx_scan_item(A, item % n_windows, item / n_windows);
+  else nmx_scan_item(A, item / A.n_channels, item % A.n_channels);
+}
+
+extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
+  static int order = -1;
+  if (order < 0) { const char* v = getenv("NMX_SCAN_ORDER"); order = (v && v[0] == '1') ? 1 : 0; }
+  hipLaunchKernelGGL(nmx_kern_scan, dim3((n_items + 3) / 4), dim3(256), 0, s, *A, n_items, n_items / A->n_channels, order);
 }
 
 // dense-first launch: compact LDS layout (more waves per CU); overflowing items are flagged
