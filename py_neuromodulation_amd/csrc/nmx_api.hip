@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs 
   nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
 }
 // kernels compiled with a compile-time workgroup size live in nmx_timeosc.hip / nmx_wave.hip
-extern "C" int nmx_timeosc_fixed_width(void);
-extern "C" void nmx_timeosc_fixed_launch(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s);
+extern "C" void nmx_timeosc_fixed_launch128(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s);
+extern "C" void nmx_hilbert_fixed_launch128(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s);
 // one-item-per-wave kernels live in nmx_wave.hip (compile-time workgroup size)
 extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_items, size_t lds, hipStream_t s);
 extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s);
@@ -195,7 +195,7 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
   }
   static int fixed_ok = -1;
   if (fixed_ok < 0) { const char* v = getenv("NMX_TIMEOSC_FIXED"); fixed_ok = !(v && v[0] == '0'); }
-  if (fixed_ok && nt == nmx_timeosc_fixed_width()) { nmx_timeosc_fixed_launch(&A, n_items, lds, s); return; }
+  if (fixed_ok && nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_timeosc, dim3(n_items), dim3(nt), lds, s, A);
 }
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
@@ -244,12 +244,11 @@ static void be_launch_sharp_todo(const NmxSharpArgs& A, int n_items, size_t lds,
   be_init_once();
   nmx_wave_launch_sharp_todo(&A, n_items, lds, todo, s);
 }
-extern "C" void nmx_hilbert_fixed_launch(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s);
 static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   static int fixed_ok = -1;
   if (fixed_ok < 0) { const char* v = getenv("NMX_HILBERT_FIXED"); fixed_ok = !(v && v[0] == '0'); }
-  if (fixed_ok && nt == nmx_timeosc_fixed_width()) { nmx_hilbert_fixed_launch(&A, n_items, lds, s); return; }
+  if (fixed_ok && nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
 }
 static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {

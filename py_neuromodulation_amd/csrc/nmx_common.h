@@ -48,7 +48,11 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #ifdef NMX_NT_FIXED
 #define NMX_SYNC() NMX_WAVE_FENCE()
 #elif defined(NMX_BLOCK_FIXED)
-#define NMX_SYNC() __syncthreads()
+#define NMX_SYNC()                                        \
+  do {                                                    \
+    if (NMX_BLOCK_FIXED <= 64) { NMX_WAVE_FENCE(); }      \
+    else { __syncthreads(); }                             \
+  } while (0)
 #else
 #define NMX_SYNC()                                   \
   do {                                               \

@@ -7,38 +7,40 @@
 #endif
 #include <hip/hip_runtime.h>
 
+#define NMX_CAT2(a, b) a##b
+#define NMX_CAT(a, b) NMX_CAT2(a, b)
+
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_timeosc.h"
 
 extern __shared__ __attribute__((aligned(16))) float nmx_smem_to[];
 
-__global__ void __launch_bounds__(NMX_BLOCK_FIXED) nmx_kern_timeosc_fixed(const NmxTimeOscArgs A) {
+__global__ void __launch_bounds__(NMX_BLOCK_FIXED) NMX_CAT(nmx_kern_timeosc_fixed, NMX_BLOCK_FIXED)(const NmxTimeOscArgs A) {
   const int item = blockIdx.x;
   nmx_time_osc_item(A, item / A.n_channels, item % A.n_channels, nmx_smem_to);
 }
 
-__global__ void __launch_bounds__(NMX_BLOCK_FIXED) nmx_kern_hilbert_fixed(const NmxHilbertArgs A) {
+__global__ void __launch_bounds__(NMX_BLOCK_FIXED) NMX_CAT(nmx_kern_hilbert_fixed, NMX_BLOCK_FIXED)(const NmxHilbertArgs A) {
   nmx_hilbert_item(A, (long long)blockIdx.x, nmx_smem_to);
 }
 
-extern "C" int nmx_timeosc_fixed_width(void) { return NMX_BLOCK_FIXED; }
 
-extern "C" void nmx_hilbert_fixed_launch(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s) {
+extern "C" void NMX_CAT(nmx_hilbert_fixed_launch, NMX_BLOCK_FIXED)(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s) {
   static bool once = false;
   if (!once) {
     once = true;
-    (void)hipFuncSetAttribute((const void*)nmx_kern_hilbert_fixed, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_hilbert_fixed, NMX_BLOCK_FIXED), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
-  hipLaunchKernelGGL(nmx_kern_hilbert_fixed, dim3((unsigned)n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+  hipLaunchKernelGGL(NMX_CAT(nmx_kern_hilbert_fixed, NMX_BLOCK_FIXED), dim3((unsigned)n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
 }
 
-extern "C" void nmx_timeosc_fixed_launch(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s) {
+extern "C" void NMX_CAT(nmx_timeosc_fixed_launch, NMX_BLOCK_FIXED)(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s) {
   static bool once = false;
   if (!once) {
     once = true;
-    (void)hipFuncSetAttribute((const void*)nmx_kern_timeosc_fixed, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_timeosc_fixed, NMX_BLOCK_FIXED), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
-  hipLaunchKernelGGL(nmx_kern_timeosc_fixed, dim3(n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+  hipLaunchKernelGGL(NMX_CAT(nmx_kern_timeosc_fixed, NMX_BLOCK_FIXED), dim3(n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
 }
