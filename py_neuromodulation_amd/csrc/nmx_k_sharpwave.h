@@ -45,7 +45,6 @@ struct NmxSharpArgs {
   NmxCols cols;       // a = filter, b = slot (x n_polarities + polarity when !between)
   NmxCols np_cols;    // num_peaks (between mode), a = filter
   int has_num_peaks;
-  int dbg_skip;          // experiment switch (0 in production)
   int dense_ok;          // distances <= 10 and only mean / max / min estimators: register-resident path
   int fast_estimators;   // all pairs are mean/max/min of loop-free per-trough quantities
   // LDS carve (float offsets): z[W] | emax,emin,selP,selT,lf,rt (u16[pm]) | st (u8[2 pm]) | vals | res | red
@@ -591,17 +590,17 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   const int W = A.W;
   int n_max = 0, n_min = 0;
 #ifdef NMX_HOST_EMU
-  if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min);
+  nmx_extrema(z, W, emax, emin, &n_max, &n_min);
 #else
   // dense_only callers provide lists for 128 entries: longer ones are counted, not stored
-  if (!(A.dbg_skip & 2)) nmx_extrema(z, W, emax, emin, &n_max, &n_min, dense_only ? 128 : 0x7fffffff);
+  nmx_extrema(z, W, emax, emin, &n_max, &n_min, dense_only ? 128 : 0x7fffffff);
 #endif
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
 #ifndef NMX_HOST_EMU
   // wave-uniform: the register-resident path applies (else the generic list code below)
-  const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128 && !(A.dbg_skip & 1);
+  const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128;
   if (dense_only && !dense) return false;
   NmxDenseSel D;
   if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
@@ -613,7 +612,6 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     int nTr = 0, n_pairs = 0, first_valid = 0, nT = 0;
 #ifndef NMX_HOST_EMU
     if (dense) {
-      if (A.dbg_skip & 4) { ++pol_slot; continue; }
       nmx_dense_pair(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin, pol == 0 ? emax : emin,
                      pol == 0 ? n_max : n_min,
                      pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax, pol == 0 ? n_min : n_max,
@@ -626,8 +624,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     P[0].dist = A.dist_peaks; P[0].st = st; P[0].out = selP; P[0].n_out = 0;
     P[1].pos = pol == 0 ? emin : emax; P[1].n = pol == 0 ? n_min : n_max; P[1].sgn = -sgn;
     P[1].dist = A.dist_troughs; P[1].st = st + A.pm; P[1].out = selT; P[1].n_out = 0;
-    if (A.dbg_skip & 1) { P[0].n_out = 0; P[1].n_out = 0; } else nmx_select2(z, P);
-    if (A.dbg_skip & 4) { ++pol_slot; continue; }
+    nmx_select2(z, P);
     const int nPk = P[0].n_out;
     nTr = P[1].n_out;
     const nmx_u16* pk = selP;
