@@ -721,3 +721,38 @@ def case_raw_normalizer(lib):
     np.testing.assert_allclose(e2.process_batch(data, starts[:2]), got[:2], rtol=1e-6, atol=1e-7)
     e1.close()
     e2.close()
+
+
+def case_psd_keys_skip_normalisation(lib):
+    """return_spectrum adds "<ch>_fft_psd_<f>" keys; with normalize_psd = False (default) the reference
+    normalises every other column and passes the psd ones through (stream/data_processor.py:263-290).
+    Stream.run (device normaliser with a column mask) vs the oracle's hop-by-hop DataProcessor."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    for f in s.features.get_enabled():
+        setattr(s.features, f, False)
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.fft_settings.return_spectrum = True
+    s.preprocessing = ["re_referencing"]
+    s.feature_normalization_settings.normalization_time_s = 1.0   # 10 rows: the N - 1 trim acts
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 4000)) * 10 + 100
+    st = Stream(sfreq=1000.0, data=x, settings=s, lib=lib)
+    df = st.run(x, save_csv=False)
+    rows = orc.run_stream(x, 1000.0, s, channels=st.channels.to_dict("list"))
+    assert list(df.columns) == list(rows[0].keys())
+    want = np.array([[r[k] for k in df.columns] for r in rows])
+    got = df.to_numpy(dtype=np.float64)
+    psd = np.array(["psd" in c for c in df.columns])
+    assert psd.sum() == 3 * 501
+    # psd columns: raw log-spectra (1e-5 in log10 units; near-null bins as in tests/parity.py)
+    err = np.abs(got[:, psd] - want[:, psd])
+    assert np.mean(err < 1e-5) > 0.995 and err.max() < 2e-3
+    # normalised columns: z-scores of fp32 features (first row un-normalised)
+    np.testing.assert_allclose(got[0, ~psd], want[0, ~psd], rtol=1e-5, atol=1e-5)
+    zerr = np.abs(got[1:, ~psd] - want[1:, ~psd])
+    assert zerr.max() < 0.05 and np.mean(zerr < 2e-3) > 0.99

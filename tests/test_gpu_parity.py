@@ -245,3 +245,7 @@ def test_config5_30khz_512pt(gpu_lib):
 
 def test_raw_normalizer(gpu_lib):
     pc.case_raw_normalizer(gpu_lib)
+
+
+def test_psd_keys_skip_normalisation(gpu_lib):
+    pc.case_psd_keys_skip_normalisation(gpu_lib)

@@ -104,3 +104,7 @@ def test_config5_30khz_512pt(emu_lib):
 
 def test_raw_normalizer(emu_lib):
     pc.case_raw_normalizer(emu_lib)
+
+
+def test_psd_keys_skip_normalisation(emu_lib):
+    pc.case_psd_keys_skip_normalisation(emu_lib)
