@@ -345,40 +345,48 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         // Register i of every lane covers samples [2 mb, 2 mb + 127]: all but the (at most two)
         // registers that straddle lo or hi are wave-uniformly inside or outside the tail, so the
         // range test is a scalar branch and the sums are packed adds / fmas.
+        // ONE pass: sum and sum of squares together, var = E[y^2] - E[y]^2.  The series is the output
+        // of a band-pass filter, so E[y]^2 << E[y^2] and the subtraction costs no accuracy in fp32
+        // (a second, mean-shifted pass over the registers was 8 % of the kernel).
         const int lo = W - F.bp_seglen + yoff, hi = W + yoff;
-        float part[NMX_LANES];
+        float part[NMX_LANES], part2[NMX_LANES];
         NMX_LANE_LOOP {
-          nmx_c2 acc = nmx_mk2(0.f, 0.f);
+          nmx_c2 acc = nmx_mk2(0.f, 0.f), acc2 = nmx_mk2(0.f, 0.f);
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
             const int mb = 64 * (i >> 2) + 256 * (i & 3);
             if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
-            const nmx_c2 val = v[NMX_LI][i];
-            if (2 * mb >= lo && 2 * mb + 127 < hi) {
-              acc = nmx_cadd(acc, val);
-            } else {
-              acc = nmx_cadd(acc, nmx_w64_range_mask(val, l + mb, lo, hi));
-            }
+            nmx_c2 val = v[NMX_LI][i];
+            if (!(2 * mb >= lo && 2 * mb + 127 < hi)) val = nmx_w64_range_mask(val, l + mb, lo, hi);
+            acc = nmx_cadd(acc, val);
+            acc2 = nmx_c2_fma(val, val, acc2);
           }
           part[NMX_LI] = acc.x + acc.y;
+          part2[NMX_LI] = acc2.x + acc2.y;
         }
-        float tot;
+        float tot, tot2;
         NMX_W64_REDUCE_SUM(part, tot);
+        NMX_W64_REDUCE_SUM(part2, tot2);
         const float mean = tot / (float)F.bp_seglen;
-        NMX_LANE_LOOP {
-          nmx_c2 acc = nmx_mk2(0.f, 0.f);
-          const nmx_c2 mean2 = nmx_mk2(mean, mean);
-          NMX_UNROLL
-          for (int i = 0; i < 16; ++i) {
-            const int mb = 64 * (i >> 2) + 256 * (i & 3);
-            if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
-            nmx_c2 d = nmx_csub(v[NMX_LI][i], mean2);
-            if (!(2 * mb >= lo && 2 * mb + 127 < hi)) d = nmx_w64_range_mask(d, l + mb, lo, hi);
-            acc = nmx_c2_fma(d, d, acc);
+        tot = tot2 - mean * tot;   // sum (y - mean)^2 = sum y^2 - mean sum y
+        if (mean * mean * (float)F.bp_seglen > 4.f * tot) {
+          // wave-uniform, rare (a short tail of a slow band is almost a constant): the subtraction
+          // above cancels, redo it mean-shifted like np.var
+          NMX_LANE_LOOP {
+            nmx_c2 acc = nmx_mk2(0.f, 0.f);
+            const nmx_c2 mean2 = nmx_mk2(mean, mean);
+            NMX_UNROLL
+            for (int i = 0; i < 16; ++i) {
+              const int mb = 64 * (i >> 2) + 256 * (i & 3);
+              if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
+              nmx_c2 d = nmx_csub(v[NMX_LI][i], mean2);
+              if (!(2 * mb >= lo && 2 * mb + 127 < hi)) d = nmx_w64_range_mask(d, l + mb, lo, hi);
+              acc = nmx_c2_fma(d, d, acc);
+            }
+            part[NMX_LI] = acc.x + acc.y;
           }
-          part[NMX_LI] = acc.x + acc.y;
+          NMX_W64_REDUCE_SUM(part, tot);
         }
-        NMX_W64_REDUCE_SUM(part, tot);
         const float act = tot / (float)F.bp_seglen;
         NMX_LANE_LOOP {
           if (l == 0) {
