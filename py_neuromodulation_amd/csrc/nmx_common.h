@@ -126,6 +126,7 @@ struct NmxOsc {
 };
 
 struct NmxTimeOscArgs {
+  int stft_per_wave;     // STFT segments distributed over the waves of the workgroup (needs 2 x 250 complex per buffer)
   const float* x;        // input samples
   long long ch_stride;   // elements between channels
   long long win_stride;  // elements between windows (0 for a strided stream view)

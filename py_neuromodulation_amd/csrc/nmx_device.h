@@ -423,10 +423,17 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
 // VALU instructions in the FFT kernels (SQ_INSTS_SALU ~ SQ_INSTS_VALU), i.e. they were
 // scalar-issue bound.  Here radix, Ns and all strides are compile-time constants.
 // ---------------------------------------------------------------------------------------
-template <int DIR, int R, int NS, int N>
+// WAVE = true: the transform belongs to ONE wave of a multi-wave workgroup (its own buffers): lanes
+// stride by 64 and the stages are separated by wave-local LDS fences instead of workgroup barriers.
+template <int DIR, int R, int NS, int N, bool WAVE = false>
 NMX_DEV void nmx_stage_static(const float2* in, float2* out, const float2* NMX_RESTRICT tw) {
   constexpr int m = N / R, tstep = N / (NS * R);
-  for (int j = NMX_TID; j < m; j += NMX_NT) {
+#ifdef NMX_HOST_EMU
+  const int tid0 = NMX_TID, nt0 = NMX_NT;
+#else
+  const int tid0 = WAVE ? (int)(threadIdx.x & 63) : NMX_TID, nt0 = WAVE ? 64 : NMX_NT;
+#endif
+  for (int j = tid0; j < m; j += nt0) {
     const int q = j / NS, k = j - q * NS;   // NS is a constant: mul/shift, no division
     const int o = q * NS * R + k;
     const int tb = k * tstep;
@@ -495,6 +502,9 @@ NMX_DEV void nmx_stage_static(const float2* in, float2* out, const float2* NMX_R
       out[o + NS] = nmx_csub(a0, a1);
     }
   }
+#ifndef NMX_HOST_EMU
+  if (WAVE) { NMX_WAVE_FENCE(); return; }
+#endif
   NMX_SYNC();
 }
 
@@ -505,6 +515,14 @@ NMX_DEV float2* nmx_fft3(const float2* in0, float2* a, float2* b, const float2* 
   nmx_stage_static<DIR, R2, R1, N>(a, b, tw);
   nmx_stage_static<DIR, R3, R1 * R2, N>(b, a, tw);
   return a;
+}
+template <int DIR, int N, int R1, int R2, int R3, int R4>
+NMX_DEV float2* nmx_fft4_wave(const float2* in0, float2* a, float2* b, const float2* tw) {
+  nmx_stage_static<DIR, R1, 1, N, true>(in0, a, tw);
+  nmx_stage_static<DIR, R2, R1, N, true>(a, b, tw);
+  nmx_stage_static<DIR, R3, R1 * R2, N, true>(b, a, tw);
+  nmx_stage_static<DIR, R4, R1 * R2 * R3, N, true>(a, b, tw);
+  return b;
 }
 template <int DIR, int N, int R1, int R2, int R3, int R4>
 NMX_DEV float2* nmx_fft4(const float2* in0, float2* a, float2* b, const float2* tw) {

@@ -281,7 +281,34 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       if (e < 2 * h + W) return xs[W - 2 - (e - h - W)];
       return 0.f;
     };
-    for (int sgi = 0; sgi < O.nseg; ++sgi) {
+    int sg_first = 0;
+#ifndef NMX_HOST_EMU
+    if (!O.complex_full && O.fft.n == 250 && NMX_NT >= 128 && A.stft_per_wave) {
+      // default STFT (nperseg 500): every WAVE takes whole segments and runs its own 250-point
+      // transform in its own slice of the buffers -- no workgroup barriers inside the segment loop and
+      // 50 of 64 lanes busy in the radix-5 passes (a 128-thread workgroup had 50 of 128)
+      const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nwv = NMX_NT >> 6;
+      float2* wA = bufA + wv * 250;
+      float2* wB = bufB + wv * 250;
+      NMX_SYNC();
+      for (int sgi = wv; sgi < O.nseg; sgi += nwv) {
+        const int s0 = sgi * O.step;
+        for (int i = lane; i < 250; i += 64)
+          wB[i] = make_float2(xe(s0 + 2 * i) * O.win[2 * i], xe(s0 + 2 * i + 1) * O.win[2 * i + 1]);
+        NMX_WAVE_FENCE();
+        const float2* Z = nmx_fft4_wave<-1, 250, 5, 5, 5, 2>(wB, wA, wB, O.fft.tw);
+        for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+          const float2 X = nmx_rfft_bin(Z, O.fft.twr, 250, k);
+          float v = sqrtf(X.x * X.x + X.y * X.y) * O.scale;
+          if (O.log_transform) v = log10f(v);
+          spec[(k - O.k_lo) * O.nseg + sgi] = v;
+        }
+        NMX_WAVE_FENCE();
+      }
+      sg_first = O.nseg;
+    }
+#endif
+    for (int sgi = sg_first; sgi < O.nseg; ++sgi) {
       const int s0 = sgi * O.step;
       NMX_SYNC();
       if (O.complex_full) {
