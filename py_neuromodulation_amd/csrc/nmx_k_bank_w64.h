@@ -273,6 +273,11 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       const float x0 = xs[0], xl = xs[W - 1];
       NMX_UNROLL
       for (int r = 0; r < 16; ++r) {
+        if (128 * r >= h && 128 * r + 127 < W + h) {   // wave-uniform: this register is all interior
+          const float* q = xs + (2 * l + 128 * r - h);
+          vv[r] = nmx_mk2(q[0], q[1]);
+          continue;
+        }
         float e2[2];
         for (int u = 0; u < 2; ++u) {
           const int jp = 2 * (l + 64 * r) + u;
