@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "nmx_k_bursts.h"
+#include "nmx_k_fft500.h"
 #include "nmx_k_scan.h"
 #include "nmx_k_sharpwave.h"
 
@@ -30,6 +31,15 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   if (item >= n_items) return;
   const int fi = item % A.n_filters, r = item / A.n_filters;
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
+}
+
+// Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)
+__global__ void __launch_bounds__(64) nmx_kern_hilbert_w500(const NmxHilbertArgs A) {
+  nmx_hilbert_w500_item(A, (long long)blockIdx.x, nmx_smem_wave);
+}
+
+extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long n_items, hipStream_t s) {
+  hipLaunchKernelGGL(nmx_kern_hilbert_w500, dim3((unsigned)n_items), dim3(64), (size_t)NMX_W500_LDS_FLOATS * 4, s, *A);
 }
 
 // register-resident scan (Hjorth / Raw / LineLength only): four waves per workgroup, no LDS
