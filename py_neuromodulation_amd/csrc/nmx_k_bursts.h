@@ -38,6 +38,7 @@ struct NmxBurstThrArgs {
   double q;             // threshold / 100
   int P2;               // power of two >= max(W, overlap): bitonic sort size of the new piece
   int off_l0, off_l1, off_p, off_red, lds_floats;
+  int list_in_global;   // the top-K list stays in its global (L2-resident) state array, LDS holds only the working sets
 };
 
 // bitonic sort (descending) of p[0..n2), n2 a power of two, in LDS
@@ -189,7 +190,7 @@ NMX_DEV float nmx_lerp_thr(double a, double b, double frac, bool have_b) {
 // re-cut from the list's tail.  Bit-identical to the per-hop full merge.
 template <int CH>
 NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
-  float* L = smem + A.off_l0;
+  float* L = A.list_in_global ? A.top + ((long long)c * A.n_bands + bi) * A.K : smem + A.off_l0;
   float* pc = smem + A.off_p;            // [P2] raw new samples / flush staging
   float* ps = pc + A.P2;                 // [P2] sorted new samples
   int* ins = (int*)(ps + A.P2);          // [P2] insertion indices
@@ -203,7 +204,7 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
   long long nwin = A.counts[2 * sidx + 1];
   int len = (int)(total < K ? total : K);
   float* gtop = A.top + sidx * K;
-  for (int i = NMX_TID; i < len; i += NMX_NT) L[i] = gtop[i];
+  if (!A.list_in_global) for (int i = NMX_TID; i < len; i += NMX_NT) L[i] = gtop[i];
 #ifdef NMX_HOST_EMU
   std::vector<float> vals_store(K > 0 ? K : 1);
   float* vals = vals_store.data();
@@ -336,7 +337,7 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
     }
   }
   NMX_SYNC();
-  for (int i = NMX_TID; i < len; i += NMX_NT) gtop[i] = L[i];
+  if (!A.list_in_global) for (int i = NMX_TID; i < len; i += NMX_NT) gtop[i] = L[i];
   if (NMX_TID == 0) {
     A.counts[2 * sidx] = total;
     A.counts[2 * sidx + 1] = nwin;
