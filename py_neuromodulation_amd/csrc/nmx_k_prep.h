@@ -27,8 +27,10 @@ struct NmxRerefArgs {
 // block = 256 threads <-> 256 consecutive samples; blockIdx.y <-> NMX_REREF_ROWS output rows
 NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
   if (t >= A.T) return;
-  float acc[NMX_REREF_ROWS];
-  for (int i = 0; i < NMX_REREF_ROWS; ++i) acc[i] = 0.f;
+  // float64 accumulators: a 256-term fp32 dot product of samples carrying a DC offset loses ~3 digits
+  // (visible in near-null spectral bins downstream); the kernel is bandwidth bound either way
+  double acc[NMX_REREF_ROWS];
+  for (int i = 0; i < NMX_REREF_ROWS; ++i) acc[i] = 0.0;
   const int nrow = (A.C - c0) < NMX_REREF_ROWS ? (A.C - c0) : NMX_REREF_ROWS;
   for (int j = 0; j < A.C_in; ++j) {
     const float v = nmx_clean(A.x[(long long)j * A.ldx + t]);
@@ -36,9 +38,9 @@ NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
 #pragma unroll
 #endif
     for (int i = 0; i < NMX_REREF_ROWS; ++i)
-      if (i < nrow) acc[i] += A.R[(long long)(c0 + i) * A.C_in + j] * v;
+      if (i < nrow) acc[i] += (double)A.R[(long long)(c0 + i) * A.C_in + j] * (double)v;
   }
-  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = acc[i];
+  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = (float)acc[i];
 }
 
 // Common-average style matrices R = (d - o) I + o 1 1^T (the reference's DEFAULT channel table,
