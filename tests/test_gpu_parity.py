@@ -249,3 +249,45 @@ def test_raw_normalizer(gpu_lib):
 
 def test_psd_keys_skip_normalisation(gpu_lib):
     pc.case_psd_keys_skip_normalisation(gpu_lib)
+
+
+def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
+    """Plan-level knobs select fallback / alternative kernels (list-based sharp-wave code, dense
+    re-reference, serial launch order, fused sharp waves, global-memory burst list, block-wide STFT).
+    They must reproduce the default path on the bench feature set within the parity tolerances."""
+    C, n_hops = 64, 40
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(77)
+    t = np.arange(T) / 1000.0
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-300, 300, (C, 1))).astype(np.float32)
+    starts = np.arange(n_hops) * 100
+
+    def run():
+        s, eng = _bench_like_engine(gpu_lib, C)
+        out = eng.process_batch(x, starts)
+        keys = list(eng.keys)
+        eng.close()
+        return s, keys, out
+
+    s, keys, want = run()
+    for knob, val in (("NMX_SW_DENSE", "0"), ("NMX_SW_DENSE_FIRST", "0"), ("NMX_CAR_FAST", "0"), ("NMX_OVERLAP", "0"),
+                      ("NMX_FUSE_SHARP", "1"), ("NMX_THR_LIST_GLOBAL", "1"), ("NMX_STFT_PER_WAVE", "0"),
+                      ("NMX_CHUNK_WINDOWS", "9")):
+        monkeypatch.setenv(knob, val)
+        _, keys2, got = run()
+        monkeypatch.delenv(knob)
+        assert keys2 == keys
+        # two fp32 paths against each other: every entry inside the per-family tolerance except the
+        # near-null-bin / decision-flip outliers of tests/parity.py, here bounded as a fraction (both
+        # sides carry the fp32 error) with the same absolute caps
+        n_bad = 0
+        for i in range(n_hops):
+            b, rep, _ = parity.compare(keys, got[i], want[i].astype(np.float64), s, 1000.0, 400.0, 1000,
+                                       burst_slack=True)
+            if b:
+                fam = [parity.family_of(k) for k in keys]
+                err = np.abs(got[i].astype(np.float64) - want[i])
+                spectral = np.array([f in ("fft", "welch", "stft", "bandpass") for f in fam])
+                assert err[spectral].max() < 2e-3, f"{knob}={val} hop {i}\n{rep}"
+            n_bad += b
+        assert n_bad <= max(2, got.size // 2000), f"{knob}={val}: {n_bad} entries outside tolerance"
