@@ -683,6 +683,58 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
       // per-trough quantity that needs no inner loop: ONE pass over the troughs, no value lists,
       // one shuffle reduction per pair (default settings: 3 pairs)
       const int s_off = A.sharp_off;
+      if (nT <= 128 && n_pairs <= 128) {
+        // at most two entries per lane: gather the list entries and the samples they point at ONCE,
+        // then every (feature, estimator) pair is register arithmetic + one reduction
+        int tq[2], lq[2], rq[2], tprev[2];
+        float zt[2], zl[2], zr[2], zm[2], zp[2];
+        bool okT[2], okP[2], okS[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const int p = NMX_TID + 64 * sl;
+          okT[sl] = p < nT; okP[sl] = p < n_pairs;
+          tq[sl] = okT[sl] ? (int)trv[p] : 0;
+          tprev[sl] = (okT[sl] && p > 0) ? (int)trv[p - 1] : tq[sl];
+          lq[sl] = okP[sl] ? (int)lf[p] : 0;
+          rq[sl] = okP[sl] ? (int)rt[p] : 0;
+          okS[sl] = okT[sl] && (tq[sl] - s_off > 0) && (tq[sl] + s_off < W);
+          zt[sl] = sgn * z[tq[sl]]; zl[sl] = sgn * z[lq[sl]]; zr[sl] = sgn * z[rq[sl]];
+          zm[sl] = okS[sl] ? sgn * z[tq[sl] - s_off] : 0.f;
+          zp[sl] = okS[sl] ? sgn * z[tq[sl] + s_off] : 0.f;
+        }
+        for (int cb = 0; cb < A.n_combos; ++cb) {
+          const int f = A.combo_feature[cb], e = A.combo_est[cb];
+          if (f == NMX_SW_NUM_PEAKS) continue;
+          float acc = e == NMX_SWE_MEAN ? 0.f : (e == NMX_SWE_MAX ? -INFINITY : INFINITY);
+          int cnt = 0;
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const bool pt = okP[sl] && (NMX_TID + 64 * sl) < nPT;   // arrays that pair troughs with peaks
+            float v;
+            bool ok;
+            switch (f) {
+              case NMX_SW_PEAK_LEFT: v = zl[sl]; ok = okP[sl]; break;
+              case NMX_SW_PEAK_RIGHT: v = zr[sl]; ok = okP[sl]; break;
+              case NMX_SW_TROUGH: v = zt[sl]; ok = okT[sl]; break;
+              case NMX_SW_WIDTH: v = (float)(rq[sl] - lq[sl]); ok = okP[sl]; break;
+              case NMX_SW_PROMINENCE: v = fabsf((zr[sl] + zl[sl]) * 0.5f - zt[sl]); ok = pt; break;
+              case NMX_SW_INTERVAL: v = (float)(tq[sl] - tprev[sl]) * A.ms; ok = okT[sl]; break;
+              case NMX_SW_DECAY_TIME: v = (float)(lq[sl] - tq[sl]) * A.ms; ok = pt; break;
+              case NMX_SW_RISE_TIME: v = (float)(rq[sl] - tq[sl]) * A.ms; ok = pt; break;
+              default: v = zt[sl] - 0.5f * (zm[sl] + zp[sl]); ok = okS[sl]; break;   // NMX_SW_SHARPNESS
+            }
+            if (ok) {
+              ++cnt;
+              acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_nanmax(acc, v) : nmx_nanmin(acc, v));
+            }
+          }
+          if (e == NMX_SWE_MEAN) acc = nmx_wave_reduce(acc, 0.f, [](float a, float b) { return a + b; });
+          else if (e == NMX_SWE_MAX) acc = nmx_wave_reduce(acc, -INFINITY, [](float a, float b) { return nmx_nanmax(a, b); });
+          else acc = nmx_wave_reduce(acc, INFINITY, [](float a, float b) { return nmx_nanmin(a, b); });
+          cnt = nmx_wave_reduce(cnt, 0, [](int a, int b) { return a + b; });
+          if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
+        }
+      } else
       for (int cb = 0; cb < A.n_combos; ++cb) {
         const int f = A.combo_feature[cb], e = A.combo_est[cb];
         if (f == NMX_SW_NUM_PEAKS) continue;
