@@ -73,3 +73,18 @@ def test_product_loader_has_no_cpu_fallback(tmp_path):
 
     with pytest.raises(NmxError):
         NmxLibrary(tmp_path / "missing_libnmx.so")
+
+
+def test_abi_from_plain_c(tmp_path):
+    """include/nmx.h is valid C and the library links and runs from a C program."""
+    import subprocess
+
+    import __graft_entry__ as g
+
+    lib = g.build_lib()
+    exe = tmp_path / "abi_smoke"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", str(ROOT / "tests" / "c_abi" / "abi_smoke.c"), "-I", str(ROOT / "include"),
+           "-L", str(lib.parent), "-lnmx", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

@@ -291,3 +291,29 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
                 assert err[spectral].max() < 2e-3, f"{knob}={val} hop {i}\n{rep}"
             n_bad += b
         assert n_bad <= max(2, got.size // 2000), f"{knob}={val}: {n_bad} entries outside tolerance"
+
+
+def test_linearity_of_the_filter_stages(gpu_lib):
+    """Size-independent property at the headline width (256 ch): notch + re-reference and the FIR bank
+    are linear maps of the window: T(a x + b y) = a T(x) + b T(y) within fp32 rounding of the sums."""
+    from py_neuromodulation_amd import NMSettings, fir_design
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    C, W = 256, 1000
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((C, W)) * 40 + rng.uniform(-200, 200, (C, 1))
+    y = rng.standard_normal((C, W)) * 25
+    a, b = 0.75, -1.5
+    R = np.full((C, C), -1.0 / (C - 1))
+    np.fill_diagonal(R, 1.0)
+    s = NMSettings.get_default()
+    s.features.bandpass_filter = True
+    eng = HotPathEngine(s, [f"ch{i}" for i in range(C)], 1000.0, lib=gpu_lib, ref_matrix=R,
+                        notch_taps=fir_design.notch_bank(1000.0, 50))
+    px, py_, pz = eng.preprocess_window(x), eng.preprocess_window(y), eng.preprocess_window(a * x + b * y)
+    scale = np.abs(px).max() + np.abs(py_).max()
+    np.testing.assert_allclose(pz, a * px + b * py_, rtol=0, atol=3e-6 * scale)
+    fx, fy, fz = eng.filter_window(px), eng.filter_window(py_), eng.filter_window(a * px + b * py_)
+    assert fx.shape == (C, int(eng.desc.n_filters), W)
+    np.testing.assert_allclose(fz, a * fx + b * fy, rtol=0, atol=3e-6 * scale)
+    eng.close()
