@@ -208,9 +208,10 @@ extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t,
 extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
                                            hipStream_t s);
-// returns true when the sharp-wave analysis ran inside the bank kernel (`sharp` given and the
-// persistent variant was used); the caller then only launches the fallback over the flagged items
-static bool be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s,
+// returns the persistent launcher's flags (nmx_w64.hip): bit 1 = the sharp-wave analysis ran inside the
+// bank kernel (the caller then only launches the fallback over the flagged items), bit 2 = the Hilbert
+// envelopes were written by the bank kernel (no Hilbert launch); 0 = one-wave-per-workgroup kernel
+static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s,
                                const NmxSharpArgs* sharp = nullptr) {
   static int variant = -1;
   if (variant < 0) {
@@ -229,11 +230,11 @@ static bool be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
   if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
     const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)
                                 : nmx_w64p_launch_scalar(&A, n_items, n_cu, s, sharp);
-    if (rc) return rc == 2;
+    if (rc) return rc;
   }
   if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
   else nmx_w64_launch_scalar(&A, n_items, lds, s);
-  return false;
+  return 0;
 }
 extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s);
 static void be_launch_sharp_dense(const NmxSharpArgs& A, int n_items, be_stream_t s) {

@@ -25,6 +25,7 @@
 #pragma once
 
 #include "nmx_k_bank.h"
+#include "nmx_k_fft500.h"
 #include "nmx_k_sharpwave.h"
 
 #ifdef NMX_HOST_EMU
@@ -51,6 +52,9 @@ struct NmxBankW64Args {
   const float* Hs[NMX_MAX_FILTERS_DEV];   // A_k = (a + b) - (a - b) sin(th_k)
   const float* Hd[NMX_MAX_FILTERS_DEV];   // B_k = (a - b) cos(th_k)
   float* yb_out;          // burst bands: filtered series [n_windows][C][Bb][W] (Hilbert kernel input)
+  // fused Hilbert envelope (persistent kernel, W = 1000): burst-band series never leave the wave, the
+  // envelope goes to b.env_out [n_windows][C][Bb][W]; table layout: nmx_k_fft500.h
+  const float* hil_tab;
   const float* twl;       // NMX_W64_TWL_FLOATS floats: per-lane twiddles of passes B and C (persistent kernel)
   // fused sharp-wave analysis (persistent kernel): list offsets inside the exchange tile (floats,
   // the series itself sits at 0) and the per-(item, filter) flag "needs the generic kernel"
@@ -122,9 +126,6 @@ NMX_UNROLL
   NMX_SWAP(1, 4) NMX_SWAP(2, 8) NMX_SWAP(3, 12) NMX_SWAP(6, 9) NMX_SWAP(7, 13) NMX_SWAP(11, 14)
 #undef NMX_SWAP
 }
-
-template <int DIR>
-NMX_DEV nmx_c2 nmx_twd(nmx_c2 t) { return DIR > 0 ? nmx_mk2(t.x, -t.y) : t; }
 
 // padded physical index of the pass-A output buffer
 NMX_DEV int nmx_w64_pad(int idx) { return idx + (idx >> 4); }
@@ -201,7 +202,9 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
 // TAB = 1: the A/B tables of all filters sit in LDS at `tab` ([filter][A[n], B[n]]), staged once
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
-template <int PAD, int TAB, int MC, int FUSE = 0>
+// HIL = 1 (needs TAB = 1, W = 1000): Hilbert envelope of the burst bands inside the wave; `tab` then
+// continues with the NMX_W500_TAB_FLOATS table after the pass B / C twiddles.
+template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0>
 NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
                                   const NmxSharpArgs* S = nullptr) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
@@ -442,11 +445,44 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       NMX_WSYNC();
     }
 #endif
+    // ---- fused Hilbert envelope of a burst band: registers -> LDS -> two 500-point transforms ----
+#ifndef NMX_HOST_EMU
+    if (HIL && TAB && PAD == 0 && F.burst_index >= 0) {
+      const int l = (int)(threadIdx.x & 63);
+      nmx_c2* hb = X;          // [501]  (pass C has consumed the exchange tile)
+      nmx_c2* ha = X + 504;    // [500]
+      const nmx_c2* htab = (const nmx_c2*)(twC + NMX_W64_TWC_N);
+      NMX_WSYNC();
+      // lane l holds (y[2m], y[2m+1]) in v[4 t + r], m = l + 64 t + 256 r: m < 500 <=> r = 0, or r = 1 and
+      // (t < 3 or l < 52)
+      NMX_UNROLL
+      for (int t = 0; t < 4; ++t) {
+        hb[l + 64 * t] = v[0][4 * t];
+        if (t < 3 || l < 52) hb[l + 64 * t + 256] = v[0][4 * t + 1];
+      }
+      NMX_WSYNC();
+      NmxW500TwLds T;
+      T.p = htab + l;
+      const nmx_c2* ht = nmx_w500_hilbert(ha, hb, T, htab + NMX_W500_TW_N, l);
+      float* de = A.env_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W;
+      const nmx_rsrc rs = nmx_make_rsrc(de, 4 * W);
+      NMX_UNROLL
+      for (int t = 0; t < 4; ++t) {
+        NMX_UNROLL
+        for (int r = 0; r < 2; ++r) {
+          const nmx_c2 y = v[0][4 * t + r], h = ht[l + 64 * t + 256 * r];   // (m >= 500: dropped by the range check)
+          const nmx_c2 e = nmx_mk2(sqrtf(y.x * y.x + h.x * h.x), sqrtf(y.y * y.y + h.y * h.y));
+          __builtin_amdgcn_raw_buffer_store_b64(e, rs, 8 * l + 512 * t + 2048 * r, 0, 0);
+        }
+      }
+      NMX_WSYNC();
+    }
+#endif
     // ---- filtered series to HBM (lane-consecutive) ---------------------------------------------
     if (PAD == 0) {
       float* dsw = (F.sw_index >= 0 && !sw_done)
           ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
-      float* dyb = F.burst_index >= 0
+      float* dyb = (F.burst_index >= 0 && !HIL)
           ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
 #ifdef NMX_HOST_EMU
       NMX_LANE_LOOP {
@@ -503,6 +539,7 @@ struct NmxHilbertArgs {
   NmxFft hil_c;     // complex length W
   int hil_full;
   int off_a, off_b, off_y, lds_floats;
+  const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h)
 };
 
 NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* smem) {
@@ -557,3 +594,33 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
   const float2* an = nmx_fft_auto<+1, true>(A.hil_c, Ab, Zbuf, Ab);
   for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
 }
+
+#ifndef NMX_HOST_EMU
+// Hilbert envelope of one length-1000 series per WAVE (same arithmetic as the fused tail of the
+// persistent bank kernel: both call nmx_w500_hilbert with the same tables).
+// LDS per wave: a[500] + b[501] complex.
+#define NMX_W500_LDS_FLOATS (1008 + 1000)
+NMX_DEV void nmx_hilbert_w500_item(const NmxHilbertArgs& A, long long item, float* smem) {
+  const int l = NMX_TID;
+  nmx_c2* hb = (nmx_c2*)smem;
+  nmx_c2* ha = hb + 504;
+  const nmx_rsrc rin = nmx_make_rsrc(A.y + item * 1000, 4000);
+  const nmx_rsrc rout = nmx_make_rsrc(A.env + item * 1000, 4000);
+  NmxW500TwReg T;
+  T.load(A.w500_tab, l);
+  nmx_c2 y[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) y[q] = __builtin_amdgcn_raw_buffer_load_b64(rin, 8 * l + 512 * q, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q < 7 || l < 52) hb[l + 64 * q] = y[q];
+  NMX_WAVE_FENCE();
+  const nmx_c2* ht = nmx_w500_hilbert(ha, hb, T, (const nmx_c2*)A.w500_tab + NMX_W500_TW_N, l);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const nmx_c2 h = ht[l + 64 * q];
+    const nmx_c2 e = nmx_mk2(sqrtf(y[q].x * y[q].x + h.x * h.x), sqrtf(y[q].y * y[q].y + h.y * h.y));
+    __builtin_amdgcn_raw_buffer_store_b64(e, rout, 8 * l + 512 * q, 0, 0);
+  }
+}
+#endif

@@ -11,26 +11,37 @@
 //   * every index is  lane + compile-time constant,  stages are separated by wave-local LDS fences.
 #pragma once
 
-#include "nmx_k_bank_w64.h"
+#include "nmx_device.h"
+
+template <int DIR>
+NMX_DEV nmx_c2 nmx_twd(nmx_c2 t) { return DIR > 0 ? nmx_mk2(t.x, -t.y) : t; }
+
+// Tables of the wave-level transform, built once on the host (nmx_engine.inc: build_hilbert), floats:
+//   tw[i * 64 + lane], i = 0..16 (complex): the 17 twiddles lane `lane` needs --
+//     i = 0..8   stage 2: exp(-2 pi i 5 k r / 500), k = lane % 10, r = i + 1
+//     i = 9..12  stage 3, butterfly j = lane:      exp(-2 pi i j r / 500), r = i - 8
+//     i = 13..16 stage 3, butterfly j = lane + 50: r = i - 12          (lanes >= 50: copies of lane 0)
+//   cs[k], k = 0..499 (complex): (2 cos(2 pi k / 1000), 2 sin(2 pi k / 1000)) / 1000, cs[0] = 0 --
+//     the spectral step of the Hilbert transform (nmx_w500_hilbert)
+#define NMX_W500_TW_N (17 * 64)
+#define NMX_W500_CS_N 500
+#define NMX_W500_TAB_FLOATS (2 * (NMX_W500_TW_N + NMX_W500_CS_N))
 
 #ifndef NMX_HOST_EMU
 
-struct NmxW500Tw {
-  nmx_c2 s2[9];    // stage 2: exp(-2 pi i 5 k r / 500), k = lane % 10, r = 1..9
-  nmx_c2 s3a[4];   // stage 3, butterfly j = lane:      exp(-2 pi i j r / 500), r = 1..4
-  nmx_c2 s3b[4];   // stage 3, butterfly j = lane + 50
-};
-
-NMX_DEV void nmx_w500_load_tw(NmxW500Tw& T, const float2* tw, int lane) {
-  const int l = lane < 50 ? lane : 0, k = l % 10;
+// twiddle providers: registers (loaded once per wave from the global table) or an LDS copy
+struct NmxW500TwReg {
+  nmx_c2 a[17];
+  NMX_DEV void load(const float* tab, int lane) {
 #pragma unroll
-  for (int r = 1; r < 10; ++r) T.s2[r - 1] = nmx_to_c2(tw[(5 * k * r) % 500]);
-#pragma unroll
-  for (int r = 1; r < 5; ++r) {
-    T.s3a[r - 1] = nmx_to_c2(tw[(l * r) % 500]);
-    T.s3b[r - 1] = nmx_to_c2(tw[((l + 50) * r) % 500]);
+    for (int i = 0; i < 17; ++i) a[i] = ((const nmx_c2*)tab)[i * 64 + lane];
   }
-}
+  NMX_DEV nmx_c2 get(int i) const { return a[i]; }
+};
+struct NmxW500TwLds {
+  const nmx_c2* p;   // table + lane
+  NMX_DEV nmx_c2 get(int i) const { return p[64 * i]; }
+};
 
 template <int DIR>
 NMX_DEV void nmx_dft5_c2(nmx_c2& x0, nmx_c2& x1, nmx_c2& x2, nmx_c2& x3, nmx_c2& x4) {
@@ -62,8 +73,8 @@ NMX_DEV void nmx_dft10_c2(nmx_c2* v) {
 }
 
 // in -> a -> b -> a ; returns a (natural order).  `in` may alias b.  All three are wave-private.
-template <int DIR>
-NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const NmxW500Tw& T, int lane) {
+template <int DIR, typename TW>
+NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T, int lane) {
   nmx_c2 v[10];
   if (lane < 50) {
     // stage 1: R = 10, Ns = 1: in[j + 50 r] -> a[10 j + r]
@@ -80,7 +91,7 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const NmxW5
 #pragma unroll
     for (int r = 0; r < 10; ++r) v[r] = a[lane + 50 * r];
 #pragma unroll
-    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul(v[r], nmx_twd<DIR>(T.s2[r - 1]));
+    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul(v[r], nmx_twd<DIR>(T.get(r - 1)));
     nmx_dft10_c2<DIR>(v);
     const int q = lane / 10, k = lane - 10 * q;
     nmx_c2* o = b + 100 * q + k;
@@ -94,11 +105,10 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const NmxW5
     for (int h = 0; h < 2; ++h) {
       const nmx_c2* src = b + lane + 50 * h;
       nmx_c2 x0 = src[0], x1 = src[100], x2 = src[200], x3 = src[300], x4 = src[400];
-      const nmx_c2* w = h ? T.s3b : T.s3a;
-      x1 = nmx_cmul(x1, nmx_twd<DIR>(w[0]));
-      x2 = nmx_cmul(x2, nmx_twd<DIR>(w[1]));
-      x3 = nmx_cmul(x3, nmx_twd<DIR>(w[2]));
-      x4 = nmx_cmul(x4, nmx_twd<DIR>(w[3]));
+      x1 = nmx_cmul(x1, nmx_twd<DIR>(T.get(9 + 4 * h)));
+      x2 = nmx_cmul(x2, nmx_twd<DIR>(T.get(10 + 4 * h)));
+      x3 = nmx_cmul(x3, nmx_twd<DIR>(T.get(11 + 4 * h)));
+      x4 = nmx_cmul(x4, nmx_twd<DIR>(T.get(12 + 4 * h)));
       nmx_dft5_c2<DIR>(x0, x1, x2, x3, x4);
       nmx_c2* o = a + lane + 50 * h;
       o[0] = x0; o[100] = x1; o[200] = x2; o[300] = x3; o[400] = x4;
@@ -108,44 +118,24 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const NmxW5
   return a;
 }
 
-// Hilbert envelope of one length-1000 series per WAVE (same math as nmx_hilbert_item, even-W branch).
-// LDS per wave: a[500] + b[501] complex + ys[1000] floats.
-#define NMX_W500_LDS_FLOATS (1000 + 1004 + 1000)
-NMX_DEV void nmx_hilbert_w500_item(const NmxHilbertArgs& A, long long item, float* smem) {
-  const int lane = NMX_TID;
-  nmx_c2* a = (nmx_c2*)smem;
-  nmx_c2* b = (nmx_c2*)(smem + 1000);
-  float* ys = smem + 2004;
-  const float* src = A.y + item * 1000;
-  float* dst = A.env + item * 1000;
-  NmxW500Tw T;
-  nmx_w500_load_tw(T, A.hil_r.tw, lane);
-  {
-    float* pk = (float*)b;   // packed complex: (x[2i], x[2i+1])
-    nmx_stage_row(src, 1000, [=](int i, float v) { pk[i] = v; ys[i] = v; });
-  }
-  NMX_WAVE_FENCE();
+// Hilbert transform H[y] of a real series of 1000 samples (scipy.signal.hilbert's imaginary part).
+// In: b[m] = (y[2m], y[2m+1]), m < 500.  Out (returned pointer, = a): (H[y][2m], H[y][2m+1]).
+// With Z = FFT_500(b), th = 2 pi k / 1000, the half-length forward split, the multiplication by -i
+// (DC and Nyquist dropped) and the half-length inverse unsplit collapse to
+//     Z'[k] = 2 (cos(th) conj(Z[500 - k]) + i sin(th) Z[k]),   Z'[0] = 0,
+// and H[y] = IFFT_500(Z') / 1000 -- four flops per point with one table (cs, normalisation folded in).
+template <typename TW>
+NMX_DEV const nmx_c2* nmx_w500_hilbert(nmx_c2* a, nmx_c2* b, const TW& T, const nmx_c2* cs, int lane) {
   const nmx_c2* Z = nmx_w500_fft<-1>(b, a, b, T, lane);   // = a
-  // Hermitian half Y[0..500] of the length-1000 real transform -> b (Z = a stays intact)
-  const float2* Zf = (const float2*)Z;
-  float2* Yb = (float2*)b;
-  for (int k = lane; k <= 500; k += 64) Yb[k] = nmx_rfft_bin(Zf, A.hil_r.twr, 500, k);
-  NMX_WAVE_FENCE();
-  // Z'[k] of the half-length inverse of -i Y (DC and Nyquist dropped) -> a
-  float2* Pre = (float2*)a;
-  for (int k = lane; k < 500; k += 64) {
-    const float2 yk = Yb[k], yn = Yb[500 - k];
-    const float2 xk = k == 0 ? make_float2(0.f, 0.f) : make_float2(yk.y, -yk.x);
-    const float2 xn = k == 0 ? make_float2(0.f, 0.f) : make_float2(yn.y, -yn.x);
-    Pre[k] = nmx_irfft_pre(xk, xn, A.hil_r.twr[k]);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = lane + 64 * q;
+    if (k < 500) {
+      const nmx_c2 zk = Z[k], zc = Z[k == 0 ? 0 : 500 - k], w = cs[k];
+      b[k] = nmx_mk2(w.x * zc.x - w.y * zk.y, w.y * zk.x - w.x * zc.y);
+    }
   }
   NMX_WAVE_FENCE();
-  // in = a, first output buffer must differ from the input: a -> b -> a -> b
-  const float* ht = (const float*)nmx_w500_fft<+1>(a, b, a, T, lane);
-  const float invW = 1.f / 1000.f;
-  for (int i = lane; i < 1000; i += 64) {
-    const float re = ys[i], im = ht[i] * invW;
-    dst[i] = sqrtf(re * re + im * im);
-  }
+  return nmx_w500_fft<+1>(b, a, b, T, lane);
 }
 #endif

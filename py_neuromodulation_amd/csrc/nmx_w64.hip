@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // Persistent variant: one workgroup of `nw` waves per CU; the A/B tables of all filters are
 // staged in LDS once per workgroup (instead of being re-fetched from L2 for every item: 27 % of
 // the kernel's time), then every wave walks its own items with wave-local fences only.
-template <int WAVES, int FUSE>
+// HIL = 1: Hilbert envelopes of the burst bands inside the kernel (tables after the twiddles in LDS).
+template <int WAVES, int FUSE, int HIL>
 __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
                                                                                      int n_items, int x_floats,
                                                                                      const NmxSharpArgs S) {
@@ -47,14 +48,17 @@ __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W
     tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
   }
   for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
+  if (HIL)
+    for (int i = threadIdx.x; i < NMX_W500_TAB_FLOATS; i += blockDim.x)
+      tab[tab_floats + NMX_W64_TWL_FLOATS + i] = A.hil_tab[i];
   __syncthreads();
   // readfirstlane: the wave index is wave-uniform, but only this tells the compiler (item-derived
   // addresses, descriptors and branches then live in SGPRs)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + (HIL ? NMX_W500_TAB_FLOATS : 0) + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<0, 1, 0, FUSE>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
+    nmx_bank_w64_item<0, 1, 0, FUSE, HIL>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
 }
 
 // same structure for the notch (odd-reflected window, one filter)
@@ -75,10 +79,11 @@ __global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_notch_w6
     nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
 }
 
-// sharp != nullptr: run the sharp-wave analysis inside the kernel (returns 2 in that case)
+// Return value: 0 = configuration does not fit the persistent kernel (caller falls back), else bit 0 set,
+// bit 1 = the sharp-wave analysis ran inside the kernel (sharp != nullptr), bit 2 = the Hilbert envelopes
+// of the burst bands were written to b.env_out (hil_tab given, W = 1000) instead of the series to yb_out.
 extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu,
                                                        hipStream_t s, const NmxSharpArgs* sharp) {
-  // returns 0 when the configuration does not fit the persistent kernel (caller falls back)
   if (A->b.bp_features & 6u) return 0;
   const bool notch = A->b.pad_mode != 0;
   const int x_floats = A->lds_floats;            // per-wave exchange tile (+ scratch)
@@ -93,41 +98,51 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   }
   if (notch && !notch_on) return 0;
   const int want = notch ? NMX_W64P_WAVES : want_bank;
-  int nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats;
+  bool hil = !notch && !sharp && want == 8 && A->hil_tab && A->b.W == 1000 && A->b.env_out && A->b.n_burst_bands > 0;
+  int nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS - (hil ? NMX_W500_TAB_FLOATS : 0)) / x_floats;
+  if (hil && nw < want) {   // no room for the Hilbert tables next to the filter tables: separate kernel
+    hil = false;
+    nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats;
+  }
   if (nw > want) nw = want;
   if (nw < want) return 0;
   static bool once = false;
   if (!once) {
     once = true;
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + nw * x_floats) * 4;
+  const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + (hil ? NMX_W500_TAB_FLOATS : 0) + nw * x_floats) * 4;
   int grid = n_cu > 0 ? n_cu : 256;
   if (grid * nw > n_items) grid = (n_items + nw - 1) / nw;
   if (notch)
     hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
                        n_items, x_floats);
   else if (sharp && nw == 8) {
-    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
                        n_items, x_floats, *sharp);
-    return 2;
+    return 3;
   } else {
     static const NmxSharpArgs none{};
     if (nw == 11)
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+                         n_items, x_floats, none);
+    else if (hil)
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
     else
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
   }
-  return 1;
+  return hil ? 5 : 1;
 }
 
 extern "C" void NMX_CAT(nmx_w64_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, size_t lds,

@@ -11,7 +11,7 @@
 #include <cstdlib>
 
 #include "nmx_k_bursts.h"
-#include "nmx_k_fft500.h"
+#include "nmx_k_bank_w64.h"
 #include "nmx_k_scan.h"
 #include "nmx_k_sharpwave.h"
 
