@@ -142,6 +142,7 @@ struct NmxTimeOscArgs {
   NmxOsc fft, welch, stft;
   // LDS carve (float offsets)
   int off_x, off_a, off_b, off_spec, off_red, lds_floats;
+  const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h), else NULL
 };
 
 #define NMXD_F_HJORTH (1u << 0)

@@ -19,17 +19,23 @@ NMX_DEV float nmx_from_next_lane(float v, float wrap, int lane) {
   return lane == 63 ? wrap : t;
 }
 
-NMX_DEV void nmx_scan_item(const NmxTimeOscArgs& A, int w, int c) {
-  w = nmx_uniform_i(w);
-  c = nmx_uniform_i(c);
+typedef float nmx_f4 __attribute__((ext_vector_type(4)));
+
+// group k of a lane = samples 4 (lane + 64 k) .. + 3 ; out-of-range dwords read 0
+struct NmxScanRegs {
+  float x[4][6];   // [group][0..3 own samples, 4..5 the two samples that follow]
+  float sum;       // sum of the window (set by nmx_scan_emit)
+};
+
+// window -> registers (w, c wave-uniform)
+NMX_DEV void nmx_scan_load(const NmxTimeOscArgs& A, int w, int c, NmxScanRegs& R) {
   const int lane = (int)(threadIdx.x & 63);
   const int W = A.W;
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
                      (A.starts ? nmx_uniform_ll(A.starts[w]) : 0ll);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4 * W, 0x00020000);
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  // group k of this lane = samples 4 (lane + 64 k) .. + 3 ; out-of-range dwords read 0
-  float x[4][6];   // [group][0..3 own samples, 4..5 the two samples that follow]
+  typedef nmx_f4 f4;
+  float (&x)[4][6] = R.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     f4 v;
@@ -55,6 +61,13 @@ NMX_DEV void nmx_scan_item(const NmxTimeOscArgs& A, int w, int c) {
     x[k][4] = nmx_from_next_lane(x[k][0], w0, lane);
     x[k][5] = nmx_from_next_lane(x[k][1], w1, lane);
   }
+}
+
+// Hjorth / LineLength / Raw of the window held in R -> out (same formulas as nmx_time_osc_item)
+NMX_DEV void nmx_scan_emit(const NmxTimeOscArgs& A, int w, int c, NmxScanRegs& R) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int W = A.W;
+  float (&x)[4][6] = R.x;
   // pass 1: sums of x, dx, d2x and |dx|
   // a group whose last lane still has two successors inside the window needs no masks (wave-uniform
   // test); for W = 1000 that is three of the four groups
@@ -85,6 +98,7 @@ NMX_DEV void nmx_scan_item(const NmxTimeOscArgs& A, int w, int c) {
   auto add = [](float a, float b) { return a + b; };
   p0 = nmx_wave_reduce(p0, 0.f, add); p1 = nmx_wave_reduce(p1, 0.f, add);
   p2 = nmx_wave_reduce(p2, 0.f, add); p3 = nmx_wave_reduce(p3, 0.f, add);
+  R.sum = p0;
   const float m0 = p0 / (float)W, m1 = p1 / (float)(W - 1), m2 = p2 / (float)(W - 2);
   // pass 2: mean-shifted sums of squares from the same registers
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;
@@ -139,5 +153,13 @@ NMX_DEV void nmx_scan_item(const NmxTimeOscArgs& A, int w, int c) {
     }
     if (A.features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = last;
   }
+}
+
+NMX_DEV void nmx_scan_item(const NmxTimeOscArgs& A, int w, int c) {
+  w = nmx_uniform_i(w);
+  c = nmx_uniform_i(c);
+  NmxScanRegs R;
+  nmx_scan_load(A, w, c, R);
+  nmx_scan_emit(A, w, c, R);
 }
 #endif

@@ -1,0 +1,176 @@
+// nmx_k_timeosc_w1000.h -- kernel A for the default shape, ONE WAVE per (window, channel):
+// W = 1000 samples, FFT over the whole window, Welch with one 1000-sample segment, STFT with five
+// 500-sample segments (nperseg 500, hop 250, even boundary), band MEANS only (the default estimator).
+// Any other configuration runs the generic workgroup kernel (nmx_k_timeosc.h); both follow the same
+// reference arithmetic (features/hjorth_raw.py, linelength.py, oscillatory.py -- see nmx_k_timeosc.h).
+//
+// CDNA4 mapping
+//   * the window is loaded ONCE with four range-checked 16-byte buffer loads per lane; Hjorth / LineLength
+//     / Raw come straight from those registers (nmx_k_scan.h), then the window is parked in LDS (4 KB);
+//   * every transform is the wave-level 500-point complex transform of nmx_k_fft500.h (radix 10.10.5,
+//     17 twiddles per lane in VGPRs, wave-local fences, no workgroup barrier):
+//       FFT    the window itself, read as 500 packed complex points          (1 transform)
+//       Welch  (x - mean) * hann, packed                                       (1 transform)
+//       STFT   TWO real segments per transform, z = seg_a + i seg_b, separated afterwards with
+//              A[k] = (Z[k] + conj Z[500-k]) / 2,  B[k] = (Z[k] - conj Z[500-k]) / 2i   (3 transforms)
+//   * band means are accumulated per lane while the bins are produced (no spectrum buffer) and reduced
+//     with DPP wave reductions.
+// LDS per wave: xs[1000] + a[500] + b[501] complex = 12 KB -> 13 waves per CU.
+#pragma once
+
+#include "nmx_k_bank_w64.h"
+#include "nmx_k_scan.h"
+
+#ifndef NMX_HOST_EMU
+
+#define NMX_TOW_LDS_FLOATS (1000 + 1008 + 1008)
+
+// can this configuration run on the wave kernel?  (host side, called by the launcher)
+static inline bool nmx_timeosc_w1000_ok(const NmxTimeOscArgs& A) {
+  if (!A.w500_tab || A.W != 1000 || A.n_bands > 8) return false;
+  auto mean_only = [](const NmxOsc& O) {
+    return !O.complex_full && O.estimators == NMXD_EST_MEAN && !O.return_spectrum;
+  };
+  if (A.fft.enabled && !(mean_only(A.fft) && A.fft.n == 1000)) return false;
+  if (A.welch.enabled && !(mean_only(A.welch) && A.welch.n == 1000 && A.welch.nseg == 1)) return false;
+  if (A.stft.enabled && !(mean_only(A.stft) && A.stft.n == 500 && A.stft.nseg == 5 && A.stft.step == 250 &&
+                          A.stft.half == 250)) return false;
+  return A.fft.enabled || A.welch.enabled || A.stft.enabled;
+}
+
+struct NmxBandAcc {
+  float s[8];
+  NMX_DEV void clear() {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) s[b] = 0.f;
+  }
+  // value v of bin k joins every band whose [lo, hi) holds k
+  NMX_DEV void add(const NmxOsc& O, int n_bands, int k, float v) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
+  }
+  NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b >= n_bands) continue;
+      const float tot = nmx_wave_reduce(s[b], 0.f, [](float a_, float b_) { return a_ + b_; });
+      const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
+      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot / (float)cnt : NAN;
+    }
+  }
+};
+
+NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float* smem) {
+  w = nmx_uniform_i(w);
+  c = nmx_uniform_i(c);
+  const int lane = (int)(threadIdx.x & 63);
+  float* xs = smem;                              // [1000] the window, natural order
+  nmx_c2* fa = (nmx_c2*)(smem + 1000);           // [500]
+  nmx_c2* fb = (nmx_c2*)(smem + 2008);           // [501]
+  float* out_row = A.out + (long long)w * A.n_outputs;
+  const int nb = A.n_bands;
+
+  NmxScanRegs R;
+  nmx_scan_load(A, w, c, R);
+  NmxW500TwReg T;
+  T.load(A.w500_tab, lane);
+  R.sum = 0.f;
+  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) {
+    nmx_scan_emit(A, w, c, R);
+  } else if (A.welch.enabled) {
+    float p0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p0 += (R.x[k][0] + R.x[k][1]) + (R.x[k][2] + R.x[k][3]);   // out-of-range samples are 0
+    R.sum = nmx_wave_reduce(p0, 0.f, [](float a_, float b_) { return a_ + b_; });
+  }
+  // park the window in LDS (group 3: lanes 0..57)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
+  NMX_WAVE_FENCE();
+
+  NmxBandAcc acc;
+  // ---- FFT band power: |rfft(x)| -> log10 -> band means ---------------------------------------------
+  if (A.fft.enabled) {
+    const NmxOsc& O = A.fft;
+    const float2* Z = (const float2*)nmx_w500_fft<-1>((const nmx_c2*)xs, fa, fb, T, lane);
+    acc.clear();
+    for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+      const float2 X = nmx_rfft_bin(Z, O.fft.twr, 500, k);
+      float v = sqrtf(X.x * X.x + X.y * X.y);
+      if (O.log_transform) v = log10f(v);
+      acc.add(O, nb, k, v);
+    }
+    acc.emit(O, nb, 1, out_row, c, lane);
+    NMX_WAVE_FENCE();
+  }
+  // ---- Welch: one segment = the window; constant detrend, hann, density scaling ---------------------
+  if (A.welch.enabled) {
+    const NmxOsc& O = A.welch;
+    const float mean = R.sum / 1000.f;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 4000, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rw, 16 * lane + 1024 * k, 0, 0);
+      const nmx_f4 y = {(R.x[k][0] - mean) * __uint_as_float(r.x), (R.x[k][1] - mean) * __uint_as_float(r.y),
+                        (R.x[k][2] - mean) * __uint_as_float(r.z), (R.x[k][3] - mean) * __uint_as_float(r.w)};
+      if (k < 3 || lane < 58) ((nmx_f4*)fb)[lane + 64 * k] = y;
+    }
+    NMX_WAVE_FENCE();
+    const float2* Z = (const float2*)nmx_w500_fft<-1>(fb, fa, fb, T, lane);
+    acc.clear();
+    for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+      const float2 X = nmx_rfft_bin(Z, O.fft.twr, 500, k);
+      float p = (X.x * X.x + X.y * X.y) * O.scale;
+      if (!(k == 0 || k == 500)) p *= 2.f;
+      if (O.log_transform) p = log10f(p);
+      acc.add(O, nb, k, p);
+    }
+    acc.emit(O, nb, 1, out_row, c, lane);
+    NMX_WAVE_FENCE();
+  }
+  // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
+  if (A.stft.enabled) {
+    const NmxOsc& O = A.stft;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 2000, 0x00020000);
+    float hw[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hw[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, 4 * lane + 256 * q, 0, 0));
+    acc.clear();
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = lane + 64 * q;
+        if (i < 500) {
+          float va, vb;
+          if (pr == 0) { va = xs[i < 250 ? 250 - i : i - 250]; vb = xs[i]; }              // segments 0, 1
+          else if (pr == 1) { va = xs[i + 250]; vb = xs[i + 500]; }                        // segments 2, 3
+          else { va = xs[i < 250 ? 750 + i : 1248 - i]; vb = 0.f; }                        // segment 4
+          fb[i] = nmx_mk2(va * hw[q], vb * hw[q]);
+        }
+      }
+      NMX_WAVE_FENCE();
+      const nmx_c2* Z = nmx_w500_fft<-1>(fb, fa, fb, T, lane);
+      for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+        const nmx_c2 zk = Z[k == 500 ? 0 : k], zn = Z[k == 0 ? 0 : 500 - k];
+        // A = (zk + conj zn) / 2,  B = -i (zk - conj zn) / 2
+        const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
+        const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+        float va = sqrtf(ax * ax + ay * ay) * O.scale;
+        if (O.log_transform) va = log10f(va);
+        acc.add(O, nb, k, va);
+        if (pr < 2) {
+          float vb = sqrtf(bx * bx + by * by) * O.scale;
+          if (O.log_transform) vb = log10f(vb);
+          acc.add(O, nb, k, vb);
+        }
+      }
+      NMX_WAVE_FENCE();
+    }
+    acc.emit(O, nb, 5, out_row, c, lane);
+  }
+}
+#endif

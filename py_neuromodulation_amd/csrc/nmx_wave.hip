@@ -13,6 +13,7 @@
 #include "nmx_k_bursts.h"
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_scan.h"
+#include "nmx_k_timeosc_w1000.h"
 #include "nmx_k_sharpwave.h"
 
 extern __shared__ __attribute__((aligned(16))) float nmx_smem_wave[];
@@ -40,6 +41,19 @@ __global__ void __launch_bounds__(64) nmx_kern_hilbert_w500(const NmxHilbertArgs
 
 extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long n_items, hipStream_t s) {
   hipLaunchKernelGGL(nmx_kern_hilbert_w500, dim3((unsigned)n_items), dim3(64), (size_t)NMX_W500_LDS_FLOATS * 4, s, *A);
+}
+
+// time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
+__global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
+  const int item = blockIdx.x;
+  nmx_timeosc_w1000_item(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+}
+
+// returns 0 when the configuration needs the generic kernel
+extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
+  if (!nmx_timeosc_w1000_ok(*A)) return 0;
+  hipLaunchKernelGGL(nmx_kern_timeosc_w1000, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+  return 1;
 }
 
 // register-resident scan (Hjorth / Raw / LineLength only): four waves per workgroup, no LDS
