@@ -190,7 +190,7 @@ def main() -> None:
                          "traffic": traffic,
                          "note": "FIR bank is LDS/FP32-vector bound (SURVEY 8d); frac is vs the HBM roof"},
         }
-        if args.cpu_windows > 0:
+        if args.cpu_windows > 0 and world == 1:   # CPU baseline: rank 0 at N = 1 only
             v, secs = cpu_baseline(s, C, sfreq, args.cpu_windows, 99)
             res["cpu_baseline"] = {"value": v, "unit": "windows/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_windows} hops of the same {C}-channel workload "
