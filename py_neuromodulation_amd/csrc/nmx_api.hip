@@ -259,8 +259,13 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt
   if (fixed_ok && nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
 }
-static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s);
+// windows_seen: hops every sequence has absorbed before this batch (-1: always the workgroup kernel)
+static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s,
+                                long long windows_seen = -1) {
   be_init_once();
+  // ring already full at the first hop: the barrier-free one-wave walk over the list in L2
+  if (windows_seen > 0 && nmx_burst_thr_wave_ok(A, windows_seen)) { nmx_wave_launch_burst_thr(&A, n_items, s); return; }
   const int chunk = (A.K + nt - 1) / nt;
   if (chunk <= 32) hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A);
   else if (chunk <= 64) hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A);

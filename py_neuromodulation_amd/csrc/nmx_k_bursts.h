@@ -344,6 +344,213 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
   }
 }
 
+#ifndef NMX_HOST_EMU
+// ---------------------------------------------------------------------------------------
+// Steady regime of the threshold walk with ONE WAVE per (channel, band).
+//
+// The 256-thread kernel above spends ~1.5 us per hop in workgroup barriers, LDS atomics and one-hop-deep
+// global loads, and its 8 waves x 169 VGPRs + 100 KB of LDS per CU starve the throughput kernels that
+// run next to it.  When the ring is already full at the first hop of a batch (the host knows: it counts the
+// hops) the same algorithm runs here without any barrier:
+//   * the new samples of a hop are two registers per lane (overlap <= 128), loaded NMX_THRW_PF hops ahead;
+//   * classification is two ballots; a hop without a sample above the smallest kept value (most hops once
+//     the history is long) costs a ballot, a compare and the store of the unchanged threshold;
+//   * fringe update and the pending list use mbcnt compaction and wave-local LDS fences;
+//   * the sorted top-K list never leaves its global state array (L2): a flush streams it once, block by
+//     block from the top, shifting every entry up by the number of pending samples that sort before it
+//     (binary search in the sorted pending list in LDS) -- all loads independent, no dependent chains.
+// 17 KB of LDS and one wave per sequence.  Same values as nmx_burst_thr_item, bit for bit.
+#define NMX_THRW_PF 8
+#define NMX_THRW_I 128
+#define NMX_THRW_LDS_FLOATS (2 * NMX_THR_F + 3 * NMX_THR_P + NMX_THRW_I)
+
+// number of entries of the DESCENDING list l[0..n) that are > v
+NMX_DEV int nmx_count_gt_lds(const float* l, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (l[mid] > v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// host-side test: may the wave kernel take this batch?  (first hop already in the steady regime)
+static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long windows_seen) {
+  if (windows_seen <= 0 || A.overlap > 128 || A.overlap + 8 >= NMX_THR_FREFILL) return false;
+  const long long total = (long long)A.W + (windows_seen - 1) * (long long)A.overlap;
+  const long long m_ring = A.n_ring;
+  const double pos_ring = A.q * (double)(m_ring - 1);
+  const long long lo_ring = (long long)floor(pos_ring);
+  const int ia_ring = (int)(m_ring - 1 - lo_ring);
+  return A.K > 2 * NMX_THR_F && total >= m_ring && ia_ring >= A.K - 3 && ia_ring < A.K;
+}
+
+NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
+  const int lane = (int)(threadIdx.x & 63);
+  float* F = smem;                          // [NMX_THR_F] ascending fringe
+  float* F2 = F + NMX_THR_F;
+  float* Pp = F2 + NMX_THR_F;               // [NMX_THR_P] pending, unsorted
+  float* ps = Pp + NMX_THR_P;               // [NMX_THR_P] pending, sorted descending (flush)
+  int* ins = (int*)(ps + NMX_THR_P);        // [NMX_THR_P] insertion indices (flush)
+  float* I = (float*)(ins + NMX_THR_P);     // [NMX_THRW_I] this hop's fringe inserts
+  const int K = A.K, W = A.W, ov = A.overlap;
+  const long long sidx = (long long)c * A.n_bands + bi;
+  float* L = A.top + sidx * K;              // descending top-K list (global, L2 resident)
+  long long total = A.counts[2 * sidx];
+  long long nwin = A.counts[2 * sidx + 1];
+  const long long m_ring = A.n_ring;
+  const double pos_ring = A.q * (double)(m_ring - 1);
+  const long long lo_ring = (long long)floor(pos_ring);
+  const double frac_ring = pos_ring - (double)lo_ring;
+  const int ja = K - 1 - (int)(m_ring - 1 - lo_ring);   // ascending fringe index of s[lo]: 0, 1 or 2
+
+  // enter: cut the fringe from the list's tail
+  int nF = NMX_THR_FREFILL, Lm = K - nF, nP = 0;
+  for (int j = lane; j < nF; j += 64) F[j] = L[K - 1 - j];
+  NMX_WAVE_FENCE();
+  float T = F[0], Fmax = F[nF - 1];
+  float thr_cur = nmx_lerp_thr((double)F[ja], (double)F[ja + 1], frac_ring, true);
+
+  const long long hop_stride = (long long)A.n_channels * A.n_bands * W;
+  const float* e0 = A.env + ((long long)c * A.n_bands + bi) * W + (W - ov);
+  const bool v0 = lane < ov, v1 = lane + 64 < ov;
+  float na[NMX_THRW_PF], nb[NMX_THRW_PF];   // samples of the next NMX_THRW_PF hops
+#pragma unroll
+  for (int u = 0; u < NMX_THRW_PF; ++u) {
+    const float* e = e0 + (long long)u * hop_stride;
+    const bool in = u < A.n_windows;
+    na[u] = (in && v0) ? e[lane] : -INFINITY;
+    nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
+  }
+  for (int w0 = 0; w0 < A.n_windows; w0 += NMX_THRW_PF) {
+    float xa[NMX_THRW_PF], xb[NMX_THRW_PF];
+#pragma unroll
+    for (int u = 0; u < NMX_THRW_PF; ++u) { xa[u] = na[u]; xb[u] = nb[u]; }
+#pragma unroll
+    for (int u = 0; u < NMX_THRW_PF; ++u) {   // in flight while this group of hops is processed
+      const int w = w0 + NMX_THRW_PF + u;
+      const float* e = e0 + (long long)w * hop_stride;
+      const bool in = w < A.n_windows;
+      na[u] = (in && v0) ? e[lane] : -INFINITY;
+      nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < NMX_THRW_PF; ++u) {
+      const int w = w0 + u;
+      if (w >= A.n_windows) break;
+      const float x0 = xa[u], x1 = xb[u];
+      const bool c0 = x0 > T, c1 = x1 > T;
+      const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
+      const int a = __popcll(b0) + __popcll(b1);
+      if (a) {
+        const bool i0 = c0 && x0 <= Fmax, i1 = c1 && x1 <= Fmax;
+        const unsigned long long bi0 = __ballot(i0), bi1 = __ballot(i1);
+        const unsigned long long bp0 = b0 & ~bi0, bp1 = b1 & ~bi1;
+        const int nI = __popcll(bi0) + __popcll(bi1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (i0) I[__popcll(bi0 & below)] = x0;
+        if (i1) I[__popcll(bi0) + __popcll(bi1 & below)] = x1;
+        if (c0 && !i0) Pp[nP + __popcll(bp0 & below)] = x0;
+        if (c1 && !i1) Pp[nP + __popcll(bp0) + __popcll(bp1 & below)] = x1;
+        nP += __popcll(bp0) + __popcll(bp1);
+        NMX_WAVE_FENCE();
+        // new fringe = (F u I) minus its a smallest; ties: fringe entries first
+        for (int i = lane; i < nF; i += 64) {
+          const float v = F[i];
+          int lt = 0;
+          for (int r = 0; r < nI; ++r) lt += (I[r] < v);
+          const int idx = i + lt - a;
+          if (idx >= 0) F2[idx] = v;
+        }
+        for (int r = lane; r < nI; r += 64) {
+          const float v = I[r];
+          int rank = 0;   // among the insert candidates (ascending, stable)
+          for (int j = 0; j < nI; ++j) rank += (I[j] < v) || (I[j] == v && j < r);
+          int lo2 = 0, hi2 = nF;   // fringe entries <= v
+          while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (F[mid] <= v) lo2 = mid + 1; else hi2 = mid; }
+          const int idx = rank + lo2 - a;
+          if (idx >= 0) F2[idx] = v;
+        }
+        nF = nF + nI - a;
+        { float* tsw = F; F = F2; F2 = tsw; }
+        NMX_WAVE_FENCE();
+        T = F[0];
+        Fmax = F[nF - 1];
+        thr_cur = nmx_lerp_thr((double)F[ja], (double)F[ja + 1], frac_ring, true);
+      }
+      total += ov;
+      nwin += 1;
+      if (lane == 0) A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] = thr_cur;
+      // flush when the fringe could run dry or the pending list could overflow on the next hop
+      if (nF < ov + 8 || nP + ov > NMX_THR_P || w + 1 == A.n_windows) {
+        // (1) pending -> ps, sorted descending (rank by counting; equal values: lower index first)
+        const int n4 = (nP + 3) & ~3;
+        for (int i = nP + lane; i < n4; i += 64) Pp[i] = -INFINITY;
+        for (int j = lane; j < nP; j += 64) ins[j] = Lm;   // default: after every entry of L_main
+        NMX_WAVE_FENCE();
+        for (int t = lane; t < nP; t += 64) {
+          const float v = Pp[t];
+          int rank = 0;
+          for (int j = 0; j < n4; j += 4) {
+            const float u0 = Pp[j], u1 = Pp[j + 1], u2 = Pp[j + 2], u3 = Pp[j + 3];
+            rank += (u0 > v) || (u0 == v && j < t);
+            rank += (u1 > v) || (u1 == v && j + 1 < t);
+            rank += (u2 > v) || (u2 == v && j + 2 < t);
+            rank += (u3 > v) || (u3 == v && j + 3 < t);
+          }
+          ps[rank] = v;
+        }
+        NMX_WAVE_FENCE();
+        // (2) stream L_main from its last block to its first: entry i moves to i + cnt(i), cnt(i) = pending
+        // samples > L[i] (equal values: list entries first).  Stores only go to addresses at or above
+        // the block they come from, so the blocks loaded ahead (lower addresses) are never clobbered.
+        if (nP > 0) {
+          const int nblk = (Lm + 63) >> 6;
+          for (int bb = nblk - 1; bb >= 0; bb -= 4) {
+            float v[4], vp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = 64 * (bb - q) + lane;
+              v[q] = (bb - q >= 0 && i < Lm) ? L[i] : 0.f;
+              vp[q] = (bb - q >= 0 && lane == 0 && i > 0) ? L[i - 1] : 0.f;   // lane 0: its predecessor's value
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = 64 * (bb - q) + lane;
+              const bool ok = bb - q >= 0 && i < Lm;
+              const int cnt = ok ? nmx_count_gt_lds(ps, nP, v[q]) : 0;
+              int cprev = __builtin_amdgcn_update_dpp(0, cnt, 0x138, 0xf, 0xf, false);   // wave_shr:1
+              if (lane == 0) cprev = (ok && i > 0) ? nmx_count_gt_lds(ps, nP, vp[q]) : 0;
+              if (ok) {
+                for (int j = cprev; j < cnt; ++j) ins[j] = i;   // pending samples j sort right before entry i
+                if (cnt) L[i + cnt] = v[q];
+              }
+            }
+          }
+          NMX_WAVE_FENCE();
+          for (int j = lane; j < nP; j += 64) L[ins[j] + j] = ps[j];
+        }
+        Lm += nP;
+        for (int j = lane; j < nF; j += 64) L[Lm + j] = F[nF - 1 - j];
+        // (Lm + nF == K by construction)
+        __threadfence();   // the re-cut below reads what this wave just stored
+        nF = NMX_THR_FREFILL;
+        Lm = K - nF;
+        nP = 0;
+        for (int j = lane; j < nF; j += 64) F[j] = L[K - 1 - j];
+        NMX_WAVE_FENCE();
+        T = F[0];
+        Fmax = F[nF - 1];
+      }
+    }
+  }
+  if (lane == 0) {
+    A.counts[2 * sidx] = total;
+    A.counts[2 * sidx + 1] = nwin;
+  }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 struct NmxBurstStatArgs {
   const float* env;   // [n_windows][C][Bb][W]

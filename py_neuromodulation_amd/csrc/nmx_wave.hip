@@ -34,6 +34,17 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
 }
 
+// threshold walk, steady regime: one wave per (channel, band)
+__global__ void __launch_bounds__(64) nmx_kern_burst_thr_wave(const NmxBurstThrArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // sequential and on the critical path: win issue arbitration
+  const int item = blockIdx.x;
+  nmx_burst_thr_wave_item(A, item / A.n_bands, item % A.n_bands, nmx_smem_wave);
+}
+
+extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s) {
+  hipLaunchKernelGGL(nmx_kern_burst_thr_wave, dim3(n_items), dim3(64), (size_t)NMX_THRW_LDS_FLOATS * 4, s, *A);
+}
+
 // Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)
 __global__ void __launch_bounds__(64) nmx_kern_hilbert_w500(const NmxHilbertArgs A) {
   nmx_hilbert_w500_item(A, (long long)blockIdx.x, nmx_smem_wave);

@@ -83,7 +83,7 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int, s
   std::vector<float> sm(lds / 4 + 16);
   for (long long it = 0; it < n_items; ++it) nmx_hilbert_item(A, it, sm.data());
 }
-static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size_t lds, be_stream_t) {
+static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size_t lds, be_stream_t, long long = -1) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_burst_thr_item<1>(A, it / A.n_bands, it % A.n_bands, sm.data());
 }

@@ -322,3 +322,47 @@ def test_linearity_of_the_filter_stages(gpu_lib):
     assert fx.shape == (C, int(eng.desc.n_filters), W)
     np.testing.assert_allclose(fz, a * fx + b * fy, rtol=0, atol=3e-6 * scale)
     eng.close()
+
+
+def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
+    """The burst threshold walk has two implementations: the 256-thread workgroup kernel (fill regime and
+    transitions) and the barrier-free one-wave kernel used when the 30 s ring is already full at the first
+    hop of a batch.  Both move the same values around, so every burst feature must agree BIT FOR BIT over a
+    long stream (default ring: 291 fill hops, then steady), fed in chunks of 128 hops, in uneven batches and
+    with a state export / import in the middle."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    sfreq, C, n_hops = 1000.0, 3, 900
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(5)
+    t = np.arange(T) / sfreq
+    amp = 1 + 0.8 * np.sin(2 * np.pi * 0.05 * t) + 2 * t / t[-1]          # slowly growing power: steady inserts
+    data = (rng.standard_normal((C, T)) * 20 + 30 * amp * np.sin(2 * np.pi * 18 * t)).astype(np.float32)
+    data[1] *= 1e-3                                                        # tiny amplitudes
+    data[2] = np.round(data[2])                                            # many equal values (ties)
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * 100
+    monkeypatch.setenv("NMX_CHUNK_WINDOWS", "128")
+
+    def run(wave, plan, export_at=None):
+        monkeypatch.setenv("NMX_THR_WAVE", "1" if wave else "0")
+        eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib, features=["bursts"], bank_taps=None)
+        rows, i = [], 0
+        for n in plan:
+            if export_at is not None and i == export_at:
+                blob = eng.export_state()
+                eng.close()
+                eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib, features=["bursts"], bank_taps=None)
+                eng.import_state(blob)
+            rows.append(eng.process_batch(data, starts[i:i + n]))
+            i += n
+        eng.close()
+        return np.concatenate(rows)
+
+    want = run(False, [n_hops])
+    assert not np.isnan(want).any()
+    np.testing.assert_array_equal(run(True, [n_hops]), want)
+    np.testing.assert_array_equal(run(True, [300, 1, 7, 292, 300]), want)
+    np.testing.assert_array_equal(run(True, [450, 450], export_at=450), want)
