@@ -360,9 +360,10 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
 //     block from the top, shifting every entry up by the number of pending samples that sort before it
 //     (binary search in the sorted pending list in LDS) -- all loads independent, no dependent chains.
 // 17 KB of LDS and one wave per sequence.  Same values as nmx_burst_thr_item, bit for bit.
-#define NMX_THRW_PF 8
+#define NMX_THRW_PF 16
 #define NMX_THRW_I 128
-#define NMX_THRW_LDS_FLOATS (2 * NMX_THR_F + 3 * NMX_THR_P + NMX_THRW_I)
+// + K / 64 + 2 block counters (launcher)
+#define NMX_THRW_LDS_FLOATS (2 * NMX_THR_F + 3 * NMX_THR_P + NMX_THRW_I + NMX_THRW_PF * 128)
 
 // number of entries of the DESCENDING list l[0..n) that are > v
 NMX_DEV int nmx_count_gt_lds(const float* l, int n, float v) {
@@ -385,14 +386,25 @@ static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long win
   return A.K > 2 * NMX_THR_F && total >= m_ring && ia_ring >= A.K - 3 && ia_ring < A.K;
 }
 
+#ifdef NMX_THRW_PROFILE
+#define NMX_TP(i) { const long long t_ = clock64(); tp[i] += t_ - tlast; tlast = t_; }
+#else
+#define NMX_TP(i)
+#endif
 NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
   const int lane = (int)(threadIdx.x & 63);
-  float* F = smem;                          // [NMX_THR_F] ascending fringe
+#ifdef NMX_THRW_PROFILE
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  int n_ins = 0, n_flush = 0;
+#endif
+  float* F = smem;                          // [NMX_THR_F] ascending fringe: entries F[fh .. fh + nF)
   float* F2 = F + NMX_THR_F;
   float* Pp = F2 + NMX_THR_F;               // [NMX_THR_P] pending, unsorted
   float* ps = Pp + NMX_THR_P;               // [NMX_THR_P] pending, sorted descending (flush)
   int* ins = (int*)(ps + NMX_THR_P);        // [NMX_THR_P] insertion indices (flush)
   float* I = (float*)(ins + NMX_THR_P);     // [NMX_THRW_I] this hop's fringe inserts
+  float* stage = I + NMX_THRW_I;            // [NMX_THRW_PF][128] new samples of the current group of hops
+  int* cb = (int*)(stage + NMX_THRW_PF * 128);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
   const int K = A.K, W = A.W, ov = A.overlap;
   const long long sidx = (long long)c * A.n_bands + bi;
   float* L = A.top + sidx * K;              // descending top-K list (global, L2 resident)
@@ -405,7 +417,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
   const int ja = K - 1 - (int)(m_ring - 1 - lo_ring);   // ascending fringe index of s[lo]: 0, 1 or 2
 
   // enter: cut the fringe from the list's tail
-  int nF = NMX_THR_FREFILL, Lm = K - nF, nP = 0;
+  int nF = NMX_THR_FREFILL, fh = 0, Lm = K - nF, nP = 0;
   for (int j = lane; j < nF; j += 64) F[j] = L[K - 1 - j];
   NMX_WAVE_FENCE();
   float T = F[0], Fmax = F[nF - 1];
@@ -423,9 +435,10 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
     nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
   }
   for (int w0 = 0; w0 < A.n_windows; w0 += NMX_THRW_PF) {
-    float xa[NMX_THRW_PF], xb[NMX_THRW_PF];
+    // the group's samples go to LDS so that the hop loop below stays ROLLED (one copy of the insert and
+    // flush code)
 #pragma unroll
-    for (int u = 0; u < NMX_THRW_PF; ++u) { xa[u] = na[u]; xb[u] = nb[u]; }
+    for (int u = 0; u < NMX_THRW_PF; ++u) { stage[128 * u + lane] = na[u]; stage[128 * u + 64 + lane] = nb[u]; }
 #pragma unroll
     for (int u = 0; u < NMX_THRW_PF; ++u) {   // in flight while this group of hops is processed
       const int w = w0 + NMX_THRW_PF + u;
@@ -434,116 +447,216 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
       na[u] = (in && v0) ? e[lane] : -INFINITY;
       nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
     }
-#pragma unroll
-    for (int u = 0; u < NMX_THRW_PF; ++u) {
+    NMX_WAVE_FENCE();
+    NMX_TP(0)   // group top: wait for the prefetched samples, stage them, issue the next loads
+    const int ng = (A.n_windows - w0) < NMX_THRW_PF ? (A.n_windows - w0) : NMX_THRW_PF;
+#pragma nounroll
+    for (int u = 0; u < ng; ++u) {
       const int w = w0 + u;
-      if (w >= A.n_windows) break;
-      const float x0 = xa[u], x1 = xb[u];
+      const float x0 = stage[128 * u + lane], x1 = stage[128 * u + 64 + lane];
       const bool c0 = x0 > T, c1 = x1 > T;
       const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
       const int a = __popcll(b0) + __popcll(b1);
+      NMX_TP(1)   // classify
       if (a) {
         const bool i0 = c0 && x0 <= Fmax, i1 = c1 && x1 <= Fmax;
         const unsigned long long bi0 = __ballot(i0), bi1 = __ballot(i1);
         const unsigned long long bp0 = b0 & ~bi0, bp1 = b1 & ~bi1;
         const int nI = __popcll(bi0) + __popcll(bi1);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (i0) I[__popcll(bi0 & below)] = x0;
-        if (i1) I[__popcll(bi0) + __popcll(bi1 & below)] = x1;
         if (c0 && !i0) Pp[nP + __popcll(bp0 & below)] = x0;
         if (c1 && !i1) Pp[nP + __popcll(bp0) + __popcll(bp1 & below)] = x1;
         nP += __popcll(bp0) + __popcll(bp1);
-        NMX_WAVE_FENCE();
-        // new fringe = (F u I) minus its a smallest; ties: fringe entries first
-        for (int i = lane; i < nF; i += 64) {
-          const float v = F[i];
-          int lt = 0;
-          for (int r = 0; r < nI; ++r) lt += (I[r] < v);
-          const int idx = i + lt - a;
-          if (idx >= 0) F2[idx] = v;
+        if (nI == 0) {
+          // every accepted sample lies above the fringe: the a smallest fringe entries are evicted and
+          // nothing moves -- advance the head
+          fh += a;
+          nF -= a;
+        } else {
+          if (i0) I[__popcll(bi0 & below)] = x0;
+          if (i1) I[__popcll(bi0) + __popcll(bi1 & below)] = x1;
+          NMX_WAVE_FENCE();
+          // new fringe = (F u I) minus its a smallest; ties: fringe entries first
+          const float* Fc = F + fh;
+          if (nI <= 8) {
+            // the inserts fit in eight wave-uniform registers -> no dependent LDS chains.  Fringe entry i
+            // moves to i + #(inserts < F[i]) - a; insert r lands at #(inserts before it) + #(F <= I[r]) - a,
+            // the second count taken with ballots in the same pass.
+            float iv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) iv[r] = r < nI ? I[r] : INFINITY;
+            float fv[NMX_THR_F / 64];
+#pragma unroll
+            for (int q = 0; q < NMX_THR_F / 64; ++q) fv[q] = (lane + 64 * q < nF) ? Fc[lane + 64 * q] : INFINITY;
+            int le[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) le[r] = 0;
+#pragma unroll
+            for (int q = 0; q < NMX_THR_F / 64; ++q) {
+              if (64 * q >= nF) break;
+              const float v = fv[q];
+              int lt = 0;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                lt += (iv[r] < v);
+                le[r] += __popcll(__ballot(v <= iv[r]));   // (padding lanes hold +inf)
+              }
+              const int idx = lane + 64 * q + lt - a;
+              if (lane + 64 * q < nF && idx >= 0) F2[idx] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              if (r >= nI) break;
+              int rank = 0;   // among the insert candidates (ascending, stable)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) rank += (iv[j] < iv[r]) || (iv[j] == iv[r] && j < r);
+              const int idx = rank + le[r] - a;
+              if (lane == 0 && idx >= 0) F2[idx] = iv[r];
+            }
+          } else {
+            for (int i = lane; i < nF; i += 64) {
+              const float v = Fc[i];
+              int lt = 0;
+              for (int r = 0; r < nI; ++r) lt += (I[r] < v);
+              const int idx = i + lt - a;
+              if (idx >= 0) F2[idx] = v;
+            }
+            for (int r = lane; r < nI; r += 64) {
+              const float v = I[r];
+              int rank = 0;   // among the insert candidates (ascending, stable)
+              for (int j = 0; j < nI; ++j) rank += (I[j] < v) || (I[j] == v && j < r);
+              int lo2 = 0, hi2 = nF;   // fringe entries <= v
+              while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (Fc[mid] <= v) lo2 = mid + 1; else hi2 = mid; }
+              const int idx = rank + lo2 - a;
+              if (idx >= 0) F2[idx] = v;
+            }
+          }
+          nF = nF + nI - a;
+          fh = 0;
+          { float* tsw = F; F = F2; F2 = tsw; }
+          NMX_WAVE_FENCE();
         }
-        for (int r = lane; r < nI; r += 64) {
-          const float v = I[r];
-          int rank = 0;   // among the insert candidates (ascending, stable)
-          for (int j = 0; j < nI; ++j) rank += (I[j] < v) || (I[j] == v && j < r);
-          int lo2 = 0, hi2 = nF;   // fringe entries <= v
-          while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (F[mid] <= v) lo2 = mid + 1; else hi2 = mid; }
-          const int idx = rank + lo2 - a;
-          if (idx >= 0) F2[idx] = v;
-        }
-        nF = nF + nI - a;
-        { float* tsw = F; F = F2; F2 = tsw; }
-        NMX_WAVE_FENCE();
-        T = F[0];
-        Fmax = F[nF - 1];
-        thr_cur = nmx_lerp_thr((double)F[ja], (double)F[ja + 1], frac_ring, true);
+        T = F[fh];
+        thr_cur = nmx_lerp_thr((double)F[fh + ja], (double)F[fh + ja + 1], frac_ring, true);
+#ifdef NMX_THRW_PROFILE
+        ++n_ins;
+#endif
+        NMX_TP(2)   // fringe update
       }
       total += ov;
       nwin += 1;
       if (lane == 0) A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] = thr_cur;
       // flush when the fringe could run dry or the pending list could overflow on the next hop
       if (nF < ov + 8 || nP + ov > NMX_THR_P || w + 1 == A.n_windows) {
+        NMX_TP(3)   // threshold store + bookkeeping
         // (1) pending -> ps, sorted descending (rank by counting; equal values: lower index first)
         const int n4 = (nP + 3) & ~3;
         for (int i = nP + lane; i < n4; i += 64) Pp[i] = -INFINITY;
-        for (int j = lane; j < nP; j += 64) ins[j] = Lm;   // default: after every entry of L_main
         NMX_WAVE_FENCE();
-        for (int t = lane; t < nP; t += 64) {
-          const float v = Pp[t];
+        for (int t0 = 0; t0 < nP; t0 += 64) {
+          // rank of (v, t) in the order "larger value first, equal values: lower index first".  For the
+          // lanes of one round the index test is wave-uniform outside the round's own 64 entries:
+          // j < t0 -> count u >= v,  j >= t0 + 64 -> count u > v  (two instructions per entry)
+          const int t = t0 + lane;
+          const float v = t < nP ? Pp[t] : 0.f;
           int rank = 0;
-          for (int j = 0; j < n4; j += 4) {
+#pragma unroll 2
+          for (int j = 0; j < t0; j += 4) {
+            const float u0 = Pp[j], u1 = Pp[j + 1], u2 = Pp[j + 2], u3 = Pp[j + 3];
+            rank += (u0 >= v); rank += (u1 >= v); rank += (u2 >= v); rank += (u3 >= v);
+          }
+          const int t1 = (t0 + 64) < n4 ? (t0 + 64) : n4;
+          for (int j = t0; j < t1; j += 4) {
             const float u0 = Pp[j], u1 = Pp[j + 1], u2 = Pp[j + 2], u3 = Pp[j + 3];
             rank += (u0 > v) || (u0 == v && j < t);
             rank += (u1 > v) || (u1 == v && j + 1 < t);
             rank += (u2 > v) || (u2 == v && j + 2 < t);
             rank += (u3 > v) || (u3 == v && j + 3 < t);
           }
-          ps[rank] = v;
+#pragma unroll 2
+          for (int j = t1; j < n4; j += 4) {
+            const float u0 = Pp[j], u1 = Pp[j + 1], u2 = Pp[j + 2], u3 = Pp[j + 3];
+            rank += (u0 > v); rank += (u1 > v); rank += (u2 > v); rank += (u3 > v);
+          }
+          if (t < nP) ps[rank] = v;
         }
         NMX_WAVE_FENCE();
-        // (2) stream L_main from its last block to its first: entry i moves to i + cnt(i), cnt(i) = pending
-        // samples > L[i] (equal values: list entries first).  Stores only go to addresses at or above
-        // the block they come from, so the blocks loaded ahead (lower addresses) are never clobbered.
+        NMX_TP(4)   // flush: sort
+        // (2) merge into L_main in place.  Entry i moves to i + cnt(i), cnt(i) = pending samples > L[i]
+        // (equal values: list entries first); pending sample j lands at ins[j] + j, ins[j] = list entries
+        // >= ps[j].  Both lists are sorted, so one binary search per 64-entry BLOCK START (cb[b] = pending
+        // samples > L[64 b]) confines everything else to the handful of pending samples between two block
+        // starts.  The blocks are streamed from the last to the first: stores only go to addresses at or
+        // above the block they come from, so the blocks loaded ahead (lower addresses) are never clobbered.
         if (nP > 0) {
           const int nblk = (Lm + 63) >> 6;
-          for (int bb = nblk - 1; bb >= 0; bb -= 4) {
-            float v[4], vp[4];
+          for (int b = lane; b < nblk; b += 64) cb[b] = nmx_count_gt_lds(ps, nP, L[64 * b]);
+          if (lane == 0) cb[nblk] = nP;
+          NMX_WAVE_FENCE();
+          for (int j = lane; j < cb[0]; j += 64) ins[j] = 0;
+          // NB blocks per step, and the loads of the NEXT step are issued before this step's entries are
+          // placed (they lie at lower addresses than anything stored so far)
+          constexpr int NB = 8;
+          float vn[NB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = 64 * (bb - q) + lane;
-              v[q] = (bb - q >= 0 && i < Lm) ? L[i] : 0.f;
-              vp[q] = (bb - q >= 0 && lane == 0 && i > 0) ? L[i - 1] : 0.f;   // lane 0: its predecessor's value
+          for (int q = 0; q < NB; ++q) {
+            const int i = 64 * (nblk - 1 - q) + lane;
+            vn[q] = (nblk - 1 - q >= 0 && i < Lm) ? L[i] : 0.f;
+          }
+          for (int bb = nblk - 1; bb >= 0; bb -= NB) {
+            float v[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) v[q] = vn[q];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+              const int i = 64 * (bb - NB - q) + lane;
+              vn[q] = (bb - NB - q >= 0) ? L[i] : 0.f;   // (blocks below the top one are full)
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = 64 * (bb - q) + lane;
-              const bool ok = bb - q >= 0 && i < Lm;
-              const int cnt = ok ? nmx_count_gt_lds(ps, nP, v[q]) : 0;
-              int cprev = __builtin_amdgcn_update_dpp(0, cnt, 0x138, 0xf, 0xf, false);   // wave_shr:1
-              if (lane == 0) cprev = (ok && i > 0) ? nmx_count_gt_lds(ps, nP, vp[q]) : 0;
-              if (ok) {
-                for (int j = cprev; j < cnt; ++j) ins[j] = i;   // pending samples j sort right before entry i
-                if (cnt) L[i + cnt] = v[q];
+            for (int q = 0; q < NB; ++q) {
+              const int b = bb - q;
+              if (b < 0) break;
+              const int i = 64 * b + lane;
+              const bool ok = i < Lm;
+              const int c_lo = cb[b], c_hi = cb[b + 1];
+              int cnt = c_lo;
+              for (int j = c_lo; j < c_hi; ++j) {
+                const float pj = ps[j];
+                cnt += (pj > v[q]);
+                const int at = 64 * b + __popcll(__ballot(ok && v[q] >= pj));
+                if (lane == 0) ins[j] = at;
               }
+              if (ok && cnt) L[i + cnt] = v[q];
             }
           }
           NMX_WAVE_FENCE();
           for (int j = lane; j < nP; j += 64) L[ins[j] + j] = ps[j];
         }
+        NMX_TP(5)   // flush: stream + scatter
         Lm += nP;
-        for (int j = lane; j < nF; j += 64) L[Lm + j] = F[nF - 1 - j];
+        for (int j = lane; j < nF; j += 64) L[Lm + j] = F[fh + nF - 1 - j];
         // (Lm + nF == K by construction)
         __threadfence();   // the re-cut below reads what this wave just stored
         nF = NMX_THR_FREFILL;
+        fh = 0;
         Lm = K - nF;
         nP = 0;
         for (int j = lane; j < nF; j += 64) F[j] = L[K - 1 - j];
         NMX_WAVE_FENCE();
         T = F[0];
         Fmax = F[nF - 1];
+#ifdef NMX_THRW_PROFILE
+        ++n_flush;
+#endif
+        NMX_TP(6)   // flush: re-cut
       }
     }
   }
+#ifdef NMX_THRW_PROFILE
+  if (lane == 0 && (sidx == 0 || sidx == 311))
+    printf("[thrw %lld] hops %d inserts %d flushes %d | cycles: top %lld classify %lld fringe %lld store %lld sort %lld stream %lld recut %lld\n",
+           sidx, A.n_windows, n_ins, n_flush, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+#endif
   if (lane == 0) {
     A.counts[2 * sidx] = total;
     A.counts[2 * sidx + 1] = nwin;

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(64) nmx_kern_burst_thr_wave(const NmxBurstThrA
 }
 
 extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s) {
-  hipLaunchKernelGGL(nmx_kern_burst_thr_wave, dim3(n_items), dim3(64), (size_t)NMX_THRW_LDS_FLOATS * 4, s, *A);
+  const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS + A->K / 64 + 4) * 4;
+  hipLaunchKernelGGL(nmx_kern_burst_thr_wave, dim3(n_items), dim3(64), lds, s, *A);
 }
 
 // Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)
