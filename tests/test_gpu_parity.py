@@ -253,7 +253,7 @@ def test_psd_keys_skip_normalisation(gpu_lib):
 
 def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     """Plan-level knobs select fallback / alternative kernels (list-based sharp-wave code, dense
-    re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list, block-wide STFT).
+    re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list, block-wide STFT, generic time / oscillatory kernel).
     They must reproduce the default path on the bench feature set within the parity tolerances."""
     C, n_hops = 64, 72    # 4608 items: enough for the persistent bank kernel (>= 4096) and its fused variants
     T = 1000 + (n_hops - 1) * 100
@@ -272,6 +272,7 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     s, keys, want = run()
     for knob, val in (("NMX_SW_DENSE", "0"), ("NMX_SW_DENSE_FIRST", "0"), ("NMX_CAR_FAST", "0"), ("NMX_OVERLAP", "0"),
                       ("NMX_FUSE_SHARP", "1"), ("NMX_FUSE_HILBERT", "1"), ("NMX_THR_LIST_GLOBAL", "1"), ("NMX_STFT_PER_WAVE", "0"),
+                      ("NMX_TIMEOSC_W1000", "0"), ("NMX_SHARP_FIRST", "1"),
                       ("NMX_CHUNK_WINDOWS", "9")):
         monkeypatch.setenv(knob, val)
         _, keys2, got = run()
