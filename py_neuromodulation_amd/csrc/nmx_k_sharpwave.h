@@ -132,6 +132,8 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
 }
 #else
 // Device version: the per-lane chunk (<= 64 samples) is classified without branches into two
+// (a lane-interleaved variant with ballots instead of the scan -- conflict-free LDS reads -- measured
+// 10 % slower: the kernel is issue bound and that form needs more instructions per sample)
 // bitmasks (a divergent `if` costs several scalar instructions and the CU has one scalar unit);
 // only plateau starts -- rare -- take a branch.  Bit k = extremum whose (plateau) start is i0 + k.
 NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, int* n_max, int* n_min,
@@ -582,7 +584,17 @@ NMX_DEV NmxSharpLds nmx_sharp_layout(const NmxSharpArgs& A, float* smem) {
 
 // Analysis of the series in L.z.  dense_only: the caller provides lists for 128 entries only; returns
 // false (nothing written) when the window needs the generic list code.
-NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, int c, int fi, bool dense_only) {
+#ifdef NMX_SW_PROFILE
+#define NMX_SWP(i) { const long long t_ = clock64(); swp[i] += t_ - swl; swl = t_; }
+#else
+#define NMX_SWP(i)
+#endif
+NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, int c, int fi, bool dense_only,
+                            long long t_in = 0) {
+#ifdef NMX_SW_PROFILE
+  long long swp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, swl = clock64();
+  swp[0] = swl - t_in;
+#endif
   float* z = L.z;
   nmx_u16 *emax = L.emax, *emin = L.emin, *selP = L.selP, *selT = L.selT, *lf = L.lf, *rt = L.rt;
   unsigned char* st = L.st;
@@ -595,6 +607,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   // dense_only callers provide lists for 128 entries: longer ones are counted, not stored
   nmx_extrema(z, W, emax, emin, &n_max, &n_min, dense_only ? 128 : 0x7fffffff);
 #endif
+  NMX_SWP(1)   // extrema
   float* row = A.out + (long long)w * A.n_outputs;
   int pol_slot = 0;
   const int n_pol = (A.est_peaks ? 1 : 0) + (A.est_troughs ? 1 : 0);
@@ -605,6 +618,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   NmxDenseSel D;
   if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
 #endif
+  NMX_SWP(2)   // distance selection
   for (int pol = 0; pol < 2; ++pol) {
     if ((pol == 0 && !A.est_peaks) || (pol == 1 && !A.est_troughs)) continue;
     const float sgn = pol == 0 ? 1.f : -1.f;   // "Trough" analysis runs on -y
@@ -674,6 +688,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     }
     NMX_SYNC();
     }
+    NMX_SWP(3)   // pairing
     const nmx_u16* trv = selT + first_valid;  // trough list after the reference's slice
     const int nPT = (n_pairs == nT) ? n_pairs : 0;  // arrays that broadcast pairs with troughs
     if (NMX_TID == 0) res[2 * A.n_combos + pol] = (float)nT;
@@ -706,7 +721,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
           const int f = A.combo_feature[cb], e = A.combo_est[cb];
           if (f == NMX_SW_NUM_PEAKS) continue;
           float acc = e == NMX_SWE_MEAN ? 0.f : (e == NMX_SWE_MAX ? -INFINITY : INFINITY);
-          int cnt = 0;
+          int cnt = 0;   // entries that take part: counted with ballots (scalar), not reduced
 #pragma unroll
           for (int sl = 0; sl < 2; ++sl) {
             const bool pt = okP[sl] && (NMX_TID + 64 * sl) < nPT;   // arrays that pair troughs with peaks
@@ -723,15 +738,12 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
               case NMX_SW_RISE_TIME: v = (float)(rq[sl] - tq[sl]) * A.ms; ok = pt; break;
               default: v = zt[sl] - 0.5f * (zm[sl] + zp[sl]); ok = okS[sl]; break;   // NMX_SW_SHARPNESS
             }
-            if (ok) {
-              ++cnt;
-              acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_nanmax(acc, v) : nmx_nanmin(acc, v));
-            }
+            cnt += __popcll(__ballot(ok));
+            if (ok) acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_nanmax(acc, v) : nmx_nanmin(acc, v));
           }
           if (e == NMX_SWE_MEAN) acc = nmx_wave_reduce(acc, 0.f, [](float a, float b) { return a + b; });
           else if (e == NMX_SWE_MAX) acc = nmx_wave_reduce(acc, -INFINITY, [](float a, float b) { return nmx_nanmax(a, b); });
           else acc = nmx_wave_reduce(acc, INFINITY, [](float a, float b) { return nmx_nanmin(a, b); });
-          cnt = nmx_wave_reduce(cnt, 0, [](int a, int b) { return a + b; });
           if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
         }
       } else
@@ -841,6 +853,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
         if (NMX_TID == 0) res[pol * A.n_combos + cb] = r;
       }
     }
+    NMX_SWP(4)   // estimators
     NMX_SYNC();
     if (!A.between && NMX_TID == 0) {
       for (int cb = 0; cb < A.n_combos; ++cb) {
@@ -864,6 +877,12 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
       row[A.np_cols.base + c * A.np_cols.ch_stride + fi * A.np_cols.a_stride] =
           0.5f * (res[2 * A.n_combos] + res[2 * A.n_combos + 1]);
   }
+  NMX_SWP(5)   // outputs
+#ifdef NMX_SW_PROFILE
+  if (NMX_TID == 0 && fi == 0 && c == 7 && (w == 3 || w == 600))
+    printf("[sw w=%d] n_max %d n_min %d | cycles: load %lld extrema %lld select %lld pair %lld est %lld out %lld\n", w, n_max, n_min,
+           swp[0], swp[1], swp[2], swp[3], swp[4], swp[5]);
+#endif
   return true;
 }
 
@@ -889,9 +908,14 @@ NMX_DEV void nmx_sharp_item_dense(const NmxSharpArgs& A, int w, int c, int fi, l
   const int W = A.W;
   const float* src = A.y + (((long long)w * A.n_channels + c) * A.n_filters + fi) * W;
   float* z = L.z;
+#ifdef NMX_SW_PROFILE
+  const long long t_in = clock64();
+#else
+  const long long t_in = 0;
+#endif
   nmx_stage_row(src, W, [=](int i, float v) { z[i] = v; });
   NMX_SYNC();
-  const bool done = nmx_sharp_body(A, L, w, c, fi, true);
+  const bool done = nmx_sharp_body(A, L, w, c, fi, true, t_in);
   if (NMX_TID == 0) A.todo[item] = done ? 0 : 1;
 }
 #endif
