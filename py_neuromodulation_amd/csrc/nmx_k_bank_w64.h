@@ -312,6 +312,21 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   }
   NMX_WSYNC();
 
+#ifndef NMX_HOST_EMU
+  // conjugate partners Z[n - k] of this lane's points: one cross-lane read per point, ONCE per item (they
+  // do not depend on the filter; inside the filter loop they were a third of its LDS-crossbar traffic)
+  nmx_c2 zcr[16];
+  if (PAD == 0) {   // (the notch has one filter: nothing to hoist, and it needs its 3 waves/SIMD)
+    const int l = (int)(threadIdx.x & 63);
+    NMX_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const nmx_c2 zs = zr[0][NMX_J2I(15 - r)];
+      nmx_c2 zc = nmx_mk2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
+      if (l == 0) zc = (r == 0) ? zr[0][0] : zr[0][NMX_J2I((16 - r) & 15)];
+      zcr[r] = zc;
+    }
+  }
+#endif
   const int yoff = (PAD == 1) ? A.pad_half : 0;
   for (int fi = 0; fi < A.n_filters; ++fi) {
     const NmxFilterDev& F = A.f[fi];
@@ -327,11 +342,17 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         const nmx_c2 zk = zr[NMX_LI][NMX_J2I(r)];
 #ifdef NMX_HOST_EMU
         nmx_c2 zc = zr[(64 - l) & 63][NMX_J2I(15 - r)];
-#else
-        const nmx_c2 zs = zr[0][NMX_J2I(15 - r)];
-        nmx_c2 zc = nmx_mk2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
-#endif
         if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
+#else
+        nmx_c2 zc;
+        if (PAD == 0) {
+          zc = zcr[r];
+        } else {
+          const nmx_c2 zs = zr[0][NMX_J2I(15 - r)];
+          zc = nmx_mk2(__shfl(zs.x, (64 - l) & 63), __shfl(zs.y, (64 - l) & 63));
+          if (l == 0) zc = (r == 0) ? zr[0][0] : zr[0][NMX_J2I((16 - r) & 15)];
+        }
+#endif
         const float ha = (Hs + l)[64 * r], hb = (Hd + l)[64 * r];
         // Z'[k] = A_k Z[k] + i B_k conj(Z[n-k]),  A = Hs - Hd sin(th_k), B = Hd cos(th_k)
         vv[r] = nmx_c2_axpby_swap(ha, zk, hb, zc);
