@@ -178,6 +178,25 @@ NMX_UNROLL
   }
 }
 
+// Inverse pass C when only the first half of the outputs is read (W <= 1024 samples = packed index
+// m < 512 = the r = 0, 1 outputs of each 4-point butterfly): two of the four outputs, 6 instead of 8 adds.
+template <int DIR>
+NMX_DEV void nmx_w64_passC_lds_half(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
+  const nmx_c2* tw = twC + lane;
+NMX_UNROLL
+  for (int t = 0; t < 4; ++t) {
+    const nmx_c2* Xi = X + lane;
+    nmx_c2 a0 = Xi[64 * t], a1 = Xi[64 * t + 256], a2 = Xi[64 * t + 512], a3 = Xi[64 * t + 768];
+    a1 = nmx_cmul(a1, nmx_twd<DIR>(tw[64 * t]));
+    a2 = nmx_cmul(a2, nmx_twd<DIR>(tw[64 * (4 + t)]));
+    a3 = nmx_cmul(a3, nmx_twd<DIR>(tw[64 * (8 + t)]));
+    const nmx_c2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+    const nmx_c2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
+    v[4 * t] = nmx_cadd(t0, t2);
+    v[4 * t + 1] = nmx_cadd(t1, t3);
+  }
+}
+
 // tail-range mask of a register that straddles the band-pass segment boundary: kept out of line so
 // that the compiler does not if-convert it into 16 x 2 lane predicates (64-bit masks that were
 // spilling the scalar register file); it runs for at most two registers per pass
@@ -204,7 +223,9 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
 // HIL = 1 (needs TAB = 1, W = 1000): Hilbert envelope of the burst bands inside the wave; `tab` then
 // continues with the NMX_W500_TAB_FLOATS table after the pass B / C twiddles.
-template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0>
+// HALF = 1 (PAD = 0, W <= 1024): only the output registers v[4 t + r], r < 2 (samples < 1024) exist -- the
+// others are never computed, reduced or stored.
+template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0, int HALF = 0>
 NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
                                   const NmxSharpArgs* S = nullptr) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
@@ -365,7 +386,10 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     NMX_WSYNC();
     NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
     NMX_WSYNC();
-    NMX_LANE_LOOP { nmx_w64_passC_lds<+1>(v[NMX_LI], X, twC, l); }
+    NMX_LANE_LOOP {
+      if (HALF) nmx_w64_passC_lds_half<+1>(v[NMX_LI], X, twC, l);
+      else nmx_w64_passC_lds<+1>(v[NMX_LI], X, twC, l);
+    }
     // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
 
     if (F.bp_seglen > 0) {
@@ -383,6 +407,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
           nmx_c2 acc = nmx_mk2(0.f, 0.f), acc2 = nmx_mk2(0.f, 0.f);
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
+            if (HALF && (i & 3) >= 2) continue;
             const int mb = 64 * (i >> 2) + 256 * (i & 3);
             if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
             nmx_c2 val = v[NMX_LI][i];
@@ -406,6 +431,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
             const nmx_c2 mean2 = nmx_mk2(mean, mean);
             NMX_UNROLL
             for (int i = 0; i < 16; ++i) {
+              if (HALF && (i & 3) >= 2) continue;
               const int mb = 64 * (i >> 2) + 256 * (i & 3);
               if (2 * mb + 127 < lo || 2 * mb >= hi) continue;
               nmx_c2 d = nmx_csub(v[NMX_LI][i], mean2);
@@ -523,11 +549,14 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         const nmx_rsrc rs = nmx_make_rsrc(d, 4 * W);
         if ((W & 1) == 0) {
           NMX_UNROLL
-          for (int i = 0; i < 16; ++i)
+          for (int i = 0; i < 16; ++i) {
+            if (HALF && (i & 3) >= 2) continue;
             __builtin_amdgcn_raw_buffer_store_b64(v[0][i], rs, 8 * l + 512 * (i >> 2) + 2048 * (i & 3), 0, 0);
+          }
         } else {
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
+            if (HALF && (i & 3) >= 2) continue;
             const int off = 8 * l + 512 * (i >> 2) + 2048 * (i & 3);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][i].x), rs, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][i].y), rs, off + 4, 0, 0);

@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // staged in LDS once per workgroup (instead of being re-fetched from L2 for every item: 27 % of
 // the kernel's time), then every wave walks its own items with wave-local fences only.
 // HIL = 1: Hilbert envelopes of the burst bands inside the kernel (tables after the twiddles in LDS).
-template <int WAVES, int FUSE, int HIL>
+// HALF = 1: windows of at most 1024 samples -- the upper half of each inverse transform's outputs is never formed.
+template <int WAVES, int FUSE, int HIL, int HALF = 0>
 __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
                                                                                      int n_items, int x_floats,
                                                                                      const NmxSharpArgs S) {
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W
   float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + (HIL ? NMX_W500_TAB_FLOATS : 0) + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<0, 1, 0, FUSE, HIL>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
+    nmx_bank_w64_item<0, 1, 0, FUSE, HIL, HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
 }
 
 // same structure for the notch (odd-reflected window, one filter)
@@ -89,8 +90,10 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   const int x_floats = A->lds_floats;            // per-wave exchange tile (+ scratch)
   const int tab_floats = A->b.n_filters * 2 * NMX_W64_N;
   if (!A->twl) return 0;
-  static int want_bank = 0, notch_on = 1;
+  static int want_bank = 0, notch_on = 1, half_ok = 1;
   if (!want_bank) {
+    const char* h = getenv("NMX_W64_HALF");
+    half_ok = !(h && h[0] == '0');
     const char* v = getenv("NMX_W64P_WAVES");
     want_bank = (v && atoi(v) == 11) ? 11 : 8;
     const char* u = getenv("NMX_W64P_NOTCH");
@@ -110,6 +113,8 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   if (!once) {
     once = true;
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -137,6 +142,9 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
                          n_items, x_floats, none);
     else if (hil)
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
+                         n_items, x_floats, none);
+    else if (A->b.W <= 1024 && half_ok)
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
     else
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
