@@ -185,7 +185,7 @@ def main() -> None:
             "algorithmic_GBps_pipeline": value / world * C * bytes_cw / 1e9,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
             "nan_outputs": bad,
-            "roofline": {"bound": "hbm", "kernel": "nmx_kern_bank_w64p_scalar<8, 0, 0>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "nmx_kern_bank_w64p_scalar<8, 0, 0, 1>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "note": "FIR bank is LDS/FP32-vector bound (SURVEY 8d); frac is vs the HBM roof"},
