@@ -308,6 +308,33 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       sg_first = O.nseg;
     }
 #endif
+    if (N <= 64 && sg_first == 0) {
+      // short segments (e.g. 17 samples at 30 kHz: dozens of segments per window): one (segment, bin)
+      // pair per thread, direct N-term DFT -- no transform buffers, no barrier per segment
+      const int nb = O.k_hi - O.k_lo;
+      NMX_SYNC();
+      for (int idx = NMX_TID; idx < O.nseg * nb; idx += NMX_NT) {
+        const int sgi = idx / nb, k = O.k_lo + (idx - sgi * nb);
+        const int s0 = sgi * O.step;
+        float re = 0.f, im = 0.f;
+        for (int i = 0; i < N; ++i) {
+          float sn, cs;
+#ifdef NMX_HOST_EMU
+          const double ang = -2.0 * 3.14159265358979323846 * (double)((k * i) % N) / (double)N;
+          sn = (float)sin(ang); cs = (float)cos(ang);
+#else
+          sincospif(-2.f * (float)((k * i) % N) / (float)N, &sn, &cs);
+#endif
+          const float v = xe(s0 + i) * O.win[i];
+          re += v * cs;
+          im += v * sn;
+        }
+        float v = sqrtf(re * re + im * im) * O.scale;
+        if (O.log_transform) v = log10f(v);
+        spec[(k - O.k_lo) * O.nseg + sgi] = v;
+      }
+      sg_first = O.nseg;
+    }
     for (int sgi = sg_first; sgi < O.nseg; ++sgi) {
       const int s0 = sgi * O.step;
       NMX_SYNC();
