@@ -367,3 +367,43 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
     np.testing.assert_array_equal(run(True, [n_hops]), want)
     np.testing.assert_array_equal(run(True, [300, 1, 7, 292, 300]), want)
     np.testing.assert_array_equal(run(True, [450, 450], export_at=450), want)
+
+
+@pytest.mark.parametrize("W", [800, 901])
+def test_persistent_bank_equals_one_window_kernel_other_lengths(gpu_lib, W):
+    """Batches of >= 4096 (window, channel) items run the persistent FIR-bank kernel (tables in LDS, lower
+    half of the inverse transforms only); a single window runs the one-wave-per-workgroup kernel.  Same
+    arithmetic, so band-pass power, sharp-wave and (first-hop) burst features must agree bit for bit --
+    here for an even and an odd window length other than the default 1000 (odd: dword-wise buffer
+    accesses), and against the CPU oracle on two hops."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.bandpass_filter = s.features.sharpwave_analysis = True
+    s.segment_length_features_ms = W
+    s.bandpass_filter_settings.segment_lengths_ms = {"theta": W, "alpha": 500, "low_beta": 333, "high_beta": 333}
+    s = s.validate()
+    sfreq, C, n_hops = 1000.0, 64, 66
+    T = W + (n_hops - 1) * 100
+    rng = np.random.default_rng(W)
+    t = np.arange(T) / sfreq
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-300, 300, (C, 1))).astype(np.float32)
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * 100
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    got = eng.process_batch(x, starts)          # 66 * 64 = 4224 items: persistent kernel
+    assert not np.isnan(got).any()
+    for i in (0, 31, 65):
+        one = eng.process_window(x[:, starts[i]:starts[i] + W].astype(np.float64))
+        np.testing.assert_array_equal(one, got[i])
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in eng.enabled]
+    for i in (3, 40):
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(x[:, starts[i]:starts[i] + W].astype(np.float64)))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 400.0, W)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
