@@ -237,7 +237,8 @@ int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
 /* ---- Feature normalisation over a batch of hops (processing/normalization.py:31-111,150-163) ----
  * The reference post-processes every feature vector with a rolling normaliser (on by default,
  * default_settings.yaml:69-78).  One nmx_norm carries the history of one stream.
- *   method      NMX_NORM_MEAN ((x - mean) / mean) or NMX_NORM_ZSCORE ((x - mean) / std, std 0 -> 1);
+ *   method      NMX_NORM_MEAN ((x - mean) / mean), NMX_NORM_ZSCORE ((x - mean) / std, std 0 -> 1),
+ *               NMX_NORM_MEDIAN or NMX_NORM_ZSCORE_MEDIAN (the same with the NaN-ignoring median);
  *               statistics over the last n_hist rows INCLUDING the current one, NaNs ignored
  *   clip        > 0: clip to [-clip, clip]; <= 0: none          (normalization.py:104-105)
  *   n_hist      int(normalization_time_s * sampling_rate_features_hz) >= 2
@@ -248,6 +249,8 @@ int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
  * memspace / hip_stream as in nmx_process_batch. */
 #define NMX_NORM_MEAN 0
 #define NMX_NORM_ZSCORE 1
+#define NMX_NORM_MEDIAN 2          /* (x - median) / median        (normalization.py:155-157) */
+#define NMX_NORM_ZSCORE_MEDIAN 3   /* (x - median) / std, std 0 -> 1 (normalization.py:166-169) */
 typedef struct nmx_norm nmx_norm;
 int nmx_norm_create(int32_t device, int32_t n_cols, int32_t method, float clip, int32_t n_hist,
                     const uint8_t* colmask, nmx_norm** out);

@@ -18,6 +18,8 @@
 
 #define NMX_NORM_MEAN 0
 #define NMX_NORM_ZSCORE 1
+#define NMX_NORM_MEDIAN 2
+#define NMX_NORM_ZSCORE_MEDIAN 3
 
 struct NmxNormArgs {
   float* rows;                 // [n_rows][ld]  in place
@@ -29,7 +31,70 @@ struct NmxNormArgs {
   long long seq0;              // rows seen before this batch
   int method;
   float clip;                  // <= 0: none
+  float* sorted;               // median methods: [cap][n_cols] scratch, the window's non-NaN values ascending
 };
+
+// The median methods (normalization.py:155-157,166-169: np.median / np.nanmedian over the history incl.
+// the current row) keep the window's non-NaN values SORTED per column: a new value is inserted and the
+// value that leaves the window removed by shifting (<= N moves, lanes = columns, so every move is a
+// coalesced row access); the median is then one or two reads.  The sorted copy is scratch -- it is rebuilt
+// from the ring at the start of every batch, like the sums.
+NMX_DEV int nmx_norm_lower(const float* S, int n_cols, int j, int n, float x) {   // first index with S[idx] >= x
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (S[(long long)mid * n_cols + j] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// S[k] for k in [a, b) moves one slot up (to k + 1), highest first; four independent loads per step
+NMX_DEV void nmx_norm_shift_up(float* S, int n_cols, int j, int a, int b) {
+  int k = b;
+  for (; k - 4 >= a; k -= 4) {
+    float* q = S + (long long)(k - 4) * n_cols + j;
+    const float t0 = q[0], t1 = q[n_cols], t2 = q[2ll * n_cols], t3 = q[3ll * n_cols];
+    q[n_cols] = t0; q[2ll * n_cols] = t1; q[3ll * n_cols] = t2; q[4ll * n_cols] = t3;
+  }
+  for (; k > a; --k) S[(long long)k * n_cols + j] = S[(long long)(k - 1) * n_cols + j];
+}
+// S[k] for k in (a, b] moves one slot down (to k - 1), lowest first
+NMX_DEV void nmx_norm_shift_down(float* S, int n_cols, int j, int a, int b) {
+  int k = a;
+  for (; k + 4 <= b; k += 4) {
+    float* q = S + (long long)k * n_cols + j;
+    const float t1 = q[n_cols], t2 = q[2ll * n_cols], t3 = q[3ll * n_cols], t4 = q[4ll * n_cols];
+    q[0] = t1; q[n_cols] = t2; q[2ll * n_cols] = t3; q[3ll * n_cols] = t4;
+  }
+  for (; k < b; ++k) S[(long long)k * n_cols + j] = S[(long long)(k + 1) * n_cols + j];
+}
+NMX_DEV void nmx_norm_insert(float* S, int n_cols, int j, int& n, float x) {
+  const int p = nmx_norm_lower(S, n_cols, j, n, x);
+  nmx_norm_shift_up(S, n_cols, j, p, n);
+  S[(long long)p * n_cols + j] = x;
+  ++n;
+}
+NMX_DEV void nmx_norm_remove(float* S, int n_cols, int j, int& n, float x) {   // x is in the list
+  const int p = nmx_norm_lower(S, n_cols, j, n, x);
+  nmx_norm_shift_down(S, n_cols, j, p, n - 1);
+  --n;
+}
+// remove `o` (in the list) and insert `x` in one pass: only the entries between the two positions move
+NMX_DEV void nmx_norm_replace(float* S, int n_cols, int j, int n, float o, float x) {
+  const int po = nmx_norm_lower(S, n_cols, j, n, o);
+  const int px = nmx_norm_lower(S, n_cols, j, n, x);   // position of x in the list that still holds o
+  if (px > po) {   // x lands above o: entries (po, px) move down, x takes slot px - 1
+    nmx_norm_shift_down(S, n_cols, j, po, px - 1);
+    S[(long long)(px - 1) * n_cols + j] = x;
+  } else {         // x lands at or below o: entries [px, po) move up, x takes slot px
+    nmx_norm_shift_up(S, n_cols, j, px, po);
+    S[(long long)px * n_cols + j] = x;
+  }
+}
+NMX_DEV double nmx_norm_median(const float* S, int n_cols, int j, int n) {
+  if (n == 0) return NAN;
+  const double hi = (double)S[(long long)(n >> 1) * n_cols + j];
+  return (n & 1) ? hi : 0.5 * ((double)S[(long long)((n >> 1) - 1) * n_cols + j] + hi);
+}
 
 NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
   if (j >= A.n_cols) return;
@@ -43,17 +108,38 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     const float h = A.ring[(q % cap) * A.n_cols + j];
     if (h == h) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
   }
+  const bool med = A.method >= NMX_NORM_MEDIAN;
+  int ns = 0;   // entries of the sorted copy (== cnt)
+  if (med)
+    for (long long q = A.seq0 - have; q < A.seq0; ++q) {
+      const float h = A.ring[(q % cap) * A.n_cols + j];
+      if (h == h) nmx_norm_insert(A.sorted, A.n_cols, j, ns, h);
+    }
+  bool pend = false;   // median methods: the value trimmed after the previous hop leaves the sorted copy
+  float pend_val = 0.f;   //   together with the next insertion (nothing reads the copy in between)
   for (int r = 0; r < A.n_rows; ++r) {
     const long long q = A.seq0 + r;
     float* cell = A.rows + (long long)r * A.ld + j;
     const float x = *cell;
     if (len == cap) {  // cannot happen with the trim below; kept for safety
       const float o = A.ring[((q - cap) % cap) * A.n_cols + j];
-      if (o == o) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; }
+      if (o == o) {
+        s1 -= (double)o; s2 -= (double)o * (double)o; --cnt;
+        if (med) {
+          if (pend) { nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val); pend = false; }
+          nmx_norm_remove(A.sorted, A.n_cols, j, ns, o);
+        }
+      }
       --len;
     }
     A.ring[(q % cap) * A.n_cols + j] = x;
     if (x == x) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
+    if (med) {
+      if (x == x && pend) nmx_norm_replace(A.sorted, A.n_cols, j, ns, pend_val, x);
+      else if (x == x) nmx_norm_insert(A.sorted, A.n_cols, j, ns, x);
+      else if (pend) nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val);
+      pend = false;
+    }
     ++len;
     if (q > 0) {  // the first row ever is returned as it came
       double out;
@@ -63,6 +149,9 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         const double mean = s1 / (double)cnt;
         if (A.method == NMX_NORM_MEAN) {
           out = ((double)x - mean) / mean;
+        } else if (A.method == NMX_NORM_MEDIAN) {
+          const double m = nmx_norm_median(A.sorted, A.n_cols, j, ns);
+          out = ((double)x - m) / m;
         } else {
           double var = s2 / (double)cnt - mean * mean;
           if (var < 1e-9 * mean * mean) {  // cancellation: two-pass over the ring (rare)
@@ -75,7 +164,8 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
           }
           double sd = var > 0.0 ? sqrt(var) : 0.0;
           if (sd == 0.0) sd = 1.0;
-          out = ((double)x - mean) / sd;
+          const double centre = A.method == NMX_NORM_ZSCORE_MEDIAN ? nmx_norm_median(A.sorted, A.n_cols, j, ns) : mean;
+          out = ((double)x - centre) / sd;
         }
       }
       if (A.clip > 0.f) {  // ndarray.clip: NaN stays NaN
@@ -87,7 +177,7 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     // history keeps its last N - 1 rows (normalization.py:107)
     if (len > cap - 1) {
       const float o = A.ring[((q - (cap - 1)) % cap) * A.n_cols + j];
-      if (o == o) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; }
+      if (o == o) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; if (med) { pend = true; pend_val = o; } }
       --len;
     }
   }

@@ -189,14 +189,15 @@ class FeatureNormalizer:
 
 
 class DeviceFeatureNormalizer:
-    """processing/normalization.py:31-111 for normalization_method in {"mean", "zscore"} on the GPU.
+    """processing/normalization.py:31-111 for normalization_method in {"mean", "median", "zscore",
+    "zscore-median"} on the GPU (the scikit-learn based methods stay on the host: ``FeatureNormalizer``).
 
     ``process(row)`` keeps the reference's call shape (one feature vector per hop);
     ``process_batch(rows)`` normalises ``rows[n_hops, n_features]`` with the same hop-by-hop
     semantics in one kernel launch (rows may also be a device pointer, see ``process_device``).
     """
 
-    METHODS = {"mean": 0, "zscore": 1}
+    METHODS = {"mean": 0, "zscore": 1, "median": 2, "zscore-median": 3}
 
     def __init__(self, settings, n_features: int, colmask=None, device: int = 0, lib=None) -> None:
         import ctypes as C

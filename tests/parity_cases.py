@@ -363,7 +363,8 @@ def case_reference_property_tests(lib):
 
 
 def case_feature_normalizer_batches(lib):
-    """nmx_norm_* (batch scan) == the reference's hop-by-hop Normalizer for "zscore" and "mean":
+    """nmx_norm_* (batch scan) == the reference's hop-by-hop Normalizer for "zscore", "mean", "median" and
+    "zscore-median":
     history carried across batches and through export/import, N - 1 trimming, NaN-aware statistics,
     constant columns (std 0 -> 1), the untouched first row, clip, and the "psd" column mask.
     Tolerance: statistics are float64 on both sides, values are fp32 -> 1e-5 rel / 2e-6 abs."""
@@ -380,7 +381,7 @@ def case_feature_normalizer_batches(lib):
     rows[100:180, 12] = np.nan                         # a whole history window of NaNs (N = 50)
     mask = np.ones(F, dtype=np.uint8)
     mask[20:24] = 0
-    for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0)):
+    for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0), ("median", 3), ("zscore-median", 3), ("median", 0)):
         s = NMSettings.get_default()
         s.sampling_rate_features_hz = 10
         s.feature_normalization_settings.normalization_time_s = 5

@@ -18,6 +18,8 @@ def main():
 
     n, F = 1024, 9984
     s = NMSettings.get_default()
+    if len(sys.argv) > 1:
+        s.feature_normalization_settings.normalization_method = sys.argv[1]   # mean | zscore | median | zscore-median
     dn = DeviceFeatureNormalizer(s, F)
     x = torch.randn(n, F, device="cuda") * 3 + 1
     st = torch.cuda.current_stream().cuda_stream
@@ -30,7 +32,7 @@ def main():
         dn.process_device(x.data_ptr(), F, n, st)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({"rows": n, "features": F, "n_hist": dn.num_samples_normalize, "ms_per_batch": dt * 1e3,
+    print(json.dumps({"method": s.feature_normalization_settings.normalization_method, "rows": n, "features": F, "n_hist": dn.num_samples_normalize, "ms_per_batch": dt * 1e3,
                       "rows_per_s": n / dt, "GBps_rows_rw": 2 * n * F * 4 / dt / 1e9}))
 
 
