@@ -29,6 +29,18 @@ PREPROCESSOR_ORDER = ["preprocessing_filter", "notch_filter", "raw_resampling", 
                       "raw_normalization"]
 
 
+class _LazyNanCols:
+    def __init__(self, keys, ch_names) -> None:
+        self._keys, self._ch, self._cache = keys, ch_names, {}
+
+    def __getitem__(self, ci: int) -> np.ndarray:
+        cols = self._cache.get(ci)
+        if cols is None:
+            ch = self._ch[ci]
+            cols = self._cache[ci] = np.array([i for i, k in enumerate(self._keys) if ch in k], dtype=int)
+        return cols
+
+
 class DataProcessor:
     def __init__(self, sfreq: float, settings, channels, coord_names=None, coord_list=None,
                  line_noise: float | None = None, path_grids=None, verbose: bool = True,
@@ -138,9 +150,10 @@ class DataProcessor:
                                                                  device=device, lib=lib)
             else:  # median / scikit-learn methods: host NumPy, hop by hop like the reference
                 self.feature_normalizer = FeatureNormalizer(st)
-        # NaN policy: columns whose key contains the channel's new_name (substring, as the reference)
-        self._nan_cols = [np.array([i for i, k in enumerate(self.keys) if ch in k], dtype=int)
-                          for ch in self.ch_names_used]
+        # NaN policy: columns whose key contains the channel's new_name (substring, as the reference);
+        # built on first use per channel (256 channels x 8 000 keys of substring tests cost 50 ms up front,
+        # and a NaN channel is the exception)
+        self._nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
         self.cnt_samples = 0
 
     # ------------------------------------------------------------------------------------
