@@ -143,6 +143,54 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
   const int i0 = 1 + NMX_TID * chunk;
   const int i1 = (i0 + chunk) < (W - 1) ? (i0 + chunk) : (W - 1);
   unsigned long long mmax = 0ull, mmin = 0ull;
+  bool no_plateau = false;   // this lane saw no plateau start: every extremum is its own midpoint
+  if (chunk == 16 && NMX_NT == 64) {
+    // default window (962 < W <= 1026): the lane's 16 positions and their two neighbours are 18 consecutive
+    // floats starting at the 64-byte aligned z[16 lane] -- four 16-byte LDS reads + one 8-byte read instead
+    // of 17 dword reads, and 32-bit masks built from compile-time bit constants
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float sv[18];
+    const f4* q4 = (const f4*)(z + 16 * NMX_TID);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f4 t = q4[g];
+      sv[4 * g] = t.x; sv[4 * g + 1] = t.y; sv[4 * g + 2] = t.z; sv[4 * g + 3] = t.w;
+    }
+    {
+      // (the last lane's tail lies beyond the window: the list / scratch region that follows z in LDS is
+      // readable, the values are masked out below)
+      const f2 t = *(const f2*)(z + 16 * NMX_TID + 16);
+      sv[16] = t.x; sv[17] = t.y;
+    }
+    unsigned m1 = 0u, m2 = 0u;
+    bool plateau = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const bool in = (i0 + k) < i1;
+      const float prev = sv[k], cur = sv[k + 1], nxt = sv[k + 2];
+      const bool up = in && prev < cur, dn = in && prev > cur;
+      m1 |= (up && nxt < cur) ? (1u << k) : 0u;
+      m2 |= (dn && nxt > cur) ? (1u << k) : 0u;
+      plateau = plateau || ((up || dn) && nxt == cur);
+    }
+    if (plateau) {   // rare: resolve plateau starts with the generic walk
+      for (int i = i0; i < i1; ++i) {
+        const float prev = z[i - 1], cur = z[i], nxt = z[i + 1];
+        const bool up = prev < cur, dn = prev > cur;
+        if ((up || dn) && nxt == cur) {
+          int ahead = i + 1;
+          float a = nxt;
+          while (a == cur && ahead < W - 1) { ++ahead; a = z[ahead]; }
+          if (up && a < cur) m1 |= 1u << (i - i0);
+          if (dn && a > cur) m2 |= 1u << (i - i0);
+        }
+      }
+    }
+    mmax = m1;
+    mmin = m2;
+    no_plateau = !plateau;
+  } else
   if (i0 < i1) {
     float prev = z[i0 - 1], cur = z[i0];
     for (int i = i0; i < i1; ++i) {
@@ -171,8 +219,10 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
     const int i = i0 + __ffsll((long long)mmax) - 1;
     mmax &= mmax - 1;
     int ahead = i + 1;
-    const float cur = z[i];
-    while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    if (!no_plateau) {
+      const float cur = z[i];
+      while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    }
     if (bmax < cap) emax[bmax] = (nmx_u16)((i + ahead - 1) >> 1);   // counts stay exact past `cap`
     ++bmax;
   }
@@ -180,8 +230,10 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
     const int i = i0 + __ffsll((long long)mmin) - 1;
     mmin &= mmin - 1;
     int ahead = i + 1;
-    const float cur = z[i];
-    while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    if (!no_plateau) {
+      const float cur = z[i];
+      while (ahead < W - 1 && z[ahead] == cur) ++ahead;
+    }
     if (bmin < cap) emin[bmin] = (nmx_u16)((i + ahead - 1) >> 1);
     ++bmin;
   }
