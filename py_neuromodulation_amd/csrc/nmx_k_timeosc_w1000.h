@@ -38,21 +38,24 @@ static inline bool nmx_timeosc_w1000_ok(const NmxTimeOscArgs& A) {
   return A.fft.enabled || A.welch.enabled || A.stft.enabled;
 }
 
+// NB = compile-time bound on the number of bands (4 covers the default settings: half the select / add
+// instructions per spectral value of the 8-band build)
+template <int NB>
 struct NmxBandAcc {
-  float s[8];
+  float s[NB];
   NMX_DEV void clear() {
 #pragma unroll
-    for (int b = 0; b < 8; ++b) s[b] = 0.f;
+    for (int b = 0; b < NB; ++b) s[b] = 0.f;
   }
   // value v of bin k joins every band whose [lo, hi) holds k
   NMX_DEV void add(const NmxOsc& O, int n_bands, int k, float v) {
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < NB; ++b)
       if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
   }
   NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NB; ++b) {
       if (b >= n_bands) continue;
       const float tot = nmx_wave_reduce(s[b], 0.f, [](float a_, float b_) { return a_ + b_; });
       const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
@@ -61,6 +64,7 @@ struct NmxBandAcc {
   }
 };
 
+template <int NB>
 NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float* smem) {
   w = nmx_uniform_i(w);
   c = nmx_uniform_i(c);
@@ -90,7 +94,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
     if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
   NMX_WAVE_FENCE();
 
-  NmxBandAcc acc;
+  NmxBandAcc<NB> acc;
   // ---- FFT band power: |rfft(x)| -> log10 -> band means ---------------------------------------------
   if (A.fft.enabled) {
     const NmxOsc& O = A.fft;

@@ -56,15 +56,19 @@ extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long 
 }
 
 // time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
+template <int NB>
 __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
   const int item = blockIdx.x;
-  nmx_timeosc_w1000_item(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+  nmx_timeosc_w1000_item<NB>(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
 }
 
 // returns 0 when the configuration needs the generic kernel
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w1000_ok(*A)) return 0;
-  hipLaunchKernelGGL(nmx_kern_timeosc_w1000, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+  if (A->n_bands <= 4)
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+  else
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
   return 1;
 }
 
