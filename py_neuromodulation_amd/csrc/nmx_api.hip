@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
-  nmx_car_sample(A, (long long)blockIdx.x * 256 + threadIdx.x);
+  __shared__ float red[256];
+  nmx_car_tile(A, (long long)blockIdx.x * 64, red);
 }
 __global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
   const int item = blockIdx.x;
@@ -301,7 +302,7 @@ static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
-  hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 255) / 256)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);

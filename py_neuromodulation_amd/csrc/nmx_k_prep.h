@@ -64,6 +64,34 @@ NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
   for (int j = 0; j < A.C; ++j) A.y[(long long)j * A.ldy + t] = a * nmx_clean(A.x[(long long)j * A.ldx + t]) + b;
 }
 
+#ifndef NMX_HOST_EMU
+// Device form: a 256-thread workgroup owns 64 consecutive samples; wave q sums channels q, q + 4, q + 8 ...
+// (a quarter of the column), the four partial sums meet in LDS, then every wave writes its own channels.
+// Four times the waves of the one-thread-per-sample form and loops a quarter as long: the kernel was
+// latency bound at 1.6 waves per SIMD (0.21 ms for 105 MB in + 105 MB out).
+NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, float* red) {
+  const int lane = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
+  const long long t = t0 + lane;
+  const bool in = t < A.T;
+  float s = 0.f;
+  if (in) {
+    int j = q;
+    for (; j + 12 < A.C; j += 16) {   // four independent loads in flight
+      const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 4) * A.ldx + t];
+      const float v2 = A.x[(long long)(j + 8) * A.ldx + t], v3 = A.x[(long long)(j + 12) * A.ldx + t];
+      s += nmx_clean(v0); s += nmx_clean(v1); s += nmx_clean(v2); s += nmx_clean(v3);
+    }
+    for (; j < A.C; j += 4) s += nmx_clean(A.x[(long long)j * A.ldx + t]);
+  }
+  red[q * 64 + lane] = s;
+  __syncthreads();
+  const float tot = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  if (!in) return;
+  const float a = A.diag - A.off, b = A.off * tot;
+  for (int j = q; j < A.C; j += 4) A.y[(long long)j * A.ldy + t] = a * nmx_clean(A.x[(long long)j * A.ldx + t]) + b;
+}
+#endif
+
 struct NmxNanMaskArgs {
   const float* x;
   long long ldx;
