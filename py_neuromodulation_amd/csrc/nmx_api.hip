@@ -210,6 +210,8 @@ extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream
 extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
+extern "C" int nmx_w64q_launch_notch_slp(const NmxBankW64Args*, int, hipStream_t);
+extern "C" int nmx_w64q_launch_notch_scalar(const NmxBankW64Args*, int, hipStream_t);
 extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
                                            hipStream_t s);
 // returns the persistent launcher's flags (nmx_w64.hip): bit 1 = the sharp-wave analysis ran inside the
@@ -236,6 +238,11 @@ static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, 
                                 : nmx_w64p_launch_scalar(&A, n_items, n_cu, s, sharp);
     if (rc) return rc;
   }
+  static int notch_q = -1;
+  if (notch_q < 0) { const char* v = getenv("NMX_NOTCH_QUAD"); notch_q = !(v && v[0] == '0'); }
+  if (notch_q && A.b.pad_mode != 0 && n_items >= 1024 &&
+      (variant == 1 ? nmx_w64q_launch_notch_slp(&A, n_items, s) : nmx_w64q_launch_notch_scalar(&A, n_items, s)))
+    return 0;
   if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
   else nmx_w64_launch_scalar(&A, n_items, lds, s);
   return 0;

@@ -80,6 +80,39 @@ __global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_notch_w6
     nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
 }
 
+// Notch, four items per workgroup: the filter's A / B tables and the twiddles are staged in LDS once per
+// FOUR items (the one-wave-per-workgroup kernel fetches ~27 KB of tables from L2 per item); no item loop,
+// so none of the scalar-register pressure of the persistent form.
+__global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME)(const NmxBankW64Args A, int n_items,
+                                                                                      int x_floats) {
+  float* tab = nmx_smem_w64;
+  const int n = NMX_W64_N, tab_floats = 2 * n;
+  for (int i = threadIdx.x; i < tab_floats; i += 256) tab[i] = i < n ? A.Hs[0][i] : A.Hd[0][i - n];
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += 256) tab[tab_floats + i] = A.twl[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;
+  nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels,
+                             nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats, tab);
+}
+
+// returns 0 when the configuration does not fit (caller falls back to one wave per workgroup)
+extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, hipStream_t s) {
+  if (A->b.pad_mode == 0 || A->b.n_filters != 1 || !A->twl) return 0;
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int x_floats = A->lds_floats;
+  const size_t lds = (size_t)(2 * NMX_W64_N + NMX_W64_TWL_FLOATS + 4 * x_floats) * 4;
+  hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME), dim3((n_items + 3) / 4), dim3(256), lds, s, *A, n_items,
+                     x_floats);
+  return 1;
+}
+
 // Return value: 0 = configuration does not fit the persistent kernel (caller falls back), else bit 0 set,
 // bit 1 = the sharp-wave analysis ran inside the kernel (sharp != nullptr), bit 2 = the Hilbert envelopes
 // of the burst bands were written to b.env_out (hil_tab given, W = 1000) instead of the series to yb_out.
