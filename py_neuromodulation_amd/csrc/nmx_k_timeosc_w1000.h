@@ -9,8 +9,8 @@
 //     / Raw come straight from those registers (nmx_k_scan.h), then the window is parked in LDS (4 KB);
 //   * every transform is the wave-level 500-point complex transform of nmx_k_fft500.h (radix 10.10.5,
 //     17 twiddles per lane in VGPRs, wave-local fences, no workgroup barrier):
-//       FFT    the window itself, read as 500 packed complex points          (1 transform)
-//       Welch  (x - mean) * hann, packed                                       (1 transform)
+//       FFT + Welch  ONE transform of the centred window; the periodic hann window of Welch's single
+//              segment is applied as a three-term convolution of that spectrum   (1 transform)
 //       STFT   TWO real segments per transform, z = seg_a + i seg_b, separated afterwards with
 //              A[k] = (Z[k] + conj Z[500-k]) / 2,  B[k] = (Z[k] - conj Z[500-k]) / 2i   (3 transforms)
 //   * band means are accumulated per lane while the bins are produced (no spectrum buffer) and reduced
@@ -82,7 +82,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
   R.sum = 0.f;
   if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) {
     nmx_scan_emit(A, w, c, R);
-  } else if (A.welch.enabled) {
+  } else if (A.welch.enabled || A.fft.enabled) {
     float p0 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) p0 += (R.x[k][0] + R.x[k][1]) + (R.x[k][2] + R.x[k][3]);   // out-of-range samples are 0
@@ -95,44 +95,53 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
   NMX_WAVE_FENCE();
 
   NmxBandAcc<NB> acc;
-  // ---- FFT band power: |rfft(x)| -> log10 -> band means ---------------------------------------------
-  if (A.fft.enabled) {
-    const NmxOsc& O = A.fft;
-    const float2* Z = (const float2*)nmx_w500_fft<-1>((const nmx_c2*)xs, fa, fb, T, lane);
-    acc.clear();
-    for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
-      const float2 X = nmx_rfft_bin(Z, O.fft.twr, 500, k);
-      float v = sqrtf(X.x * X.x + X.y * X.y);
-      if (O.log_transform) v = log10f(v);
-      acc.add(O, nb, k, v);
-    }
-    acc.emit(O, nb, 1, out_row, c, lane);
-    NMX_WAVE_FENCE();
-  }
-  // ---- Welch: one segment = the window; constant detrend, hann, density scaling ---------------------
-  if (A.welch.enabled) {
-    const NmxOsc& O = A.welch;
+  // ---- FFT and Welch share ONE transform: Z' = FFT_500 of the packed CENTRED window x - mean ----------
+  //   * a constant only reaches bin 0, so for k >= 1 the spectrum X' of x - mean is the spectrum of x (what
+  //     the FFT feature reads; with the DC offset gone before the fp32 transform it is also more accurate),
+  //     and X[0] = sum(x);
+  //   * Welch here is one segment = the window, constant detrend, PERIODIC hann w[n] = 1/2 - 1/2 cos(2 pi n / N):
+  //     multiplying by w is a three-term convolution of the spectrum,
+  //         Y[k] = X'[k] / 2 - (X'[k-1] + X'[k+1]) / 4,   X'[0] = 0,  X'[-k] = conj X'[k],
+  //     so no second transform and no windowed copy of the window are needed.
+  if (A.fft.enabled || A.welch.enabled) {
     const float mean = R.sum / 1000.f;
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 4000, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      typedef unsigned u4 __attribute__((ext_vector_type(4)));
-      const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rw, 16 * lane + 1024 * k, 0, 0);
-      const nmx_f4 y = {(R.x[k][0] - mean) * __uint_as_float(r.x), (R.x[k][1] - mean) * __uint_as_float(r.y),
-                        (R.x[k][2] - mean) * __uint_as_float(r.z), (R.x[k][3] - mean) * __uint_as_float(r.w)};
-      if (k < 3 || lane < 58) ((nmx_f4*)fb)[lane + 64 * k] = y;
-    }
+    for (int k = 0; k < 4; ++k)
+      if (k < 3 || lane < 58)
+        ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
     NMX_WAVE_FENCE();
     const float2* Z = (const float2*)nmx_w500_fft<-1>(fb, fa, fb, T, lane);
-    acc.clear();
-    for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
-      const float2 X = nmx_rfft_bin(Z, O.fft.twr, 500, k);
-      float p = (X.x * X.x + X.y * X.y) * O.scale;
-      if (!(k == 0 || k == 500)) p *= 2.f;
-      if (O.log_transform) p = log10f(p);
-      acc.add(O, nb, k, p);
+    const float2* twr = (A.fft.enabled ? A.fft : A.welch).fft.twr;
+    auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
+      const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
+      if (kk == 0) return make_float2(0.f, 0.f);
+      const float2 X = nmx_rfft_bin(Z, twr, 500, kk);
+      return (k < 0 || k > 500) ? make_float2(X.x, -X.y) : X;
+    };
+    if (A.fft.enabled) {
+      const NmxOsc& O = A.fft;
+      acc.clear();
+      for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+        const float2 X = k == 0 ? make_float2(R.sum, 0.f) : xbin(k);
+        float v = sqrtf(X.x * X.x + X.y * X.y);
+        if (O.log_transform) v = log10f(v);
+        acc.add(O, nb, k, v);
+      }
+      acc.emit(O, nb, 1, out_row, c, lane);
     }
-    acc.emit(O, nb, 1, out_row, c, lane);
+    if (A.welch.enabled) {
+      const NmxOsc& O = A.welch;
+      acc.clear();
+      for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+        const float2 X0 = xbin(k), Xm = xbin(k - 1), Xp = xbin(k + 1);
+        const float yr = 0.5f * X0.x - 0.25f * (Xm.x + Xp.x), yi = 0.5f * X0.y - 0.25f * (Xm.y + Xp.y);
+        float p = (yr * yr + yi * yi) * O.scale;
+        if (!(k == 0 || k == 500)) p *= 2.f;
+        if (O.log_transform) p = log10f(p);
+        acc.add(O, nb, k, p);
+      }
+      acc.emit(O, nb, 1, out_row, c, lane);
+    }
     NMX_WAVE_FENCE();
   }
   // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
