@@ -118,6 +118,63 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T
   return a;
 }
 
+// Forward transform when only the bins k < k_hi and k > 500 - k_hi are read afterwards (band powers up to a
+// few tens of Hz: k_hi <= 100).  Stages 1 and 2 as above; in stage 3 (radix 5, outputs a[j + 100 r]) only the
+// butterflies j < k_hi (their r = 0 output) and j > 100 - k_hi (their r = 4 output) run, and each forms that
+// ONE output -- with the same operations the full butterfly uses for it, so the values are identical.
+template <typename TW>
+NMX_DEV nmx_c2* nmx_w500_fft_fwd_low(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T, int lane, int k_hi) {
+  nmx_c2 v[10];
+  if (lane < 50) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) v[r] = in[lane + 50 * r];
+    nmx_dft10_c2<-1>(v);
+    nmx_c2* o = a + 10 * lane;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) o[r] = v[r];
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) v[r] = a[lane + 50 * r];
+#pragma unroll
+    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul(v[r], T.get(r - 1));
+    nmx_dft10_c2<-1>(v);
+    const int q = lane / 10, k = lane - 10 * q;
+    nmx_c2* o = b + 100 * q + k;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) o[10 * r] = v[r];
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+    const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;
+    const float s1 = -0.95105651629515353f, s2 = -0.58778525229247314f;   // DIR = -1
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lane + 50 * h;
+      const bool lo = j < k_hi, hi = j > 100 - k_hi;
+      if (!(lo || hi)) continue;
+      const nmx_c2* src = b + j;
+      nmx_c2 x0 = src[0], x1 = src[100], x2 = src[200], x3 = src[300], x4 = src[400];
+      x1 = nmx_cmul(x1, T.get(9 + 4 * h));
+      x2 = nmx_cmul(x2, T.get(10 + 4 * h));
+      x3 = nmx_cmul(x3, T.get(11 + 4 * h));
+      x4 = nmx_cmul(x4, T.get(12 + 4 * h));
+      const nmx_c2 t1 = x1 + x4, t2 = x2 + x3;
+      if (lo) a[j] = x0 + t1 + t2;
+      if (hi) {
+        const nmx_c2 d1 = x1 - x4, d2 = x2 - x3;
+        const nmx_c2 m1 = x0 + c1 * t1 + c2 * t2;
+        const nmx_c2 u1 = s1 * d1 + s2 * d2;
+        const nmx_c2 n1 = {-u1.y, u1.x};
+        a[j + 400] = m1 - n1;
+      }
+    }
+  }
+  NMX_WAVE_FENCE();
+  return a;
+}
+
 // Hilbert transform H[y] of a real series of 1000 samples (scipy.signal.hilbert's imaginary part).
 // In: b[m] = (y[2m], y[2m+1]), m < 500.  Out (returned pointer, = a): (H[y][2m], H[y][2m+1]).
 // With Z = FFT_500(b), th = 2 pi k / 1000, the half-length forward split, the multiplication by -i

@@ -110,7 +110,11 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
       if (k < 3 || lane < 58)
         ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
     NMX_WAVE_FENCE();
-    const float2* Z = (const float2*)nmx_w500_fft<-1>(fb, fa, fb, T, lane);
+    // bins read below: up to max(k_hi) (+1 for Welch's neighbours) and their mirror images 500 - k
+    const int kmax = (A.fft.enabled ? A.fft.k_hi : 0) > (A.welch.enabled ? A.welch.k_hi + 1 : 0)
+                         ? A.fft.k_hi : (A.welch.enabled ? A.welch.k_hi + 1 : 0);
+    const float2* Z = (const float2*)(kmax <= 100 ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
+                                                  : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
     const float2* twr = (A.fft.enabled ? A.fft : A.welch).fft.twr;
     auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
       const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
@@ -166,7 +170,8 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
         }
       }
       NMX_WAVE_FENCE();
-      const nmx_c2* Z = nmx_w500_fft<-1>(fb, fa, fb, T, lane);
+      const nmx_c2* Z = O.k_hi <= 100 ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, O.k_hi)
+                                      : nmx_w500_fft<-1>(fb, fa, fb, T, lane);
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
         const nmx_c2 zk = Z[k == 500 ? 0 : k], zn = Z[k == 0 ? 0 : 500 - k];
         // A = (zk + conj zn) / 2,  B = -i (zk - conj zn) / 2
