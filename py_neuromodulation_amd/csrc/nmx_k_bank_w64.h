@@ -225,7 +225,7 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 // continues with the NMX_W500_TAB_FLOATS table after the pass B / C twiddles.
 // HALF = 1 (PAD = 0, W <= 1024): only the output registers v[4 t + r], r < 2 (samples < 1024) exist -- the
 // others are never computed, reduced or stored.
-template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0, int HALF = 0>
+template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0, int HALF = 0, int HOIST = 1>
 NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
                                   const NmxSharpArgs* S = nullptr) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
@@ -337,7 +337,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   // conjugate partners Z[n - k] of this lane's points: one cross-lane read per point, ONCE per item (they
   // do not depend on the filter; inside the filter loop they were a third of its LDS-crossbar traffic)
   nmx_c2 zcr[16];
-  if (PAD == 0) {   // (the notch has one filter: nothing to hoist, and it needs its 3 waves/SIMD)
+  if (PAD == 0 && HOIST) {   // (the notch has one filter: nothing to hoist, and it needs its 3 waves/SIMD)
     const int l = (int)(threadIdx.x & 63);
     NMX_UNROLL
     for (int r = 0; r < 16; ++r) {
@@ -366,7 +366,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         if (l == 0) zc = (r == 0) ? zr[NMX_LI][0] : zr[NMX_LI][NMX_J2I((16 - r) & 15)];
 #else
         nmx_c2 zc;
-        if (PAD == 0) {
+        if (PAD == 0 && HOIST) {
           zc = zcr[r];
         } else {
           const nmx_c2 zs = zr[0][NMX_J2I(15 - r)];

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W
   float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + (HIL ? NMX_W500_TAB_FLOATS : 0) + wave * x_floats;
 #pragma nounroll
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<0, 1, 0, FUSE, HIL, HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
+    nmx_bank_w64_item<0, 1, 0, FUSE, HIL, HALF, (WAVES <= 8)>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
 }
 
 // same structure for the notch (odd-reflected window, one filter)
@@ -120,7 +120,7 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
                                                        hipStream_t s, const NmxSharpArgs* sharp) {
   if (A->b.bp_features & 6u) return 0;
   const bool notch = A->b.pad_mode != 0;
-  const int x_floats = A->lds_floats;            // per-wave exchange tile (+ scratch)
+  int x_floats = A->lds_floats;                  // per-wave exchange tile (+ scratch)
   const int tab_floats = A->b.n_filters * 2 * NMX_W64_N;
   if (!A->twl) return 0;
   static int want_bank = 0, notch_on = 1, half_ok = 1;
@@ -128,12 +128,16 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
     const char* h = getenv("NMX_W64_HALF");
     half_ok = !(h && h[0] == '0');
     const char* v = getenv("NMX_W64P_WAVES");
-    want_bank = (v && atoi(v) == 11) ? 11 : 8;
+    want_bank = (v && atoi(v) == 12) ? 12 : 8;
     const char* u = getenv("NMX_W64P_NOTCH");
     notch_on = (u && u[0] == '1');   // measured slower than one wave per workgroup (1.58 vs 1.30 ms)
   }
   if (notch && !notch_on) return 0;
-  const int want = notch ? NMX_W64P_WAVES : want_bank;
+  int want = notch ? NMX_W64P_WAVES : want_bank;
+  if (want == 12) {   // 3 waves/SIMD: W <= 1024 only, the 64-float reduction scratch of each wave is not needed (MC = 0)
+    if (notch || sharp || A->b.W > 1024) want = 8;
+    else x_floats -= 64;
+  }
   bool hil = !notch && !sharp && want == 8 && A->hil_tab && A->b.W == 1000 && A->b.env_out && A->b.n_burst_bands > 0;
   int nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS - (hil ? NMX_W500_TAB_FLOATS : 0)) / x_floats;
   if (hil && nw < want) {   // no room for the Hilbert tables next to the filter tables: separate kernel
@@ -141,6 +145,12 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
     nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats;
   }
   if (nw > want) nw = want;
+  if (nw < want && want == 12) {   // does not fit next to this many filter tables: 8 waves
+    want = 8;
+    x_floats += 64;
+    nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS - (hil ? NMX_W500_TAB_FLOATS : 0)) / x_floats;
+    if (nw > want) nw = want;
+  }
   if (nw < want) return 0;
   static bool once = false;
   if (!once) {
@@ -153,7 +163,7 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0, 0>,
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -170,8 +180,8 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
     return 3;
   } else {
     static const NmxSharpArgs none{};
-    if (nw == 11)
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<11, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
+    if (nw == 12)
+      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
     else if (hil)
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
