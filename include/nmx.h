@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 5
+#define NMX_ABI_VERSION 6
 
 /* error codes */
 #define NMX_OK 0
@@ -233,6 +233,13 @@ int nmx_state_import(nmx_plan* plan, const void* src, int64_t n_bytes);
  * which = 0 whole batch, 1 pre-processing, 2 time/oscillatory kernel, 3 FIR-bank kernel,
  * 4 bursts kernels, 5 sharp-wave kernel.  Blocks until the events have completed. */
 int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
+
+/* Names of the kernels the first launch sequence of the last nmx_process_batch ran in stage `which`
+ * (1..5 as above; several kernels are joined by " + "), spelled as rocprofv3 --kernel-trace prints them
+ * (template arguments included).  Which variant runs depends on the shape, the batch size and the tuning
+ * knobs, so measurement code names the kernel from here instead of hard-coding it.  NUL-terminated,
+ * truncated to n - 1 characters. */
+int nmx_last_kernels(nmx_plan* plan, int which, char* buf, int64_t n);
 
 /* ---- Feature normalisation over a batch of hops (processing/normalization.py:31-111,150-163) ----
  * The reference post-processes every feature vector with a rolling normaliser (on by default,

@@ -558,7 +558,7 @@ class Bursts:
         self.batch += 1
         thr = self.update_threshold(env[:, :, -n_new:])
         st = burst_stats(env, thr, self.sfreq, self.seg_s)
-        self.last_thr = thr
+        self.last_thr, self.last_env = thr, env   # (read by the conditioning report of tests/parity.py)
         out = {}
         for ci, ch in enumerate(self.ch_names):
             for bi, fb in enumerate(self.band_names):
@@ -1016,3 +1016,78 @@ def run_stream(data: np.ndarray, sfreq: float, settings, channels: dict, line_no
             d[channels["name"][i]] = w[i, -1]
         rows.append({k: float(v) for k, v in d.items()})
     return rows
+
+
+# --------------------------------------------------------------------------------------
+# Conditioning reports (test infrastructure for tests/parity.py): the engine computes in fp32,
+# the reference in float64.  Three families of outputs are NOT Lipschitz in the data -- log10 of a
+# spectral magnitude near a null, find_peaks' discrete selections, the `env >= thr` comparison of
+# the burst detector -- so a tolerance miss there is only accepted when the float64 computation
+# itself shows the ill-conditioning.  These functions report it per output; nothing here is part
+# of the restated arithmetic.
+# --------------------------------------------------------------------------------------
+
+
+def spectral_magnitudes(family: str, settings, sfreq: float, x_row: np.ndarray):
+    """Linear magnitudes behind one channel's FFT / Welch / STFT features:
+    (mag[n_freq] or mag[n_freq, n_seg], [(band, bin_indices)], freqs).
+    Welch returns sqrt(PSD) so that all three are amplitudes."""
+    x = np.asarray(x_row, np.float64)[None]
+    if family == "fft":
+        o = FFT(settings, ["c"], sfreq)
+        mag = np.abs(sp_fft.rfft(x[:, -o.N:], axis=-1))[0]
+    elif family == "welch":
+        o = Welch(settings, ["c"], sfreq)
+        mag = np.sqrt(welch_psd(x, o.sfreq, o.sfreq))[0]
+    elif family == "stft":
+        o = STFT(settings, ["c"], sfreq)
+        mag = stft_mag(x, o.nperseg)[0]
+    else:
+        raise ValueError(family)
+    return mag, o.idx_range, o.freqs
+
+
+def spectral_null_ratio(mag: np.ndarray, idx: np.ndarray) -> float:
+    """min |X_k| over the contributing bins / rms |X_k| over ALL bins (and segments), DC included.
+    An fp32 transform puts an ABSOLUTE error of ~1e-7 * ||x||_2 / sqrt(N) = ~1e-7 * rms_k |X_k|
+    (Parseval) on every bin -- a DC offset raises it for every bin; log10 turns that into a relative
+    one, so a contributing bin at ratio r carries an error of ~1e-7 / r in log10 units."""
+    m = np.asarray(mag, np.float64)
+    rms = float(np.sqrt(np.mean(m ** 2)))
+    sel = m[np.asarray(idx, dtype=int)]
+    if sel.size == 0 or rms == 0.0:
+        return float("inf")
+    return float(sel.min() / rms)
+
+
+def _strict_extrema(z: np.ndarray) -> np.ndarray:
+    return find_peaks_distance(z, None)
+
+
+def sharpwave_decision_margin(y: np.ndarray, dist_peaks: float, dist_troughs: float) -> float:
+    """Smallest absolute perturbation of the filtered series ``y`` that can change a discrete
+    decision of features/sharpwaves.py:339-374 (both polarities):
+      * existence / position of a local extremum (find_peaks compares neighbouring samples):
+        min_i |y[i+1] - y[i]|;
+      * find_peaks' distance suppression keeps the HIGHER of two extrema closer than `distance`:
+        min |y[p] - y[q]| over same-kind extrema p, q with |p - q| < ceil(distance).
+    The trough/peak pairing that follows is index arithmetic on these sets (no further comparisons
+    of values)."""
+    y = np.asarray(y, np.float64)
+    m = float(np.min(np.abs(np.diff(y)))) if y.size > 1 else float("inf")
+    d = int(math.ceil(max(dist_peaks, dist_troughs)))
+    for z in (y, -y):
+        p = _strict_extrema(z)
+        for lag in range(1, min(d, p.size)):
+            a, b = p[:-lag], p[lag:]
+            close = (b - a) < d
+            if not close.any():
+                break   # (sorted positions: larger lags are farther apart)
+            m = min(m, float(np.min(np.abs(z[a[close]] - z[b[close]]))))
+    return m
+
+
+def burst_decision_margin(env: np.ndarray, thr: float) -> float:
+    """min_n |env[n] - thr|: the perturbation that flips one `env >= thr` sample
+    (features/bursts.py:175); a flipped sample moves run lengths / counts by whole samples."""
+    return float(np.min(np.abs(np.asarray(env, np.float64) - float(thr))))

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 5
+NMX_ABI_VERSION = 6
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -80,7 +80,7 @@ _EXPORTS = [
     "nmx_abi_version", "nmx_device_count", "nmx_last_error", "nmx_plan_create",
     "nmx_plan_destroy", "nmx_plan_n_outputs", "nmx_process_batch", "nmx_process_window",
     "nmx_preprocess_window", "nmx_filter_window", "nmx_state_reset", "nmx_state_size",
-    "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms",
+    "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms", "nmx_last_kernels",
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
 ]
@@ -127,6 +127,7 @@ class NmxLibrary:
         L.nmx_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nmx_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nmx_last_timing_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.nmx_last_kernels.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]
         L.nmx_norm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                       C.POINTER(C.c_void_p)]
         L.nmx_norm_destroy.argtypes = [C.c_void_p]

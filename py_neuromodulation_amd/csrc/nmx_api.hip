@@ -69,10 +69,27 @@ __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
   __shared__ float red[256];
   nmx_car_tile(A, (long long)blockIdx.x * 64, red);
 }
+__global__ void __launch_bounds__(256) nmx_kern_reref_struct(const NmxRerefStructArgs A) {
+  __shared__ double red[NMX_RS_GROUPS * 256];
+  nmx_reref_struct_tile(A, (long long)blockIdx.x * 64, red);
+}
 __global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
   const int item = blockIdx.x;
   nmx_nanmask_item(A, item / A.C_in, item % A.C_in, nmx_smem);
 }
+
+// ---- which kernels ran (per stage of the launch sequence; stage indices = nmx_last_timing_ms) ----
+static thread_local int g_stage = 0;
+static thread_local std::string g_stage_kernels[8];
+extern "C" void nmxi_note_kernel(const char* name) {
+  std::string& s = g_stage_kernels[g_stage & 7];
+  if (s.find(name) != std::string::npos) return;
+  if (!s.empty()) s += " + ";
+  s += name;
+}
+static void be_stage(int st) { g_stage = st; }
+static void be_stage_reset() { for (auto& s : g_stage_kernels) s.clear(); }
+static std::string be_stage_kernels(int st) { return g_stage_kernels[st & 7]; }
 
 // ---- backend ------------------------------------------------------------------------------
 typedef hipStream_t be_stream_t;
@@ -172,9 +189,8 @@ static void be_allow_lds(K kern) {
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 static void be_init_once() {
-  static bool done = false;
-  if (done) return;
-  done = true;
+  static unsigned long long seen = 0;   // per device (the opt-in is a per-device attribute)
+  if (!nmx_first_on_device(seen)) return;
   be_allow_lds(nmx_kern_timeosc);
   be_allow_lds(nmx_kern_bank);
   be_allow_lds(nmx_kern_hilbert);
@@ -201,10 +217,12 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
   if (fixed_ok < 0) { const char* v = getenv("NMX_TIMEOSC_FIXED"); fixed_ok = !(v && v[0] == '0'); }
   if (fixed_ok && nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_timeosc, dim3(n_items), dim3(nt), lds, s, A);
+  nmxi_note_kernel("nmx_kern_timeosc");
 }
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   hipLaunchKernelGGL(nmx_kern_bank, dim3(n_items), dim3(nt), lds, s, A);
+  nmxi_note_kernel("nmx_kern_bank");
 }
 extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
@@ -266,6 +284,7 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt
   if (fixed_ok < 0) { const char* v = getenv("NMX_HILBERT_FIXED"); fixed_ok = !(v && v[0] == '0'); }
   if (fixed_ok && nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
+  nmxi_note_kernel("nmx_kern_hilbert");
 }
 extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s);
 // windows_seen: hops every sequence has absorbed before this batch (-1: always the workgroup kernel)
@@ -275,9 +294,9 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, s
   // ring already full at the first hop: the barrier-free one-wave walk over the list in L2
   if (windows_seen > 0 && nmx_burst_thr_wave_ok(A, windows_seen)) { nmx_wave_launch_burst_thr(&A, n_items, s); return; }
   const int chunk = (A.K + nt - 1) / nt;
-  if (chunk <= 32) hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A);
-  else if (chunk <= 64) hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A);
-  else hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A);
+  if (chunk <= 32) { hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<32>"); }
+  else if (chunk <= 64) { hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<64>"); }
+  else { hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<128>"); }
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t s) {
   be_init_once();
@@ -290,19 +309,23 @@ static void be_launch_sharp(const NmxSharpArgs& A, int n_items, size_t lds, be_s
 static void be_launch_reref(const NmxRerefArgs& A, be_stream_t s) {
   dim3 grid((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF_ROWS - 1) / NMX_REREF_ROWS));
   hipLaunchKernelGGL(nmx_kern_reref, grid, dim3(256), 0, s, A);
+  nmxi_note_kernel("nmx_kern_reref");
 }
 static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   hipLaunchKernelGGL(nmx_kern_resample, dim3(n_items), dim3(nt), lds, s, A);
+  nmxi_note_kernel("nmx_kern_resample");
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_rawnorm_stats, dim3(A.n_channels), dim3(64), 0, s, A);
   const long long n = (long long)A.n_windows * A.n_channels * A.W;
   hipLaunchKernelGGL(nmx_kern_rawnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+  nmxi_note_kernel("nmx_kern_rawnorm_stats + nmx_kern_rawnorm_apply");
 }
 static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
   const int n = A.n_channels * A.n_bands;
   hipLaunchKernelGGL(nmx_kern_kalman, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A);
+  nmxi_note_kernel("nmx_kern_kalman");
 }
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   // one thread per column, one wave per workgroup: columns spread over as many CUs as possible
@@ -310,6 +333,11 @@ static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
+  nmxi_note_kernel("nmx_kern_car");
+}
+static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_reref_struct, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
+  nmxi_note_kernel("nmx_kern_reref_struct");
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);

@@ -61,6 +61,19 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
   } while (0)
 #endif
 #define NMX_RESTRICT __restrict__
+// host-side helpers shared by the translation units of libnmx.so
+// nmxi_note_kernel: every launcher records the kernel it actually launched (name as rocprofv3 prints it)
+// under the current stage; nmx_last_kernels() reports them (bench.py's roofline names the kernel from here).
+extern "C" void nmxi_note_kernel(const char* name);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE opt-in: true the first time the calling
+// site runs on the current device (`seen` = a static bitmask of device ordinals owned by the call site)
+static inline bool nmx_first_on_device(unsigned long long& seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+  if ((seen >> d) & 1ull) return false;
+  seen |= 1ull << d;
+  return true;
+}
 #endif
 
 // Values that are wave-uniform by construction but that the compiler cannot prove uniform (results

@@ -12,6 +12,12 @@
 // instead of the reference's O(N).  Features are fp32 numbers, so the float64 sums of <= N of them
 // are exact or within a few ulp; if the variance is small against mean^2 (cancellation) the two-pass
 // form is evaluated from the ring instead.  Lanes = consecutive columns: every row access is coalesced.
+//
+// +-inf features (log10 of a zero power: a flat or all-NaN channel) stay OUT of the sliding sums -- inf - inf
+// when the value leaves the window would poison them for good -- and are counted instead: while the window
+// holds one, np.mean is +-inf (or NaN) and np.std is NaN, so mean / zscore / zscore-median give NaN -> 0
+// (normalization.py:109); the median itself stays finite and is evaluated as usual.  Once the value has left
+// the window the sums are exactly what they would have been without it, like the reference's recomputation.
 #pragma once
 
 #include "nmx_device.h"
@@ -39,6 +45,8 @@ struct NmxNormArgs {
 // value that leaves the window removed by shifting (<= N moves, lanes = columns, so every move is a
 // coalesced row access); the median is then one or two reads.  The sorted copy is scratch -- it is rebuilt
 // from the ring at the start of every batch, like the sums.
+NMX_DEV bool nmx_norm_finite(float v) { return v - v == 0.f; }   // false for NaN and +-inf
+
 NMX_DEV int nmx_norm_lower(const float* S, int n_cols, int j, int n, float x) {   // first index with S[idx] >= x
   int lo = 0, hi = n;
   while (lo < hi) {
@@ -103,10 +111,11 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
   // rebuild the sums from the history (the last min(seq0, cap - 1) rows)
   const long long have = A.seq0 < (long long)(cap - 1) ? A.seq0 : (long long)(cap - 1);
   double s1 = 0.0, s2 = 0.0;
-  int cnt = 0, len = (int)have;
+  int cnt = 0, ninf = 0, len = (int)have;   // cnt: finite values in the window, ninf: +-inf values
   for (long long q = A.seq0 - have; q < A.seq0; ++q) {
     const float h = A.ring[(q % cap) * A.n_cols + j];
-    if (h == h) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+    if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+    else if (h == h) ++ninf;
   }
   const bool med = A.method >= NMX_NORM_MEDIAN;
   int ns = 0;   // entries of the sorted copy (== cnt)
@@ -124,7 +133,7 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     if (len == cap) {  // cannot happen with the trim below; kept for safety
       const float o = A.ring[((q - cap) % cap) * A.n_cols + j];
       if (o == o) {
-        s1 -= (double)o; s2 -= (double)o * (double)o; --cnt;
+        if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
         if (med) {
           if (pend) { nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val); pend = false; }
           nmx_norm_remove(A.sorted, A.n_cols, j, ns, o);
@@ -133,7 +142,8 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       --len;
     }
     A.ring[(q % cap) * A.n_cols + j] = x;
-    if (x == x) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
+    if (nmx_norm_finite(x)) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
+    else if (x == x) ++ninf;
     if (med) {
       if (x == x && pend) nmx_norm_replace(A.sorted, A.n_cols, j, ns, pend_val, x);
       else if (x == x) nmx_norm_insert(A.sorted, A.n_cols, j, ns, x);
@@ -143,15 +153,15 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     ++len;
     if (q > 0) {  // the first row ever is returned as it came
       double out;
-      if (cnt == 0) {
-        out = NAN;
+      if (cnt + ninf == 0 || (ninf > 0 && A.method != NMX_NORM_MEDIAN)) {
+        out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
+      } else if (A.method == NMX_NORM_MEDIAN) {
+        const double m = nmx_norm_median(A.sorted, A.n_cols, j, ns);
+        out = ((double)x - m) / m;
       } else {
         const double mean = s1 / (double)cnt;
         if (A.method == NMX_NORM_MEAN) {
           out = ((double)x - mean) / mean;
-        } else if (A.method == NMX_NORM_MEDIAN) {
-          const double m = nmx_norm_median(A.sorted, A.n_cols, j, ns);
-          out = ((double)x - m) / m;
         } else {
           double var = s2 / (double)cnt - mean * mean;
           if (var < 1e-9 * mean * mean) {  // cancellation: two-pass over the ring (rare)
@@ -177,7 +187,10 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     // history keeps its last N - 1 rows (normalization.py:107)
     if (len > cap - 1) {
       const float o = A.ring[((q - (cap - 1)) % cap) * A.n_cols + j];
-      if (o == o) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; if (med) { pend = true; pend_val = o; } }
+      if (o == o) {
+        if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
+        if (med) { pend = true; pend_val = o; }
+      }
       --len;
     }
   }

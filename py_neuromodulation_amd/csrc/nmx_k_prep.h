@@ -92,6 +92,90 @@ NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, float* red) {
 }
 #endif
 
+// Structured re-reference matrices: every row is a few explicit taps plus a multiple of one GROUP SUM,
+//   y_r = sum_{s < 4} coef[r][s] * x[idx[r][s]]  +  b_r * S_{g_r},   S_g = sum_{j in G_g} x_j
+// which covers what processing/rereference.py:52-86 can build: "average" rows (all other good channels
+// of the same type, :61-63 -> G = the type group, tap (1 - o) on the channel itself), bipolar rows
+// (:65-79 -> 2-3 taps, no group) and, with the channel pick folded in, ROW SUBSETS of such matrices
+// (a channel shard of a jointly referenced array: every GPU reads the group's rows once per sample
+// instead of running a dense [C x C_in] product).  The host finds the structure (nmx_engine.inc).
+#define NMX_RS_TAPS 4
+#define NMX_RS_GROUPS 4
+struct NmxRerefStructArgs {
+  const float* x;        // [C_in][ldx]
+  long long ldx;
+  float* y;              // [C][ldy]
+  long long ldy;
+  int C, C_in;
+  long long T;
+  const int* row_idx;    // [C][NMX_RS_TAPS] (unused taps: idx 0, coef 0)
+  const float* row_coef; // [C][NMX_RS_TAPS]
+  const int* row_group;  // [C] group or -1
+  const float* row_b;    // [C]
+  int n_groups;
+  const int* members;    // concatenated member rows of the groups
+  int group_off[NMX_RS_GROUPS + 1];
+};
+
+NMX_DEV void nmx_reref_struct_sample(const NmxRerefStructArgs& A, long long t) {
+  if (t >= A.T) return;
+  double S[NMX_RS_GROUPS];
+  for (int g = 0; g < A.n_groups; ++g) {
+    double s = 0.0;
+    for (int m = A.group_off[g]; m < A.group_off[g + 1]; ++m)
+      s += (double)nmx_clean(A.x[(long long)A.members[m] * A.ldx + t]);
+    S[g] = s;
+  }
+  for (int r = 0; r < A.C; ++r) {
+    double acc = A.row_group[r] >= 0 ? (double)A.row_b[r] * S[A.row_group[r]] : 0.0;
+    for (int k = 0; k < NMX_RS_TAPS; ++k) {
+      const float c = A.row_coef[r * NMX_RS_TAPS + k];
+      if (c != 0.f) acc += (double)c * (double)nmx_clean(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t]);
+    }
+    A.y[(long long)r * A.ldy + t] = (float)acc;
+  }
+}
+
+#ifndef NMX_HOST_EMU
+// Device form (as nmx_car_tile): a 256-thread workgroup owns 64 consecutive samples; wave q sums the members
+// q, q + 4, ... of every group (float64 partial sums: up to thousands of DC-carrying terms), the partials
+// meet in LDS, then wave q writes the rows q, q + 4, ...  `red` holds NMX_RS_GROUPS * 256 doubles.
+NMX_DEV void nmx_reref_struct_tile(const NmxRerefStructArgs& A, long long t0, double* red) {
+  const int lane = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
+  const long long t = t0 + lane;
+  const bool in = t < A.T;
+  for (int g = 0; g < A.n_groups; ++g) {
+    double s = 0.0;
+    if (in) {
+      int m = A.group_off[g] + q;
+      const int end = A.group_off[g + 1];
+      for (; m + 12 < end; m += 16) {   // four independent loads in flight
+        const float v0 = A.x[(long long)A.members[m] * A.ldx + t], v1 = A.x[(long long)A.members[m + 4] * A.ldx + t];
+        const float v2 = A.x[(long long)A.members[m + 8] * A.ldx + t], v3 = A.x[(long long)A.members[m + 12] * A.ldx + t];
+        s += ((double)nmx_clean(v0) + (double)nmx_clean(v1)) + ((double)nmx_clean(v2) + (double)nmx_clean(v3));
+      }
+      for (; m < end; m += 4) s += (double)nmx_clean(A.x[(long long)A.members[m] * A.ldx + t]);
+    }
+    red[(g * 4 + q) * 64 + lane] = s;
+  }
+  __syncthreads();
+  if (!in) return;
+  double S[NMX_RS_GROUPS];
+  for (int g = 0; g < A.n_groups; ++g)
+    S[g] = (red[(g * 4) * 64 + lane] + red[(g * 4 + 1) * 64 + lane]) + (red[(g * 4 + 2) * 64 + lane] + red[(g * 4 + 3) * 64 + lane]);
+  for (int r = q; r < A.C; r += 4) {
+    const int g = A.row_group[r];
+    double acc = 0.0;
+    for (int k = 0; k < NMX_RS_GROUPS; ++k) if (k == g) acc = (double)A.row_b[r] * S[k];   // (no dynamic register indexing)
+    for (int k = 0; k < NMX_RS_TAPS; ++k) {
+      const float c = A.row_coef[r * NMX_RS_TAPS + k];
+      if (c != 0.f) acc += (double)c * (double)nmx_clean(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t]);
+    }
+    A.y[(long long)r * A.ldy + t] = (float)acc;
+  }
+}
+#endif
+
 struct NmxNanMaskArgs {
   const float* x;
   long long ldx;

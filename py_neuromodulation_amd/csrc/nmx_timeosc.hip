@@ -9,6 +9,8 @@
 
 #define NMX_CAT2(a, b) a##b
 #define NMX_CAT(a, b) NMX_CAT2(a, b)
+#define NMX_STR2(a) #a
+#define NMX_STR(a) NMX_STR2(a)
 
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_timeosc.h"
@@ -26,21 +28,21 @@ __global__ void __launch_bounds__(NMX_BLOCK_FIXED) NMX_CAT(nmx_kern_hilbert_fixe
 
 
 extern "C" void NMX_CAT(nmx_hilbert_fixed_launch, NMX_BLOCK_FIXED)(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_hilbert_fixed, NMX_BLOCK_FIXED), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
   hipLaunchKernelGGL(NMX_CAT(nmx_kern_hilbert_fixed, NMX_BLOCK_FIXED), dim3((unsigned)n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+  nmxi_note_kernel("nmx_kern_hilbert_fixed" NMX_STR(NMX_BLOCK_FIXED));
 }
 
 extern "C" void NMX_CAT(nmx_timeosc_fixed_launch, NMX_BLOCK_FIXED)(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_timeosc_fixed, NMX_BLOCK_FIXED), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
   hipLaunchKernelGGL(NMX_CAT(nmx_kern_timeosc_fixed, NMX_BLOCK_FIXED), dim3(n_items), dim3(NMX_BLOCK_FIXED), lds, s, *A);
+  nmxi_note_kernel("nmx_kern_timeosc_fixed" NMX_STR(NMX_BLOCK_FIXED));
 }

@@ -19,6 +19,9 @@
 #endif
 #define NMX_CAT2(a, b) a##b
 #define NMX_CAT(a, b) NMX_CAT2(a, b)
+#define NMX_STR2(a) #a
+#define NMX_STR(a) NMX_STR2(a)
+#define NMX_KNAME(stem, tail) nmxi_note_kernel(stem NMX_STR(NMX_W64_NAME) tail)
 
 extern __shared__ __attribute__((aligned(16))) float nmx_smem_w64[];
 
@@ -100,9 +103,8 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_
 // returns 0 when the configuration does not fit (caller falls back to one wave per workgroup)
 extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, hipStream_t s) {
   if (A->b.pad_mode == 0 || A->b.n_filters != 1 || !A->twl) return 0;
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
@@ -110,6 +112,7 @@ extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Arg
   const size_t lds = (size_t)(2 * NMX_W64_N + NMX_W64_TWL_FLOATS + 4 * x_floats) * 4;
   hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME), dim3((n_items + 3) / 4), dim3(256), lds, s, *A, n_items,
                      x_floats);
+  NMX_KNAME("nmx_kern_notch_w64q_", "");
   return 1;
 }
 
@@ -152,9 +155,8 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
     if (nw > want) nw = want;
   }
   if (nw < want) return 0;
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>,
@@ -171,43 +173,52 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + (hil ? NMX_W500_TAB_FLOATS : 0) + nw * x_floats) * 4;
   int grid = n_cu > 0 ? n_cu : 256;
   if (grid * nw > n_items) grid = (n_items + nw - 1) / nw;
-  if (notch)
+  if (notch) {
     hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
                        n_items, x_floats);
-  else if (sharp && nw == 8) {
+    NMX_KNAME("nmx_kern_notch_w64p_", "");
+  } else if (sharp && nw == 8) {
     hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
                        n_items, x_floats, *sharp);
+    NMX_KNAME("nmx_kern_bank_w64p_", "<8, 1, 0, 0>");
     return 3;
   } else {
     static const NmxSharpArgs none{};
-    if (nw == 12)
+    if (nw == 12) {
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
-    else if (hil)
+      NMX_KNAME("nmx_kern_bank_w64p_", "<12, 0, 0, 1>");
+    } else if (hil) {
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
-    else if (A->b.W <= 1024 && half_ok)
+      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 1, 0>");
+    } else if (A->b.W <= 1024 && half_ok) {
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
-    else
+      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 0, 1>");
+    } else {
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
+      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 0, 0>");
+    }
   }
   return hil ? 5 : 1;
 }
 
 extern "C" void NMX_CAT(nmx_w64_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, size_t lds,
                                                        hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NAME),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (A->b.pad_mode == 0)
+  if (A->b.pad_mode == 0) {
     hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64_, NMX_W64_NAME), dim3(n_items), dim3(64), lds, s, *A);
-  else
+    NMX_KNAME("nmx_kern_bank_w64_", "");
+  } else {
     hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NAME), dim3(n_items), dim3(64), lds, s, *A);
+    NMX_KNAME("nmx_kern_notch_w64_", "");
+  }
 }

@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(64) nmx_kern_burst_thr_wave(const NmxBurstThrA
 extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s) {
   const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS + A->K / 64 + 4) * 4;
   hipLaunchKernelGGL(nmx_kern_burst_thr_wave, dim3(n_items), dim3(64), lds, s, *A);
+  nmxi_note_kernel("nmx_kern_burst_thr_wave");
 }
 
 // Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)
@@ -53,6 +54,7 @@ __global__ void __launch_bounds__(64) nmx_kern_hilbert_w500(const NmxHilbertArgs
 
 extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long n_items, hipStream_t s) {
   hipLaunchKernelGGL(nmx_kern_hilbert_w500, dim3((unsigned)n_items), dim3(64), (size_t)NMX_W500_LDS_FLOATS * 4, s, *A);
+  nmxi_note_kernel("nmx_kern_hilbert_w500");
 }
 
 // time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
@@ -65,10 +67,13 @@ __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArg
 // returns 0 when the configuration needs the generic kernel
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w1000_ok(*A)) return 0;
-  if (A->n_bands <= 4)
+  if (A->n_bands <= 4) {
     hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
-  else
+    nmxi_note_kernel("nmx_kern_timeosc_w1000<4>");
+  } else {
     hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+    nmxi_note_kernel("nmx_kern_timeosc_w1000<8>");
+  }
   return 1;
 }
 
@@ -85,6 +90,7 @@ extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipSt
   static int order = -1;
   if (order < 0) { const char* v = getenv("NMX_SCAN_ORDER"); order = (v && v[0] == '1') ? 1 : 0; }
   hipLaunchKernelGGL(nmx_kern_scan, dim3((n_items + 3) / 4), dim3(256), 0, s, *A, n_items, n_items / A->n_channels, order);
+  nmxi_note_kernel("nmx_kern_scan");
 }
 
 // dense-first launch: compact LDS layout (more waves per CU); overflowing items are flagged
@@ -96,6 +102,7 @@ __global__ void __launch_bounds__(64) nmx_kern_sharp_dense(const NmxSharpArgs A,
 
 extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s) {
   hipLaunchKernelGGL(nmx_kern_sharp_dense, dim3(n_items), dim3(64), (size_t)A->dz_lds_floats * 4, s, *A, n_items);
+  nmxi_note_kernel("nmx_kern_sharp_dense");
 }
 
 // items the fused bank kernel could not finish (more than 128 extrema of a kind): generic list code.
@@ -111,13 +118,13 @@ __global__ void __launch_bounds__(64) nmx_kern_sharp_todo(const NmxSharpArgs A, 
 
 extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
                                            hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_sharp_todo, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = n_items < 256 * 14 ? n_items : 256 * 14;
   hipLaunchKernelGGL(nmx_kern_sharp_todo, dim3(grid), dim3(64), lds, s, *A, n_items, todo);
+  nmxi_note_kernel("nmx_kern_sharp_todo");
 }
 
 static int waves_per_wg(size_t lds_one) {
@@ -132,25 +139,25 @@ static int waves_per_wg(size_t lds_one) {
 }
 
 extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_items, size_t lds, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_burst_stat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int k = waves_per_wg(lds);
   const int slice = (int)((lds / 4 + 3) & ~(size_t)3);
   hipLaunchKernelGGL(nmx_kern_burst_stat, dim3((n_items + k - 1) / k), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
                      n_items, slice);
+  nmxi_note_kernel("nmx_kern_burst_stat");
 }
 
 extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t lds, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    once = true;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_sharp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int k = waves_per_wg(lds);
   const int slice = (int)((lds / 4 + 3) & ~(size_t)3);
   hipLaunchKernelGGL(nmx_kern_sharp, dim3((n_items + k - 1) / k), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
                      n_items, slice);
+  nmxi_note_kernel("nmx_kern_sharp");
 }

@@ -439,3 +439,10 @@ class HotPathEngine:
         ms = C.c_float()
         self.lib.check(self.lib.lib.nmx_last_timing_ms(self._plan, which, C.byref(ms)))
         return float(ms.value)
+
+    def kernels(self, which: int) -> str:
+        """Kernels the last batch launched in stage ``which`` (1 prep, 2 time/osc, 3 FIR bank, 4 bursts,
+        5 sharp waves), named as rocprofv3 prints them."""
+        buf = C.create_string_buffer(512)
+        self.lib.check(self.lib.lib.nmx_last_kernels(self._plan, which, buf, 512))
+        return buf.value.decode()

@@ -59,6 +59,9 @@ static void be_timer_start(be_timer_t&, be_stream_t) {}
 static void be_timer_stop(be_timer_t& t, be_stream_t) { t.used = true; }
 static float be_timer_elapsed(be_timer_t&) { return 0.f; }
 static int be_check_launch() { return 0; }
+static void be_stage(int) {}
+static void be_stage_reset() {}
+static std::string be_stage_kernels(int) { return "host emulator (tests only)"; }
 
 static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
@@ -107,6 +110,9 @@ static void be_launch_reref(const NmxRerefArgs& A, be_stream_t) {
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t) {
   for (long long t = 0; t < A.T; ++t) nmx_car_sample(A, t);
+}
+static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t) {
+  for (long long t = 0; t < A.T; ++t) nmx_reref_struct_sample(A, t);
 }
 static void be_launch_resample(const NmxResampleArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);

@@ -214,6 +214,8 @@ def case_pipeline():
         "reref_nonorm": lambda s: (setattr(s, "preprocessing", ["re_referencing"]),
                                    setattr(s.postprocessing, "feature_normalization", False)),
         "nopre_norm": lambda s: setattr(s, "preprocessing", []),
+        # the un-normalised features of "default": lets the tests check features and normaliser separately
+        "default_nonorm": lambda s: setattr(s.postprocessing, "feature_normalization", False),
     }.items():
         s = nm.NMSettings.get_default()
         s.features.bandpass_filter = True

@@ -11,20 +11,27 @@ in fp32, the reference in float64:
   * sharp waves: values are gathers/differences of the filtered series -> atol = 1e-5 * max|y|
     (amplitudes) or 1e-5 * window length in ms (times); "var" estimators and the
     between-polarity variance square a difference of nearly equal numbers -> rtol 2e-3
-  * bursts: `env >= thr` is a discrete decision; one borderline sample moves a duration by
-    1/sfreq.  amplitude_max: 1e-5 rel.  Other outputs: compared exactly-to-1e-5 first; a row
-    may differ only by what ONE flipped sample explains (checked explicitly).
-  * near-null spectral bins: a log10-valued feature averages log10|X_k|; fp32 puts an ABSOLUTE
-    error of ~1e-7 * rms on every bin, so a bin whose magnitude happens to be 100x below the rms
-    level (Rayleigh statistics: ~1 bin in 10^4) carries a 1e-5..1e-3 error in log10.  Such
-    conditioning outliers (err <= 2e-3, at most 1 per 500 compared log-spectral entries, minimum
-    2 per call -- overlapping bands share bins) are tolerated and counted; everything else must meet 1e-5.
-  * sharp-wave decision flips: find_peaks' distance suppression and the trough/peak pairing are
-    discrete decisions on the filtered series; where two extrema inside the distance have heights
-    within fp32 rounding the kept one -- and with it a max/mean over a different trough set -- can
-    differ.  Perturbing the INPUT of the float64 oracle by 3e-7 relative flips such a value itself
-    (seen on 1 of 4096 entries of the 256-channel test: -3.7525 <-> -0.5093).  At most one such
-    outlier per 1000 compared sharp-wave entries is tolerated (none in tests with < 1000 entries).
+  * bursts: amplitude_max 1e-5 rel, everything else 1e-5 rel (durations are sample counts / sfreq).
+
+Three output families are not Lipschitz in the data, so fp32 rounding of an intermediate can move
+them by more than any fixed tolerance.  A miss there is NEVER accepted on a count or a magnitude
+cap alone: `compare` accepts it only when a `Verifier` recomputes, in the float64 oracle and for
+THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditioning reports"):
+
+  * log10-valued spectral features (FFT / Welch / STFT with log_transform, "psd" keys): fp32 puts an
+    absolute error of ~1e-7 * rms on every bin, log10 makes it relative.  Accepted iff some bin that
+    contributes to the entry has |X_k| < NULL_RATIO (1e-2) x the rms magnitude of all bins (the fp32
+    error of a transform scales with the total energy, DC included) AND
+    the miss is <= 2e-3 in log10 units.
+  * sharp waves: find_peaks' neighbour comparisons and its distance suppression, then index
+    arithmetic.  Accepted iff the float64 filtered series of that (channel, filter) holds a decision
+    whose margin (min |y[i+1] - y[i]|, or the height difference of two same-kind extrema inside the
+    `distance`) is < DECISION_RTOL (1e-6) x max |input row| -- the size of the fp32 error of the FIR
+    convolution.  All entries of that (channel, filter) then share the verdict.
+  * bursts: `env >= thr`.  Accepted iff min_n |env[n] - thr| of that (channel, band) in the float64
+    oracle is < DECISION_RTOL x max |input row|.
+  Without a verifier nothing is forgiven.  Every accepted entry is counted in `STATS` and the test
+  session prints the counts per test (tests/conftest.py).
   * degenerate rows (all-zero / constant input): spectral bins that are exactly 0 in exact
     arithmetic are rounding noise (1e-16 in float64, 1e-8 in fp32); log10 of noise is not
     comparable and those entries are skipped; +-inf / nan_to_num'ed +-huge values must agree in
@@ -81,47 +88,201 @@ def tolerances(key: str, settings, sfreq: float, amp_scale: float, W: int):
     return 1e-5, 1e-9 * max(amp_scale, 1.0)
 
 
-def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, burst_slack=False):
-    """Returns (n_bad, report, max_rel_by_family).  `skip(key) -> bool` drops degenerate entries."""
+NULL_RATIO = 1e-2       # contributing bin below this fraction of the spectrum's rms: ill-conditioned log10
+LOG_MISS_CAP = 2e-3     # largest accepted miss of a verified near-null entry, log10 units
+DECISION_RTOL = 1e-6    # decision margin relative to max |input row| below which fp32 can flip it
+
+STATS = {"compared": 0, "forgiven": {}, "notes": []}
+
+
+def reset_stats():
+    STATS["compared"] = 0
+    STATS["forgiven"] = {}
+    STATS["notes"] = []
+
+
+def _split_key(key: str, ch_names):
+    """-> (channel index, rest of the key after '<ch>_') for the LONGEST matching channel name."""
+    best = -1
+    for i, ch in enumerate(ch_names):
+        if key.startswith(ch + "_") and (best < 0 or len(ch) > len(ch_names[best])):
+            best = i
+    if best < 0:
+        raise KeyError(key)
+    return best, key[len(ch_names[best]) + 1:]
+
+
+class Verifier:
+    """Per-entry justification of a tolerance miss, recomputed in the float64 oracle.
+
+    ``x`` (or the callable ``x()``): the [C, W] float64 window AS THE FEATURE CLASSES SEE IT (after
+    the pre-processors); ``ch_names``: the names used in the keys.  ``sw_taps`` / ``bank_taps``: the
+    taps the engine was given (goldens store the reference's), else the oracle designs them.
+    ``bursts``: an oracle ``Bursts`` object that has just processed this window (its ``last_env`` /
+    ``last_thr`` carry the history-dependent threshold)."""
+
+    def __init__(self, settings, ch_names, sfreq, x, *, sw_taps=None, bursts=None):
+        self.s, self.ch, self.sfreq = settings, list(ch_names), sfreq
+        self._x = x
+        self._sw_taps = sw_taps
+        self._bursts = bursts
+        self._spec, self._sw_y, self._margin = {}, None, {}
+
+    @property
+    def x(self):
+        if callable(self._x):
+            self._x = np.asarray(self._x(), np.float64)
+        return self._x
+
+    def _amp(self, ci):
+        return float(np.abs(self.x[ci]).max()) + 1e-300
+
+    def spectral(self, key, fam, err):
+        from oracle import nm_oracle as orc
+
+        if err > LOG_MISS_CAP:
+            return False, f"miss {err:.2e} above the cap"
+        ci, rest = _split_key(key, self.ch)
+        if (ci, fam) not in self._spec:
+            self._spec[(ci, fam)] = orc.spectral_magnitudes(fam, self.s, self.sfreq, self.x[ci])
+        mag, idx_range, freqs = self._spec[(ci, fam)]
+        rest = rest[len(fam) + 1:]
+        if rest.startswith("psd_"):
+            f = int(rest[4:])
+            idx = np.array([k for k, fr in enumerate(freqs) if int(fr) == f])
+        else:
+            band = rest.rsplit("_", 1)[0]
+            idx = dict(idx_range)[band]
+        r = orc.spectral_null_ratio(mag, idx)
+        return r < NULL_RATIO, f"min bin / rms = {r:.2e}"
+
+    def sharpwave(self, key):
+        from oracle import nm_oracle as orc
+
+        ci, rest = _split_key(key, self.ch)
+        sw = self.s.sharpwave_analysis_settings
+        names = [f"range_{fr[0]:.0f}_{fr[1]:.0f}" for fr in sw.filter_ranges_hz]
+        fi = max((i for i, n in enumerate(names) if n in rest), key=lambda i: len(names[i]))
+        if (ci, fi) not in self._margin:
+            if self._sw_y is None:
+                an = orc.SharpwaveAnalyzer(self.s, self.ch, self.sfreq, taps=self._sw_taps)
+                self._sw_y = an.filtered(self.x)
+            m = orc.sharpwave_decision_margin(self._sw_y[ci, fi], sw.detect_troughs.distance_peaks_ms,
+                                              sw.detect_troughs.distance_troughs_ms)
+            self._margin[(ci, fi)] = m / self._amp(ci)
+        r = self._margin[(ci, fi)]
+        return r < DECISION_RTOL, f"decision margin / amp = {r:.2e}"
+
+    def bursts(self, key):
+        from oracle import nm_oracle as orc
+
+        if self._bursts is None:
+            return False, "no oracle burst state"
+        if callable(self._bursts):
+            self._bursts = self._bursts()
+        ci, rest = _split_key(key, self.ch)
+        ob = self._bursts
+        rest = rest[len("bursts_"):]
+        bi = max((i for i, n in enumerate(ob.band_names) if rest.startswith(n + "_")),
+                 key=lambda i: len(ob.band_names[i]))
+        r = orc.burst_decision_margin(ob.last_env[ci, bi], ob.last_thr[ci, bi]) / self._amp(ci)
+        return r < DECISION_RTOL, f"min |env - thr| / amp = {r:.2e}"
+
+
+def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, verifier=None):
+    """Returns (n_bad, report, max_rel_by_family).  `skip(key) -> bool` drops degenerate entries.
+    A miss of an ill-conditioned family is accepted only when `verifier` explains it (module
+    docstring); accepted entries are counted in STATS."""
     bad = []
     worst: dict[str, float] = {}
-    n_log = 0
-    outliers = []
-    n_sw = 0
-    sw_flips = []
     for k, g, w in zip(keys, got, want):
         g, w = float(g), float(w)
         if skip is not None and skip(k):
             continue
         if _same_huge(g, w):
             continue
+        STATS["compared"] += 1
         rtol, atol = tolerances(k, settings, sfreq, amp_scale, W)
         fam = family_of(k)
-        if burst_slack and fam == "bursts" and "amplitude_max" not in k:
-            # one flipped borderline sample: durations move by <= 1 sample per burst, means by O(1/len)
-            rtol, atol = 5e-2, 2.0 / sfreq
         err = abs(g - w)
         ok = err <= rtol * abs(w) + atol
         if np.isfinite(w) and w != 0:
             worst[fam] = max(worst.get(fam, 0.0), err / max(abs(w), atol / max(rtol, 1e-30)))
-        is_log = (fam in ("fft", "welch", "stft") and getattr(settings, f"{fam}_settings").log_transform) or \
-                 (fam == "bandpass" and "_activity_" in k and settings.bandpass_filter_settings.log_transform)
-        n_log += bool(is_log)
-        if not ok and is_log and err <= 2e-3:
-            outliers.append((k, g, w))   # near-null-bin conditioning (module docstring)
+        if ok:
             continue
-        n_sw += fam == "sharpwave"
-        if not ok and fam == "sharpwave":
-            sw_flips.append((k, g, w))   # discrete decision flip (module docstring), bounded below
-            continue
-        if not ok:
-            bad.append((k, g, w))
-    if len(outliers) > max(2, n_log // 500):   # (two overlapping bands can share the one bad bin)
-        bad.extend(outliers)
-    if len(sw_flips) > n_sw // 1000:
-        bad.extend(sw_flips)
-    report = "\n".join(f"  {k}: got {g!r} want {w!r}" for k, g, w in bad[:15])
+        why = "no verifier"
+        if verifier is not None:
+            accepted = False
+            if fam in ("fft", "welch", "stft") and getattr(settings, f"{fam}_settings").log_transform:
+                accepted, why = verifier.spectral(k, fam, err)
+            elif fam == "sharpwave":
+                accepted, why = verifier.sharpwave(k)
+            elif fam == "bursts":
+                accepted, why = verifier.bursts(k)
+            if accepted:
+                STATS["forgiven"][fam] = STATS["forgiven"].get(fam, 0) + 1
+                if len(STATS["notes"]) < 40:
+                    STATS["notes"].append(f"{k}: got {g!r} want {w!r} ({why})")
+                continue
+        bad.append((k, g, w, why))
+    report = "\n".join(f"  {k}: got {g!r} want {w!r} [{why}]" for k, g, w, why in bad[:15])
     return len(bad), report, worst
+
+
+class BurstTrace:
+    """Envelope / threshold of one hop of an oracle ``Bursts`` run (what Verifier.bursts reads)."""
+
+    def __init__(self, ob):
+        self.band_names, self.last_env, self.last_thr = list(ob.band_names), ob.last_env, ob.last_thr
+
+
+class BurstTracer:
+    """Runs the oracle's stateful Bursts over consecutive windows ON DEMAND: ``at(i)`` advances to hop
+    i (hops must be asked for in any order; the walk itself is sequential and cached)."""
+
+    def __init__(self, settings, ch_names, sfreq, window_fn, taps=None):
+        from oracle import nm_oracle as orc
+
+        self._ob = orc.Bursts(settings, ch_names, sfreq, taps=taps)
+        self._win, self._trace = window_fn, []
+
+    def at(self, i) -> BurstTrace:
+        while len(self._trace) <= i:
+            self._ob.calc_feature(self._win(len(self._trace)))
+            self._trace.append(BurstTrace(self._ob))
+        return self._trace[i]
+
+
+class PipelineVerifiers:
+    """Verifiers for the rows of a Stream / DataProcessor run: row i's window is the oracle's
+    pre-processed window (nan_to_num + channel pick + pre-processors), computed lazily."""
+
+    def __init__(self, settings, channels: dict, sfreq, data, starts, W, line_noise=50, key_names=None,
+                 ends=None):
+        from oracle import nm_oracle as orc
+
+        self.s, self.sfreq, self.data, self.starts, self.W = settings, sfreq, data, list(starts), int(W)
+        self.ends = list(ends) if ends is not None else [a + int(W) for a in self.starts]
+        self.dp = orc.DataProcessor(sfreq, settings, channels, line_noise)
+        self.names = list(key_names) if key_names is not None else list(self.dp.ch_names_used)
+        self._cache = {}
+        self._tracer = None
+
+    def window(self, i):
+        if i not in self._cache:
+            w = np.nan_to_num(np.asarray(self.data[:, self.starts[i]:self.ends[i]], np.float64))[self.dp.feature_idx]
+            self._cache[i] = self.dp.preprocess(w)
+        return self._cache[i]
+
+    def _burst_trace(self, i):
+        if self._tracer is None:
+            self._tracer = BurstTracer(self.s, self.names, self.dp.sfreq, self.window)
+        return self._tracer.at(i)
+
+    def row(self, i) -> Verifier:
+        has_b = "bursts" in list(self.s.features.get_enabled())
+        return Verifier(self.s, self.names, self.dp.sfreq, lambda: self.window(i),
+                        bursts=(lambda: self._burst_trace(i)) if has_b else None)
 
 
 def reference_order_features(golden, families=("hjorth", "raw", "bandpass", "stft", "fft", "welch",
@@ -157,6 +318,15 @@ def run_feature_case(lib, case: str):
         def skip(k):
             return (k.startswith("ch0_") or k.startswith("ch1_")) and family_of(k) in (
                 "fft", "welch", "stft", "bandpass", "sharpwave", "bursts")
-    n_bad, report, worst = compare(eng.keys, out, list(want.values()), s, sfreq, amp, eng.W, skip)
+    from oracle import nm_oracle as orc
+
+    def first_hop_bursts():
+        ob = orc.Bursts(s, ch, sfreq, taps=g["bursts_taps"])
+        ob.calc_feature(data)
+        return BurstTrace(ob)
+
+    ver = Verifier(s, ch, sfreq, np.asarray(data, np.float64),
+                   sw_taps=[g[f"sw_taps_{i}"] for i in range(n_f)], bursts=first_hop_bursts)
+    n_bad, report, worst = compare(eng.keys, out, list(want.values()), s, sfreq, amp, eng.W, skip, verifier=ver)
     eng.close()
     return n_bad, report, worst

@@ -251,6 +251,10 @@ def test_psd_keys_skip_normalisation(gpu_lib):
     pc.case_psd_keys_skip_normalisation(gpu_lib)
 
 
+def test_reref_structured_matrices(gpu_lib):
+    pc.case_reref_structured_matrices(gpu_lib)
+
+
 def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     """Plan-level knobs select fallback / alternative kernels (list-based sharp-wave code, dense
     re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list, block-wide STFT, generic time / oscillatory kernel).

@@ -108,3 +108,7 @@ def test_raw_normalizer(emu_lib):
 
 def test_psd_keys_skip_normalisation(emu_lib):
     pc.case_psd_keys_skip_normalisation(emu_lib)
+
+
+def test_reref_structured_matrices(emu_lib):
+    pc.case_reref_structured_matrices(emu_lib)
