@@ -11,8 +11,15 @@ channels shard across GPUs with no collective on the data path (weak scaling: 25
 each GPU = one independently referenced electrode array).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     dominant kernel (FIR bank): algorithmic bytes / HIP-event kernel time vs 8 TB/s
-  cpu_baseline the float64 NumPy/SciPy oracle ("port" of the reference) on the host cores
+  roofline     dominant kernel (FIR bank; its NAME comes from the plan = the variant that actually ran):
+               algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM roof, the same kernel against the
+               157.3 TFLOP/s FP32 vector roof (`roofline.fp32`, SURVEY 8(d): the FIR bank is FP32 / LDS
+               bound), and the PMC-measured HBM traffic of that kernel (stamped with the commit it was
+               measured at)
+  cpu_baseline the float64 NumPy/SciPy oracle ("port" of the reference) on ONE host core, median hop time;
+  cpu_baseline_allcores  the same port with the channels split over worker processes (context row)
+  cold_start_ms  the first 1024-hop step of a FRESH plan (the burst history fills during its first 291 hops:
+               the fill-regime threshold walk costs more than a whole steady-state step)
 """
 
 from __future__ import annotations
@@ -30,6 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: FP32 vector (= FP32 matrix) peak
 
 
 def make_settings():
@@ -60,23 +68,67 @@ def car_matrix(C: int) -> np.ndarray:
 
 
 def cpu_baseline(s, C: int, sfreq: float, n_windows: int, seed: int):
-    """Time the CPU oracle (float64 restatement of the reference's process()) on a bounded sample."""
+    """Time the CPU oracle (float64 restatement of the reference's process()) on a bounded sample:
+    median hop time over `n_windows` hops after 2 warm-up hops, one core."""
     from oracle import nm_oracle as orc
 
     W = int(s.segment_length_features_ms / 1000 * sfreq)
     hop = int(sfreq / s.sampling_rate_features_hz)
-    T = W + (n_windows + 1) * hop
+    T = W + (n_windows + 2) * hop
     x = synth(C, T, sfreq, seed).astype(np.float64)
     names = [f"ch{i}" for i in range(C)]
     channels = {"name": names, "rereference": ["average"] * C, "used": [1] * C, "target": [0] * C,
                 "type": ["ecog"] * C, "status": ["good"] * C, "new_name": [f"{n}_avgref" for n in names]}
     dp = orc.DataProcessor(sfreq, s, channels, line_noise=50)
-    dp.process(x[:, :W])  # warm-up (also fills the burst ring like the first hop does)
-    t0 = time.perf_counter()
-    for k in range(1, n_windows + 1):
+    for k in range(2):   # warm-up (the first hop also fills the burst ring like the reference's first hop)
         dp.process(x[:, k * hop:k * hop + W])
-    dt = time.perf_counter() - t0
-    return n_windows / dt, dt
+    per = []
+    for k in range(2, n_windows + 2):
+        t0 = time.perf_counter()
+        dp.process(x[:, k * hop:k * hop + W])
+        per.append(time.perf_counter() - t0)
+    return 1.0 / float(np.median(per)), float(np.sum(per))
+
+
+def _allcores_worker(args):
+    x, names, hops = args
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    from oracle import nm_oracle as orc
+
+    s = make_settings()
+    s.preprocessing = ["raw_resampling", "notch_filter"]          # re-referenced by the parent
+    C = len(names)
+    channels = {"name": names, "rereference": ["None"] * C, "used": [1] * C, "target": [0] * C,
+                "type": ["ecog"] * C, "status": ["good"] * C, "new_name": names}
+    dp = orc.DataProcessor(1000.0, s, channels, line_noise=50)
+    dp.process(x[:, :1000])
+    t0 = time.perf_counter()
+    for k in range(1, hops + 1):
+        dp.process(x[:, k * 100:k * 100 + 1000])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_allcores(C: int, hops: int, procs: int):
+    """The same port with the channels split over `procs` worker processes (one core each); the parent
+    applies the common-average reference once to the stream.  hops / slowest worker."""
+    import multiprocessing as mp
+
+    T = 1000 + (hops + 1) * 100
+    x = car_matrix(C) @ synth(C, T, 1000.0, 99).astype(np.float64)
+    names = [f"ch{i}" for i in range(C)]
+    shards = [ix for ix in np.array_split(np.arange(C), procs) if len(ix)]
+    jobs = [(x[ix], [names[i] for i in ix], hops) for ix in shards]
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        pool.map(_allcores_worker, [(j[0][:, :1100], j[1], 1) for j in jobs])   # start-up: imports, filter design
+        per = pool.map(_allcores_worker, jobs)
+    return hops / max(per), len(jobs), max(per)
+
+
+def bank_flops_per_item(M: int, n_filters: int, seglens) -> float:
+    """forward rFFT(M) + per filter (spectral product 6 (M/2 + 1) + inverse rFFT(M) + tail
+    variance 3 seglen); rFFT(M) ~ 2.5 M log2 M."""
+    rfft = 2.5 * M * np.log2(M)
+    return float(rfft + n_filters * (6 * (M / 2 + 1) + rfft) + 3 * sum(seglens))
 
 
 def main() -> None:
@@ -87,6 +139,8 @@ def main() -> None:
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU")
     ap.add_argument("--windows", type=int, default=1024, help="hops per step (batch)")
     ap.add_argument("--cpu-windows", type=int, default=24, help="hops timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=32, help="worker processes of cpu_baseline_allcores (0 = skip)")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start_ms measurement")
     ap.add_argument("--no-preproc", action="store_true", help="skip notch + re-referencing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
@@ -134,6 +188,16 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
+    cold_ms = None
+    if not args.no_cold_start and rank == 0:   # first step of a fresh plan (outside the timed region)
+        cold = HotPathEngine(s, ch, sfreq, device=dev_index, ref_matrix=car_matrix(C) if pre else None,
+                             notch_taps=fir_design.notch_bank(sfreq, 50) if pre else None)
+        torch.cuda.synchronize(dev)
+        tc = time.perf_counter()
+        cold.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
+        torch.cuda.synchronize(dev)
+        cold_ms = (time.perf_counter() - tc) * 1e3
+        cold.close()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -163,15 +227,24 @@ def main() -> None:
         # dominant kernel = FIR bank (nmx_kern_bank_w64_*): reads each (channel, window) once, writes
         # its 4 band-pass features; the filtered-series hand-off to the Hilbert / sharp-wave kernels
         # is NOT algorithmic traffic (it shows up in `traffic`)
-        bank_bytes = n_win * C * (4 * W + 4 * 4)
+        n_bp = sum(1 for i in range(int(eng.desc.n_filters)) if eng.desc.filters[i].bp_seglen > 0)
+        bank_bytes = n_win * C * (4 * W + 4 * n_bp)
         achieved = bank_bytes / (bank_ms * 1e-3) / 1e9 if bank_ms > 0 else 0.0
-        traffic = None
+        kernel = eng.kernels(3)   # what the plan launched in the FIR-bank stage of the last step
+        traffic = traffic_at = None
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("nmx_kern_bank_bytes_per_launch")
+                doc = json.loads(tfile.read_text())
+                hit = [v for k, v in doc.get("kernels", {}).items() if k.split("<")[0] == kernel.split("<")[0]]
+                if hit:   # PMC passes are separate runs: only reported for the kernel that ran now
+                    traffic = hit[0]["hbm_bytes_per_launch"]
+                    traffic_at = doc.get("measured_at_commit")
             except Exception:
                 traffic = None
+        nf = int(eng.desc.n_filters)
+        flops_item = bank_flops_per_item(2048, nf, [eng.desc.filters[i].bp_seglen for i in range(nf)])
+        tflops = n_win * C * flops_item / (bank_ms * 1e-3) / 1e12 if bank_ms > 0 else 0.0
         res = {
             "metric": "windows/sec (all features), 256 ch @ 1 kHz", "value": value, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -185,16 +258,34 @@ def main() -> None:
             "algorithmic_GBps_pipeline": value / world * C * bytes_cw / 1e9,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
             "nan_outputs": bad,
-            "roofline": {"bound": "hbm", "kernel": "nmx_kern_bank_w64p_scalar<8, 0, 0, 1>", "achieved": achieved,
+            "kernels": {name: eng.kernels(idx) for name, idx in
+                        (("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5))},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "note": "FIR bank is LDS/FP32-vector bound (SURVEY 8d); frac is vs the HBM roof"},
+                         "traffic": traffic, "traffic_measured_at_commit": traffic_at,
+                         "algorithmic_bytes_per_launch": bank_bytes,
+                         "fp32": {"flops_per_item": flops_item, "filters": nf, "achieved_TFLOPs": tflops,
+                                  "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": tflops / FP32_VECTOR_PEAK_TFLOPS},
+                         "note": "the FIR bank is FP32-vector / LDS bound (SURVEY 8d): frac is vs the HBM roof as "
+                                 "the contract asks, fp32.frac vs the roof that binds"},
+            "cold_start_ms": cold_ms,
+            "regime": "steady state: warm-up steps fill the 30 s burst history; cold_start_ms = first step of a fresh plan",
         }
         if args.cpu_windows > 0 and world == 1:   # CPU baseline: rank 0 at N = 1 only
             v, secs = cpu_baseline(s, C, sfreq, args.cpu_windows, 99)
             res["cpu_baseline"] = {"value": v, "unit": "windows/s", "cores": 1, "kind": "port",
-                                   "sample": f"{args.cpu_windows} hops of the same {C}-channel workload "
-                                             f"through oracle.DataProcessor.process ({secs:.1f} s)"}
+                                   "sample": f"median hop time over {args.cpu_windows} hops (after 2 warm-up hops) of the "
+                                             f"same {C}-channel workload through oracle.DataProcessor.process ({secs:.1f} s)"}
+            if args.cpu_procs > 0 and C == 256:
+                try:
+                    procs = min(args.cpu_procs, os.cpu_count() or 1)
+                    va, np_, slow = cpu_baseline_allcores(C, 8, procs)
+                    res["cpu_baseline_allcores"] = {
+                        "value": va, "unit": "windows/s", "cores": np_, "kind": "port", "host_cpus": os.cpu_count(),
+                        "sample": f"8 hops, channels split over {np_} worker processes (1 core each), common-average "
+                                  f"reference applied once by the parent; hops / slowest worker ({slow:.1f} s)"}
+                except Exception as e:   # never let the context row break the bench line
+                    res["cpu_baseline_allcores"] = {"error": repr(e)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

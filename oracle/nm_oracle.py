@@ -1030,34 +1030,42 @@ def run_stream(data: np.ndarray, sfreq: float, settings, channels: dict, line_no
 
 def spectral_magnitudes(family: str, settings, sfreq: float, x_row: np.ndarray):
     """Linear magnitudes behind one channel's FFT / Welch / STFT features:
-    (mag[n_freq] or mag[n_freq, n_seg], [(band, bin_indices)], freqs).
-    Welch returns sqrt(PSD) so that all three are amplitudes."""
+    (mag[n_freq] or mag[n_freq, n_seg], [(band, bin_indices)], freqs, white_gain).
+    Welch returns sqrt(PSD) so that all three are amplitudes.  ``white_gain`` = the rms magnitude a
+    white input of unit rms produces in this family (FFT: sqrt(N); Welch: sqrt(2 / fs) with density
+    scaling and one-sided doubling; STFT: sqrt(sum w^2) / sum w with spectrum scaling)."""
     x = np.asarray(x_row, np.float64)[None]
     if family == "fft":
         o = FFT(settings, ["c"], sfreq)
         mag = np.abs(sp_fft.rfft(x[:, -o.N:], axis=-1))[0]
+        gain = math.sqrt(o.N)
     elif family == "welch":
         o = Welch(settings, ["c"], sfreq)
         mag = np.sqrt(welch_psd(x, o.sfreq, o.sfreq))[0]
+        gain = math.sqrt(2.0 / o.sfreq)
     elif family == "stft":
         o = STFT(settings, ["c"], sfreq)
         mag = stft_mag(x, o.nperseg)[0]
+        w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(o.nperseg) / o.nperseg)
+        gain = math.sqrt(np.sum(w * w)) / np.sum(w)
     else:
         raise ValueError(family)
-    return mag, o.idx_range, o.freqs
+    return mag, o.idx_range, o.freqs, gain
 
 
-def spectral_null_ratio(mag: np.ndarray, idx: np.ndarray) -> float:
-    """min |X_k| over the contributing bins / rms |X_k| over ALL bins (and segments), DC included.
-    An fp32 transform puts an ABSOLUTE error of ~1e-7 * ||x||_2 / sqrt(N) = ~1e-7 * rms_k |X_k|
-    (Parseval) on every bin -- a DC offset raises it for every bin; log10 turns that into a relative
-    one, so a contributing bin at ratio r carries an error of ~1e-7 / r in log10 units."""
+def spectral_null_ratio(mag: np.ndarray, idx: np.ndarray, floor_rms: float) -> float:
+    """min |X_k| over the contributing bins / ``floor_rms``, the magnitude white noise with the rms of
+    the WINDOW (DC offset included) would have in this family (white_gain * rms(x)).
+    Every fp32 sample of the window -- after the fp32 pre-processing -- carries a rounding error
+    relative to its own size, DC included (a 500 uV offset on a 50 uV signal costs a decade); as white
+    noise it adds ~6e-8 * floor_rms to every bin of every family, also those (Welch: detrended, STFT:
+    windowed) whose own spectrum no longer shows the DC.  log10 turns that absolute error into a relative
+    one: a contributing bin at ratio r carries ~1e-7 / r in log10 units."""
     m = np.asarray(mag, np.float64)
-    rms = float(np.sqrt(np.mean(m ** 2)))
     sel = m[np.asarray(idx, dtype=int)]
-    if sel.size == 0 or rms == 0.0:
+    if sel.size == 0 or floor_rms == 0.0:
         return float("inf")
-    return float(sel.min() / rms)
+    return float(sel.min() / floor_rms)
 
 
 def _strict_extrema(z: np.ndarray) -> np.ndarray:

@@ -19,10 +19,10 @@ cap alone: `compare` accepts it only when a `Verifier` recomputes, in the float6
 THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditioning reports"):
 
   * log10-valued spectral features (FFT / Welch / STFT with log_transform, "psd" keys): fp32 puts an
-    absolute error of ~1e-7 * rms on every bin, log10 makes it relative.  Accepted iff some bin that
-    contributes to the entry has |X_k| < NULL_RATIO (1e-2) x the rms magnitude of all bins (the fp32
-    error of a transform scales with the total energy, DC included) AND
-    the miss is <= 2e-3 in log10 units.
+    absolute error on every bin (the rounding of each sample is relative to its size, DC offset
+    included, and spreads over all bins like white noise), log10 makes it relative.  Accepted iff some
+    bin that contributes to the entry has |X_k| < NULL_RATIO (1e-2) x the magnitude white noise with
+    the window's rms (DC included) has in that family AND the miss is <= 2e-3 in log10 units.
   * sharp waves: find_peaks' neighbour comparisons and its distance suppression, then index
     arithmetic.  Accepted iff the float64 filtered series of that (channel, filter) holds a decision
     whose margin (min |y[i+1] - y[i]|, or the height difference of two same-kind extrema inside the
@@ -145,7 +145,7 @@ class Verifier:
         ci, rest = _split_key(key, self.ch)
         if (ci, fam) not in self._spec:
             self._spec[(ci, fam)] = orc.spectral_magnitudes(fam, self.s, self.sfreq, self.x[ci])
-        mag, idx_range, freqs = self._spec[(ci, fam)]
+        mag, idx_range, freqs, gain = self._spec[(ci, fam)]
         rest = rest[len(fam) + 1:]
         if rest.startswith("psd_"):
             f = int(rest[4:])
@@ -153,8 +153,8 @@ class Verifier:
         else:
             band = rest.rsplit("_", 1)[0]
             idx = dict(idx_range)[band]
-        r = orc.spectral_null_ratio(mag, idx)
-        return r < NULL_RATIO, f"min bin / rms = {r:.2e}"
+        r = orc.spectral_null_ratio(mag, idx, gain * float(np.sqrt(np.mean(self.x[ci] ** 2))))
+        return r < NULL_RATIO, f"min bin / white-noise level of the window = {r:.2e}"
 
     def sharpwave(self, key):
         from oracle import nm_oracle as orc

@@ -74,7 +74,8 @@ def test_batch_equals_window_by_window_and_oracle_64ch(gpu_lib):
         for f in feats:
             want.update(f.calc_feature(x[:, a:a + 1000].astype(np.float64)))
         assert list(want) == eng.keys
-        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, 1000)
+        ver = parity.Verifier(s, ch, sfreq, x[:, a:a + 1000].astype(np.float64))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, 1000, verifier=ver)
         assert n_bad == 0, rep
     eng.close()
 
@@ -163,23 +164,21 @@ def test_full_size_properties_256ch(gpu_lib):
     s.preprocessing = ["notch_filter", "re_referencing"]
     s.features.bursts = False
     dp = orc.DataProcessor(1000.0, s, channels, line_noise=50)
+    pv = parity.PipelineVerifiers(s, channels, 1000.0, x, starts, 1000, line_noise=50)
     okeys = None
     for i in (0, 31):
         want = dp.process(x[:, starts[i]:starts[i] + 1000].astype(np.float64))
         okeys = list(want.keys())
         idx = [eng.keys.index(k) for k in okeys]
-        n_bad, rep, _ = parity.compare(okeys, got[i][idx], list(want.values()), s, 1000.0, 300.0, 1000)
+        n_bad, rep, _ = parity.compare(okeys, got[i][idx], list(want.values()), s, 1000.0, 300.0, 1000,
+                                       verifier=pv.row(i))
         assert n_bad == 0, rep
     for e in (eng, eng1, eng4):
         e.close()
 
 
-def test_config3_2khz_8bands_generic_path(gpu_lib):
-    """BASELINE config[2] shape at reduced channel count: 2 kHz, W=2000, 8 bands (L=1999 -> generic
-    multi-wave FIR kernel with a 3000-point convolution), STFT(500) and bursts, vs the oracle."""
-    from oracle import nm_oracle as orc
+def _config3_settings():
     from py_neuromodulation_amd import NMSettings
-    from py_neuromodulation_amd.engine import HotPathEngine
 
     s = NMSettings.get_default()
     s.features.disable_all()
@@ -188,24 +187,150 @@ def test_config3_2khz_8bands_generic_path(gpu_lib):
                              "low_gamma": [60, 80], "high_gamma": [90, 200], "HFA": [200, 400],
                              "broadband": [4, 400]}
     s.bandpass_filter_settings.segment_lengths_ms["broadband"] = 1000
-    s = s.validate()
-    sfreq, C, n_hops = 2000.0, 6, 4
-    T = 2000 + (n_hops - 1) * 200
+    return s.validate()
+
+
+def test_config3_2khz_8bands_256ch(gpu_lib):
+    """BASELINE config[2] at its FULL per-GPU width: 256 ch @ 2 kHz, W = 2000, hop = 200, 8-band band-pass
+    bank (L = 1999), STFT(500) and bursts on two bands.  Hops 0..2 of the batch against the CPU oracle (the
+    bursts history is part of the comparison: hop k needs hops 0..k), and every stateless column of the
+    batch must equal the one-window call bit for bit."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = _config3_settings()
+    sfreq, C, n_hops, W, hop = 2000.0, 256, 5, 2000, 200
+    T = W + (n_hops - 1) * hop
     rng = np.random.default_rng(5)
     t = np.arange(T) / sfreq
-    x = rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-300, 300, (C, 1))
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-300, 300, (C, 1))).astype(np.float32)
     ch = [f"ch{i}" for i in range(C)]
     eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
-    starts = np.arange(n_hops) * 200
+    starts = np.arange(n_hops) * hop
     got = eng.process_batch(x, starts)
+    assert not np.isnan(got).any()
+    eng1 = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    stateless = np.array(["_bursts_" not in k for k in eng.keys])
+    for i in (0, 4):
+        one = eng1.process_window(x[:, starts[i]:starts[i] + W].astype(np.float64))
+        np.testing.assert_array_equal(one[stateless], got[i][stateless])
     feats = [orc.BandPower(s, ch, sfreq), orc.STFT(s, ch, sfreq), orc.Bursts(s, ch, sfreq)]
-    for i, a in enumerate(starts):
+    for i in range(3):
+        w = x[:, starts[i]:starts[i] + W].astype(np.float64)
         want = {}
         for f in feats:
-            want.update(f.calc_feature(x[:, a:a + 2000]))
+            want.update(f.calc_feature(w))
         assert list(want) == eng.keys
-        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, 2000,
-                                       burst_slack=True)
+        ver = parity.Verifier(s, ch, sfreq, w, bursts=parity.BurstTrace(feats[2]))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 300.0, W, verifier=ver)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
+    eng1.close()
+
+
+def test_config4_shard_256_of_1024_notch_car(gpu_lib):
+    """BASELINE config[3]: 1024 ch @ 1 kHz re-referenced JOINTLY (common average over all 1024 rows), notch,
+    FFT + Welch + STFT + band-pass + sharp waves; one GPU computes rows 256..511 (`channel_subset`), i.e. its
+    rows of the folded re-reference matrix read all 1024 input rows (structured kernel: one group sum per
+    sample instead of a dense 256 x 1024 product).  Three hops against the CPU oracle run on the same 1024
+    rows; batch == one-window call bit for bit; the same shard through the dense product must agree."""
+    import os
+
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.data_processor import DataProcessor
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    for f in ("fft", "welch", "stft", "bandpass_filter", "sharpwave_analysis"):
+        setattr(s.features, f, True)
+    s.preprocessing = ["notch_filter", "re_referencing"]
+    s.postprocessing.feature_normalization = False
+    C_all, n_hops, W, hop = 1024, 8, 1000, 100
+    T = W + (n_hops - 1) * hop
+    rng = np.random.default_rng(44)
+    t = np.arange(T) / 1000.0
+    x = (rng.standard_normal((C_all, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + 5 * np.sin(2 * np.pi * 50 * t)
+         + rng.uniform(-500, 500, (C_all, 1))).astype(np.float32)
+    names = [f"ch{i}" for i in range(C_all)]
+    channels = {"name": names, "rereference": ["average"] * C_all, "used": [1] * C_all, "target": [0] * C_all,
+                "type": ["ecog"] * C_all, "status": ["good"] * C_all, "new_name": [f"{n}_avgref" for n in names]}
+    shard = range(256, 512)
+    starts = np.arange(n_hops) * hop
+    dp = DataProcessor(1000.0, s, channels, line_noise=50, verbose=False, lib=gpu_lib, window=W, channel_subset=shard)
+    assert dp.engine.C == 256 and dp.engine.C_in == 1024
+    got = dp.engine.process_batch(x, starts)
+    assert "nmx_kern_reref_struct" in dp.engine.kernels(1) or "emulator" in dp.engine.kernels(1)
+    assert not np.isnan(got).any()
+    one = dp.engine.process_window(x[:, starts[5]:starts[5] + W].astype(np.float64))
+    np.testing.assert_array_equal(one, got[5])
+    os.environ["NMX_REREF_STRUCT"] = "0"
+    try:
+        dpd = DataProcessor(1000.0, s, channels, line_noise=50, verbose=False, lib=gpu_lib, window=W, channel_subset=shard)
+        dense = dpd.engine.process_batch(x, starts[:2])
+        assert ("nmx_kern_reref" in dpd.engine.kernels(1) and "struct" not in dpd.engine.kernels(1)) or "emulator" in dpd.engine.kernels(1)
+    finally:
+        del os.environ["NMX_REREF_STRUCT"]
+    # oracle: pre-process all 1024 rows, features of the shard's rows
+    odp = orc.DataProcessor(1000.0, s, channels, line_noise=50)
+    sub_names = [channels["new_name"][i] for i in shard]
+    feats = [orc._FEATURE_CLS[f](s, sub_names, 1000.0) for f in dp.engine.enabled]
+    for i in (0, 1, 7):
+        pre = odp.preprocess(x[:, starts[i]:starts[i] + W].astype(np.float64))[list(shard)]
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(pre))
+        ver = parity.Verifier(s, sub_names, 1000.0, pre)
+        n_bad, rep, _ = parity.compare(dp.engine.keys, got[i], [want[k] for k in dp.engine.keys], s, 1000.0, 700.0, W,
+                                       verifier=ver)
+        assert n_bad == 0, f"hop {i}\n{rep}"
+        if i < 2:   # dense product of the same rows: same features within the policy
+            n_bad, rep, _ = parity.compare(dp.engine.keys, dense[i], [want[k] for k in dp.engine.keys], s, 1000.0, 700.0, W,
+                                           verifier=ver)
+            assert n_bad == 0, f"dense hop {i}\n{rep}"
+    dp.engine.close()
+    dpd.engine.close()
+
+
+def test_config5_30khz_512ch(gpu_lib):
+    """BASELINE config[4] at its FULL per-GPU width: 512 of 4096 ch @ 30 kHz, 512-sample windows, hop 30
+    (settings of tests/parity_cases.case_config5_30khz_512pt), three hops vs the oracle + batch == one-window."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    base = NMSettings.get_default().to_dict()
+    base["frequency_ranges_hz"] = {"gamma": [60, 200], "HFA": [200, 500], "MUA": [500, 3000], "spike": [3000, 7000]}
+    s = NMSettings(**base)
+    s.features.disable_all()
+    for f in ("fft", "stft", "raw_hjorth", "linelength", "return_raw", "bandpass_filter", "sharpwave_analysis"):
+        setattr(s.features, f, True)
+    s.sampling_rate_features_hz = 1000
+    s.segment_length_features_ms = 17
+    s.fft_settings.windowlength_ms = 17
+    s.stft_settings.windowlength_ms = 17
+    s.bandpass_filter_settings.segment_lengths_ms = {"gamma": 17, "HFA": 10, "MUA": 5, "spike": 3}
+    s.sharpwave_analysis_settings.filter_ranges_hz = [[500, 3000], [1000, 7000]]
+    s = NMSettings(**s.to_dict())
+    sfreq, C, W, hop, nh = 30000.0, 512, 512, 30, 16
+    rng = np.random.default_rng(0)
+    T = W + (nh - 1) * hop
+    t = np.arange(T) / sfreq
+    x = (rng.standard_normal((C, T)) * 30 + 40 * np.sin(2 * np.pi * 900 * t) + rng.uniform(-100, 100, (C, 1))).astype(np.float32)
+    ch = [f"c{i}" for i in range(C)]
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib, window=W)
+    starts = np.arange(nh) * hop
+    got = eng.process_batch(x, starts)
+    one = eng.process_window(x[:, starts[9]:starts[9] + W].astype(np.float64))
+    np.testing.assert_array_equal(one, got[9])
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in eng.enabled]
+    for i in (0, 7, 15):
+        w = x[:, starts[i]:starts[i] + W].astype(np.float64)
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(w))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 200.0, W,
+                                       verifier=parity.Verifier(s, ch, sfreq, w))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
 
@@ -257,8 +382,12 @@ def test_reref_structured_matrices(gpu_lib):
 
 def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     """Plan-level knobs select fallback / alternative kernels (list-based sharp-wave code, dense
-    re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list, block-wide STFT, generic time / oscillatory kernel).
-    They must reproduce the default path on the bench feature set within the parity tolerances."""
+    re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list,
+    block-wide STFT, generic time / oscillatory kernel, small chunks).  EVERY path -- the default one
+    included -- is compared with the float64 oracle over the whole 72-hop stream under the standard policy
+    (bursts history included), so a path cannot hide behind another path's rounding."""
+    from oracle import nm_oracle as orc
+
     C, n_hops = 64, 72    # 4608 items: enough for the persistent bank kernel (>= 4096) and its fused variants
     T = 1000 + (n_hops - 1) * 100
     rng = np.random.default_rng(77)
@@ -273,7 +402,26 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
         eng.close()
         return s, keys, out
 
-    s, keys, want = run()
+    s, keys, default = run()
+    names = [f"ch{i}" for i in range(C)]
+    channels = {"name": names, "rereference": ["average"] * C, "used": [1] * C, "target": [0] * C,
+                "type": ["ecog"] * C, "status": ["good"] * C, "new_name": [f"{n}_avgref" for n in names]}
+    so = type(s)(**s.to_dict())
+    so.postprocessing.feature_normalization = False
+    so.preprocessing = ["notch_filter", "re_referencing"]
+    dp = orc.DataProcessor(1000.0, so, channels, line_noise=50)
+    want = []
+    for a in starts:
+        d = dp.process(x[:, a:a + 1000].astype(np.float64))
+        want.append([d[k] for k in keys])
+    pv = parity.PipelineVerifiers(so, channels, 1000.0, x, starts, 1000, line_noise=50)
+
+    def check(tag, got):
+        for i in range(n_hops):
+            b, rep, _ = parity.compare(keys, got[i], want[i], so, 1000.0, 400.0, 1000, verifier=pv.row(i))
+            assert b == 0, f"{tag} hop {i}\n{rep}"
+
+    check("default", default)
     for knob, val in (("NMX_SW_DENSE", "0"), ("NMX_SW_DENSE_FIRST", "0"), ("NMX_CAR_FAST", "0"), ("NMX_OVERLAP", "0"),
                       ("NMX_FUSE_SHARP", "1"), ("NMX_FUSE_HILBERT", "1"), ("NMX_THR_LIST_GLOBAL", "1"), ("NMX_STFT_PER_WAVE", "0"),
                       ("NMX_TIMEOSC_W1000", "0"), ("NMX_SHARP_FIRST", "1"),
@@ -282,25 +430,7 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
         _, keys2, got = run()
         monkeypatch.delenv(knob)
         assert keys2 == keys
-        # two fp32 paths against each other: every entry inside the per-family tolerance except the
-        # near-null-bin / decision-flip outliers of tests/parity.py, here bounded as a fraction (both
-        # sides carry the fp32 error) with the same absolute caps
-        n_bad = 0
-        for i in range(n_hops):
-            b, rep, _ = parity.compare(keys, got[i], want[i].astype(np.float64), s, 1000.0, 400.0, 1000,
-                                       burst_slack=True)
-            if b:
-                fam = [parity.family_of(k) for k in keys]
-                err = np.abs(got[i].astype(np.float64) - want[i])
-                spectral = np.array([f in ("fft", "welch", "stft", "bandpass") for f in fam])
-                # cap: a mean of log10 magnitudes moves by this much when ONE of its bins sits ~1e-5 below
-                # the typical magnitude.  That is not rare in the first / last STFT segment: the even
-                # boundary extension makes the segment symmetric, its spectrum real up to a sign, and a
-                # real value crosses zero with probability ~eps (not eps^2 as a complex one does).  Both
-                # sides are fp32 here, so such a bin differs by ~10 % between any two summation orders.
-                assert err[spectral].max() < 2e-2, f"{knob}={val} hop {i}\n{rep}"
-            n_bad += b
-        assert n_bad <= max(2, got.size // 2000), f"{knob}={val}: {n_bad} entries outside tolerance"
+        check(f"{knob}={val}", got)
 
 
 def test_linearity_of_the_filter_stages(gpu_lib):
@@ -408,6 +538,30 @@ def test_persistent_bank_equals_one_window_kernel_other_lengths(gpu_lib, W):
         want = {}
         for f in feats:
             want.update(f.calc_feature(x[:, starts[i]:starts[i] + W].astype(np.float64)))
-        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 400.0, W)
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 400.0, W,
+                                       verifier=parity.Verifier(s, ch, sfreq, x[:, starts[i]:starts[i] + W].astype(np.float64)))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def test_stream_output_files(gpu_lib, tmp_path):
+    pc.case_stream_output_files(gpu_lib, tmp_path)
+
+
+def test_abi_from_plain_c_on_the_gpu(tmp_path):
+    """tests/c_abi/abi_smoke.c on a box WITH a device: its `ndev > 0` branch creates a plan and computes one
+    feature through the C ABI from plain C (the CPU tier only reaches the argument checks)."""
+    import subprocess
+    from pathlib import Path
+
+    import __graft_entry__ as g
+
+    root = Path(__file__).resolve().parent.parent
+    lib = g.build_lib()
+    exe = tmp_path / "abi_smoke"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", str(root / "tests" / "c_abi" / "abi_smoke.c"), "-I", str(root / "include"),
+           "-L", str(lib.parent), "-lnmx", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK devices="), r.stdout + r.stderr
+    assert int(r.stdout.split("=")[1]) >= 1

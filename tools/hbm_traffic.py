@@ -43,6 +43,7 @@ def main(fetch_db, write_db, out, skip=0):
     doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), averaged per launch of "
                    "bench.py's 1024-hop step. bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE (gfx950 FETCH "
                    "correction, MI355X_MICROARCH.md HBM section).",
+           "measured_at_commit": (open(".gpurun_commit").read().strip() if __import__("os").path.exists(".gpurun_commit") else None),
            "kernels": res,
            "nmx_kern_bank_bytes_per_launch": bank["hbm_bytes_per_launch"] if bank else None}
     json.dump(doc, open(out, "w"), indent=1)
