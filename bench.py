@@ -236,7 +236,7 @@ def main() -> None:
         if tfile.exists():
             try:
                 doc = json.loads(tfile.read_text())
-                hit = [v for k, v in doc.get("kernels", {}).items() if k.split("<")[0] == kernel.split("<")[0]]
+                hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == kernel]
                 if hit:   # PMC passes are separate runs: only reported for the kernel that ran now
                     traffic = hit[0]["hbm_bytes_per_launch"]
                     traffic_at = doc.get("measured_at_commit")

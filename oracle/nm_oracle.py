@@ -1068,6 +1068,21 @@ def spectral_null_ratio(mag: np.ndarray, idx: np.ndarray, floor_rms: float) -> f
     return float(sel.min() / floor_rms)
 
 
+def spectral_log_error_bound(mag: np.ndarray, idx: np.ndarray, floor_rms: float, eps: float,
+                             power: bool, estimator: str) -> float:
+    """Largest change of the log10-valued entry that an absolute error of eps * floor_rms on every
+    contributing bin explains: per bin log10(1 + eps * floor_rms / |X_k|) (twice that for a power
+    spectrum); their MEAN for the "mean" estimator, their MAX for median / std / max and single-bin
+    ("psd") entries (one bin can move those by at most its own error)."""
+    m = np.asarray(mag, np.float64)
+    sel = np.abs(m[np.asarray(idx, dtype=int)]).ravel()
+    if sel.size == 0:
+        return 0.0
+    with np.errstate(divide="ignore"):
+        per = np.log10(1.0 + eps * floor_rms / sel) * (2.0 if power else 1.0)
+    return float(per.mean() if estimator == "mean" else per.max())
+
+
 def _strict_extrema(z: np.ndarray) -> np.ndarray:
     return find_peaks_distance(z, None)
 

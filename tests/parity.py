@@ -22,7 +22,9 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
     absolute error on every bin (the rounding of each sample is relative to its size, DC offset
     included, and spreads over all bins like white noise), log10 makes it relative.  Accepted iff some
     bin that contributes to the entry has |X_k| < NULL_RATIO (1e-2) x the magnitude white noise with
-    the window's rms (DC included) has in that family AND the miss is <= 2e-3 in log10 units.
+    the window's rms (DC included) has in that family AND the miss is no larger than what an absolute
+    error of FP32_BIN_EPS (1e-6, ~16 fp32 ulp) x that level on each contributing bin explains (computed per entry from
+    the oracle's own bins: mean of log10(1 + eps * level / |X_k|) for "mean" entries, the max otherwise).
   * sharp waves: find_peaks' neighbour comparisons and its distance suppression, then index
     arithmetic.  Accepted iff the float64 filtered series of that (channel, filter) holds a decision
     whose margin (min |y[i+1] - y[i]|, or the height difference of two same-kind extrema inside the
@@ -89,7 +91,7 @@ def tolerances(key: str, settings, sfreq: float, amp_scale: float, W: int):
 
 
 NULL_RATIO = 1e-2       # contributing bin below this fraction of the spectrum's rms: ill-conditioned log10
-LOG_MISS_CAP = 2e-3     # largest accepted miss of a verified near-null entry, log10 units
+FP32_BIN_EPS = 1e-6     # absolute fp32 error of a spectral bin (pre-processing + transform) relative to the window's white-noise level: ~16 ulp
 DECISION_RTOL = 1e-6    # decision margin relative to max |input row| below which fp32 can flip it
 
 STATS = {"compared": 0, "forgiven": {}, "notes": []}
@@ -119,11 +121,16 @@ class Verifier:
     the pre-processors); ``ch_names``: the names used in the keys.  ``sw_taps`` / ``bank_taps``: the
     taps the engine was given (goldens store the reference's), else the oracle designs them.
     ``bursts``: an oracle ``Bursts`` object that has just processed this window (its ``last_env`` /
-    ``last_thr`` carry the history-dependent threshold)."""
+    ``last_thr`` carry the history-dependent threshold).  ``raw``: the window BEFORE the pre-processors
+    (all input rows) when there are any: the engine re-references / filters in fp32, so the rounding of
+    its pre-processed samples is relative to the RAW magnitudes (a common DC offset that the common
+    average removes still costs its fp32 ulps); the noise level of a channel is taken from the larger
+    of the two rms values."""
 
-    def __init__(self, settings, ch_names, sfreq, x, *, sw_taps=None, bursts=None):
+    def __init__(self, settings, ch_names, sfreq, x, *, sw_taps=None, bursts=None, raw=None):
         self.s, self.ch, self.sfreq = settings, list(ch_names), sfreq
         self._x = x
+        self._raw = raw
         self._sw_taps = sw_taps
         self._bursts = bursts
         self._spec, self._sw_y, self._margin = {}, None, {}
@@ -134,27 +141,44 @@ class Verifier:
             self._x = np.asarray(self._x(), np.float64)
         return self._x
 
+    @property
+    def raw(self):
+        if callable(self._raw):
+            self._raw = np.nan_to_num(np.asarray(self._raw(), np.float64))
+        return self._raw
+
     def _amp(self, ci):
-        return float(np.abs(self.x[ci]).max()) + 1e-300
+        a = float(np.abs(self.x[ci]).max())
+        if self.raw is not None:
+            a = max(a, float(np.abs(self.raw).max()))
+        return a + 1e-300
+
+    def _rms(self, ci):
+        r = float(np.sqrt(np.mean(self.x[ci] ** 2)))
+        if self.raw is not None:
+            r = max(r, float(np.sqrt(np.mean(self.raw ** 2))))
+        return r
 
     def spectral(self, key, fam, err):
         from oracle import nm_oracle as orc
 
-        if err > LOG_MISS_CAP:
-            return False, f"miss {err:.2e} above the cap"
         ci, rest = _split_key(key, self.ch)
         if (ci, fam) not in self._spec:
             self._spec[(ci, fam)] = orc.spectral_magnitudes(fam, self.s, self.sfreq, self.x[ci])
         mag, idx_range, freqs, gain = self._spec[(ci, fam)]
         rest = rest[len(fam) + 1:]
+        est = "psd"
         if rest.startswith("psd_"):
             f = int(rest[4:])
             idx = np.array([k for k, fr in enumerate(freqs) if int(fr) == f])
         else:
-            band = rest.rsplit("_", 1)[0]
+            band, est = rest.rsplit("_", 1)
             idx = dict(idx_range)[band]
-        r = orc.spectral_null_ratio(mag, idx, gain * float(np.sqrt(np.mean(self.x[ci] ** 2))))
-        return r < NULL_RATIO, f"min bin / white-noise level of the window = {r:.2e}"
+        floor = gain * self._rms(ci)
+        r = orc.spectral_null_ratio(mag, idx, floor)
+        bound = orc.spectral_log_error_bound(mag, idx, floor, FP32_BIN_EPS, fam == "welch", est)
+        return (r < NULL_RATIO and err <= bound,
+                f"min bin / white-noise level of the window = {r:.2e}, miss {err:.1e} <= explained {bound:.1e}")
 
     def sharpwave(self, key):
         from oracle import nm_oracle as orc
@@ -282,7 +306,8 @@ class PipelineVerifiers:
     def row(self, i) -> Verifier:
         has_b = "bursts" in list(self.s.features.get_enabled())
         return Verifier(self.s, self.names, self.dp.sfreq, lambda: self.window(i),
-                        bursts=(lambda: self._burst_trace(i)) if has_b else None)
+                        bursts=(lambda: self._burst_trace(i)) if has_b else None,
+                        raw=(lambda: self.data[:, self.starts[i]:self.ends[i]]) if self.dp.pre else None)
 
 
 def reference_order_features(golden, families=("hjorth", "raw", "bandpass", "stft", "fft", "welch",

@@ -622,7 +622,7 @@ def case_resampler(lib):
         for f in feats:
             want.update(f.calc_feature(y))
         n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, 1000.0,
-                                       float(np.abs(w).max()), 1000, verifier=parity.Verifier(s, ["a", "b"], 1000.0, y))
+                                       float(np.abs(w).max()), 1000, verifier=parity.Verifier(s, ["a", "b"], 1000.0, y, raw=w))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
     # Stream level: the reference's raw-rate quirk is refused by default, the consistent pipeline is opt-in
@@ -647,7 +647,7 @@ def case_resampler(lib):
             want.update(f.calc_feature(y))
         n_bad, rep, _ = parity.compare(names, df.iloc[i][names].to_numpy(dtype=np.float64),
                                        [want[k] for k in names], s, 1000.0, float(np.abs(xs).max()), 1000,
-                                       verifier=parity.Verifier(s, ["ch0_avgref", "ch1_avgref"], 1000.0, y))
+                                       verifier=parity.Verifier(s, ["ch0_avgref", "ch1_avgref"], 1000.0, y, raw=xs[:, a:a + W]))
         assert n_bad == 0, f"stream hop {i}\n{rep}"
 
 

@@ -280,7 +280,7 @@ def test_config4_shard_256_of_1024_notch_car(gpu_lib):
         want = {}
         for f in feats:
             want.update(f.calc_feature(pre))
-        ver = parity.Verifier(s, sub_names, 1000.0, pre)
+        ver = parity.Verifier(s, sub_names, 1000.0, pre, raw=x[:, starts[i]:starts[i] + W].astype(np.float64))
         n_bad, rep, _ = parity.compare(dp.engine.keys, got[i], [want[k] for k in dp.engine.keys], s, 1000.0, 700.0, W,
                                        verifier=ver)
         assert n_bad == 0, f"hop {i}\n{rep}"
