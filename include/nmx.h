@@ -187,6 +187,12 @@ typedef struct {
   int32_t raw_norm_method;
   int32_t raw_norm_n, raw_norm_add;
   float raw_norm_clip;
+
+  /* settings.segment_length_features_ms / 1000 as the reference's Bursts uses it (features/bursts.py:81-85:
+   * samples_overlap = int(sfreq * seg_s / feat_hz), burst_rate_per_s = duration_mean / seg_s).  0 = derive
+   * it as window / sfreq.  It differs from window / sfreq when raw_resampling changes the window length
+   * while the features are still built with the RAW rate (stream/data_processor.py:55,68,80). */
+  double segment_length_s;
 } nmx_plan_desc;
 
 typedef struct nmx_plan nmx_plan;

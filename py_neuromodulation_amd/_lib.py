@@ -69,6 +69,7 @@ class PlanDesc(C.Structure):
         ("n_pre_filters", C.c_int32), ("pre_taps", C.POINTER(C.c_double) * 4), ("n_pre_taps", C.c_int32 * 4),
         ("raw_norm_method", C.c_int32), ("raw_norm_n", C.c_int32), ("raw_norm_add", C.c_int32),
         ("raw_norm_clip", C.c_float),
+        ("segment_length_s", C.c_double),
     ]
 
 

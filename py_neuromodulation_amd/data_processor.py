@@ -80,21 +80,22 @@ class DataProcessor:
             elif name == "raw_resampling":
                 new_rate = float(st.raw_resampling_settings.resample_freq_hz)
                 if float(new_rate / self.sfreq_raw) != 1.0:
-                    if not resample_features_at_new_rate:
-                        raise NotImplementedError(
-                            "raw_resampling at a ratio != 1: the reference resamples every window but "
-                            "keeps building notch AND features with the RAW rate "
-                            "(stream/data_processor.py:55,68,80), i.e. all frequency axes are off by the "
-                            "ratio.  That behaviour is not reproduced.  Pass "
-                            "resample_features_at_new_rate=True for the consistent pipeline (notch at the "
-                            "raw rate, FFT resampling on the device, features at the new rate), or set "
-                            "raw_resampling_settings.resample_freq_hz == sfreq.")
+                    # The reference resamples every window but keeps building notch AND features with the
+                    # RAW rate (stream/data_processor.py:55,68,80): every frequency axis of the features is
+                    # off by the ratio.  Reproduced as is (default); resample_features_at_new_rate=True
+                    # selects the consistent pipeline (features designed for the rate they see).
                     resample_to = new_rate
+                    if not resample_features_at_new_rate:
+                        from . import logger
+
+                        logger.info("raw_resampling %g -> %g Hz: features are designed with the raw rate like "
+                                    "the reference (pass resample_features_at_new_rate=True for the new rate)",
+                                    self.sfreq_raw, new_rate)
             elif name == "re_referencing":
                 R = chmod.reref_matrix(self.channels)
             elif name == "raw_normalization":
                 rs = st.raw_normalization_settings
-                rate = resample_to if resample_to is not None else self.sfreq_raw
+                rate = resample_to if (resample_to is not None and resample_features_at_new_rate) else self.sfreq_raw
                 # normalization.py:52-58: add_samples = int(sfreq / feat_hz), N = int(time_s * sfreq)
                 raw_norm = (rs.normalization_method, rs.clip, int(rs.normalization_time_s * rate),
                             int(rate / st.sampling_rate_features_hz))
@@ -125,12 +126,17 @@ class DataProcessor:
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, window=window, lib=lib, dry_run=dry_run,
                                         pre_taps=pre_taps, raw_norm=raw_norm)
-        else:   # `window` counts RAW samples (the generator cuts raw data)
+        elif resample_features_at_new_rate:   # `window` counts RAW samples (the generator cuts raw data)
             self.engine = HotPathEngine(st, names, resample_to, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, lib=lib, dry_run=dry_run,
                                         resample_from=self.sfreq_raw, raw_window=window, pre_taps=pre_taps,
                                         raw_norm=raw_norm)
             self.sfreq_raw = resample_to
+        else:   # the reference: windows resampled, everything designed with the raw rate
+            self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
+                                        device=device, lib=lib, dry_run=dry_run,
+                                        resample_from=self.sfreq_raw, resample_to=resample_to,
+                                        raw_window=window, pre_taps=pre_taps, raw_norm=raw_norm)
         self.keys = self.engine.keys
         self.feature_normalizer = None
         self.non_psd_indices = None

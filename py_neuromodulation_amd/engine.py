@@ -53,11 +53,18 @@ class HotPathEngine:
                  window: int | None = None, dry_run: bool = False,
                  resample_from: float | None = None, raw_window: int | None = None,
                  pre_taps: Sequence[np.ndarray] | None = None,
-                 raw_norm: tuple | None = None) -> None:
-        """``sfreq`` is the rate the features see.  ``resample_from`` = sampling rate of the incoming
-        windows when it differs (raw_resampling, processing/resample.py:19-60): incoming windows then
-        hold ``raw_window`` samples (default int(segment_length_features_ms / 1000 * resample_from)) and
-        are resampled on the device to ``window`` = round(ratio * raw_window) samples.
+                 raw_norm: tuple | None = None, resample_to: float | None = None) -> None:
+        """``sfreq`` is the rate every feature and filter is DESIGNED with (what the reference passes to the
+        feature constructors).  ``resample_from`` = sampling rate of the incoming windows when they are
+        resampled (raw_resampling, processing/resample.py:19-60): incoming windows then hold ``raw_window``
+        samples (default int(segment_length_features_ms / 1000 * resample_from)) and are resampled on the
+        device to ``window`` = round(ratio * raw_window) samples, ratio = ``resample_to`` / resample_from.
+        ``resample_to`` defaults to ``sfreq`` (features designed for the rate they see).  The reference
+        instead keeps designing with the RAW rate (stream/data_processor.py:55,68,80): that is
+        ``sfreq = resample_from`` with ``resample_to`` = the new rate -- windows of round(ratio * raw_window)
+        samples analysed as if sampled at the raw rate (FFT / Welch segments longer than the window shrink
+        to it as NumPy slicing / scipy.signal.welch do, band-pass tails are clamped, bursts keep
+        seg_s = segment_length_features_ms / 1000).
 
         ``dry_run=True`` only derives the plan description and the key list (no library, no
         GPU) -- used to lay out the global column order when channels are sharded over GPUs."""
@@ -75,8 +82,9 @@ class HotPathEngine:
         # window samples as the generator cuts them (stream/generator.py:34-53)
         self.W = int(window) if window is not None else int(settings.segment_length_features_ms / 1000 * sfreq)
         self.W_in, self.resample_ratio = self.W, 0.0
-        if resample_from is not None and float(resample_from) != self.sfreq:
-            self.resample_ratio = self.sfreq / float(resample_from)
+        target = self.sfreq if resample_to is None else float(resample_to)
+        if resample_from is not None and float(resample_from) != target:
+            self.resample_ratio = target / float(resample_from)
             self.W_in = (int(raw_window) if raw_window is not None
                          else int(settings.segment_length_features_ms / 1000 * float(resample_from)))
             if window is None:
@@ -109,7 +117,10 @@ class HotPathEngine:
                 f"than settings['segment_length_features_ms'] = "
                 f"{self.settings.segment_length_features_ms}")
         o = _lib.OscDesc()
-        o.n = int(n)
+        # a segment longer than the window shrinks to it: x[:, -N:] (oscillatory.py:95) and
+        # scipy.signal.welch's nperseg clamp; the band bins keep the grid of the NOMINAL length
+        n_eff = min(int(n), self.W) if name in ("fft", "welch") else int(n)
+        o.n = n_eff
         o.log_transform = int(bool(s.log_transform))
         ests = _enabled(s.features)
         o.estimators = sum(_lib.EST_BITS[e] for e in ests)
@@ -120,6 +131,9 @@ class HotPathEngine:
                 raise ValueError("non-contiguous band bins")
             o.bin_lo[b] = int(idx[0]) if idx.size else 0
             o.bin_hi[b] = int(idx[-1]) + 1 if idx.size else 0
+            if o.bin_hi[b] > n_eff // 2 + 1:
+                raise IndexError(f"{name}: band {bands[b][0]} reads bin {o.bin_hi[b] - 1} of a spectrum with "
+                                 f"{n_eff // 2 + 1} bins (window shorter than the nominal segment)")
         # keys: band, estimator, channel  (oscillatory.py:102-112)
         o.cols = _cols(base, 1, len(ests) * self.C, self.C)
         for bname, _ in bands:
@@ -127,6 +141,8 @@ class HotPathEngine:
                 self.keys += [f"{ch}_{name}_{bname}_{e}" for ch in self.ch_names]
         used = len(bands) * len(ests) * self.C
         if o.return_spectrum:
+            if len(freqs) != n_eff // 2 + 1:
+                raise IndexError(f"{name}: return_spectrum needs a window as long as the nominal segment")
             ints = [int(f) for f in freqs]
             if len(set(ints)) != len(ints):
                 raise NotImplementedError(
@@ -160,6 +176,7 @@ class HotPathEngine:
             d.pre_taps[i] = self._dptr(t)
             d.n_pre_taps[i] = len(t)
         d.sfreq = sfreq
+        d.segment_length_s = float(st.segment_length_features_ms) / 1000.0
         d.feat_hz = float(st.sampling_rate_features_hz)
         bands = [(name, (float(fr[0]), float(fr[1]))) for name, fr in st.frequency_ranges_hz.items()]
         if len(bands) > _lib.NMX_MAX_BANDS:
@@ -229,7 +246,7 @@ class HotPathEngine:
                 d.bp_cols = _cols(col, len(bands) * nf, nf, 1)
                 for name, _ in bands:
                     fd = bank_filter(name)
-                    fd["bp_seglen"] = int(np.floor(sfreq / 1000 * bp.segment_lengths_ms[name]))
+                    fd["bp_seglen"] = min(int(np.floor(sfreq / 1000 * bp.segment_lengths_ms[name])), W)   # y[..., -seglen:]
                     fd["bp_band"] = band_index[name]
                 for ch in self.ch_names:
                     for name, _ in bands:

@@ -393,6 +393,33 @@ def case_raw_normalizer():
     print("raw_normalizer", {k: np.shape(v) for k, v in out.items() if k.endswith("_y")})
 
 
+def case_resample_quirk():
+    """Recordings that are NOT sampled at raw_resampling_settings.resample_freq_hz (1000 Hz) under the default
+    pre-processing: the reference resamples every window (processing/resample.py:42-60) but keeps building
+    notch and features with the RAW rate (stream/data_processor.py:55,68,80).  Down- (2 kHz) and up-sampling
+    (250 Hz) through the reference's own Stream.run; restated mne.filter.resample (parity unpinned vs MNE)."""
+    out = {}
+    for tag, sf in (("down_2k", 2000), ("up_250", 250)):
+        rng = np.random.default_rng(50 + sf)
+        T = int(2 * sf + 6 * sf / 10)
+        t = np.arange(T) / sf
+        data = (rng.standard_normal((3, T)) * 20 + 30 * np.sin(2 * np.pi * 50 * t) + 25 * np.sin(2 * np.pi * 17 * t)
+                + rng.uniform(-100, 100, (3, 1)))
+        s = nm.NMSettings.get_default()
+        s.features.bandpass_filter = True
+        s.features.stft = True
+        s.postprocessing.feature_normalization = False
+        st, df = _run_stream(data, sf, s)
+        out[f"{tag}_sfreq"] = sf
+        out[f"{tag}_data"] = data
+        out[f"{tag}_settings_json"] = dump(st.settings)
+        out[f"{tag}_columns"] = np.array(list(df.columns))
+        out[f"{tag}_values"] = df.to_numpy(dtype=np.float64)
+        out[f"{tag}_channels_json"] = json.dumps(st.channels.to_dict("list"))
+        print("resample_quirk", tag, df.shape)
+    np.savez_compressed(HERE / "resample_quirk.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -410,3 +437,4 @@ if __name__ == "__main__":
     case_pipeline()
     case_nan_and_channels()
     case_notch()
+    case_resample_quirk()

@@ -625,15 +625,12 @@ def case_resampler(lib):
                                        float(np.abs(w).max()), 1000, verifier=parity.Verifier(s, ["a", "b"], 1000.0, y, raw=w))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
-    # Stream level: the reference's raw-rate quirk is refused by default, the consistent pipeline is opt-in
-    import pytest
-
+    # Stream level: the consistent pipeline (features designed for the new rate) is opt-in; the default
+    # reproduces the reference's raw-rate design (case_raw_resampling_reference_quirk)
     from py_neuromodulation_amd.stream import Stream
 
     s.preprocessing = ["raw_resampling", "notch_filter", "re_referencing"]
     xs = np.nan_to_num(x)
-    with pytest.raises(NotImplementedError):
-        Stream(sfreq=2000.0, data=xs, settings=s, lib=lib)
     st = Stream(sfreq=2000.0, data=xs, settings=s, lib=lib, resample_features_at_new_rate=True)
     df = st.run(xs, save_csv=False)
     assert len(df) == 6 and st.data_processor.sfreq_raw == 1000.0
@@ -889,3 +886,38 @@ def case_reref_structured_matrices(lib, monkeypatch=None):
         want = R @ np.nan_to_num(x)
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-6 * np.abs(x[~np.isnan(x)]).max(), err_msg=name)
         eng.close()
+
+
+def case_raw_resampling_reference_quirk(lib):
+    """Default settings on recordings that are not sampled at resample_freq_hz: the reference resamples each
+    window but keeps designing notch AND features with the raw rate (stream/data_processor.py:55,68,80;
+    processing/resample.py:36-60).  Stream.run must reproduce that -- golden from the reference's own
+    Stream.run at 2 kHz (down-sampling: FFT / Welch segments longer than the window, clamped band-pass
+    tails, seg_s of the bursts) and 250 Hz (up-sampling: seven Welch segments, FFT of the window's tail)."""
+    import json
+
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("resample_quirk")
+    for tag in ("down_2k", "up_250"):
+        sf = float(g[f"{tag}_sfreq"])
+        data = g[f"{tag}_data"]
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        st = Stream(sfreq=sf, data=data, settings=s, line_noise=50, lib=lib)
+        df = st.run(save_csv=False)
+        assert st.data_processor.sfreq_raw == sf          # like the reference: the raw rate stays
+        cols = [str(c) for c in g[f"{tag}_columns"]]
+        assert list(df.columns) == cols
+        got, want = df.to_numpy(dtype=np.float64), g[f"{tag}_values"]
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got[:, -1], want[:, -1])
+        ch = json.loads(str(g[f"{tag}_channels_json"]))
+        starts, ends, _ = orc.window_schedule(data.shape[1], sf, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        pv = parity.PipelineVerifiers(s, ch, sf, data, starts, int(ends[0] - starts[0]), line_noise=50, ends=ends)
+        W_new = int(round(1000.0 / sf * (ends[0] - starts[0])))
+        for r in range(len(got)):
+            n_bad, rep, _ = parity.compare(cols[:-1], got[r, :-1], want[r, :-1], s, sf, float(np.abs(data).max()), W_new,
+                                           verifier=pv.row(r))
+            assert n_bad == 0, f"{tag} row {r}\n{rep}"

@@ -380,6 +380,10 @@ def test_reref_structured_matrices(gpu_lib):
     pc.case_reref_structured_matrices(gpu_lib)
 
 
+def test_raw_resampling_reference_quirk(gpu_lib):
+    pc.case_raw_resampling_reference_quirk(gpu_lib)
+
+
 def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     """Plan-level knobs select fallback / alternative kernels (list-based sharp-wave code, dense
     re-reference, serial launch order, fused sharp waves, fused Hilbert envelopes, global-memory burst list,

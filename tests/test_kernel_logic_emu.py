@@ -112,3 +112,7 @@ def test_psd_keys_skip_normalisation(emu_lib):
 
 def test_reref_structured_matrices(emu_lib):
     pc.case_reref_structured_matrices(emu_lib)
+
+
+def test_raw_resampling_reference_quirk(emu_lib):
+    pc.case_raw_resampling_reference_quirk(emu_lib)
