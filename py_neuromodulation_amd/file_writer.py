@@ -120,5 +120,8 @@ def save_channels(channels, out_dir="", prefix: str = "") -> Path:
     out_dir = Path.cwd() if not out_dir else Path(out_dir)
     path = out_dir / prefix / ("channels.csv" if not prefix else prefix + "_channels.csv")
     path.parent.mkdir(parents=True, exist_ok=True)
-    channels.to_csv(path, index=False)
+    # utils/io.py:234-253 writes through pyarrow.csv: strings (and the header) quoted, numbers bare
+    import csv
+
+    channels.to_csv(path, index=False, quoting=csv.QUOTE_NONNUMERIC, lineterminator="\n")
     return path

@@ -76,10 +76,21 @@ class Stream:
                              f"Expected (from channels[\"name\"]): : {names_expected}.")
         return data.to_numpy().transpose()
 
-    def run(self, data=None, out_dir="", experiment_name: str = "sub", save_csv: bool = True,
-            return_df: bool = True, save_msgpack: bool = False, save_interval: int = 10,
-            delete_ind_batch_files_after_stream: bool = False, **unused):
-        """Compute every hop of ``data`` and return the feature DataFrame."""
+    def run(self, data=None, out_dir="", experiment_name: str = "sub", is_stream_lsl: bool = False,
+            stream_lsl_name: str | None = None, save_csv: bool = True, save_interval: int = 10,
+            return_df: bool = True, simulate_real_time: bool = False, decoder=None, backend_interface=None,
+            delete_ind_batch_files_after_stream: bool = True, save_msgpack: bool | None = None):
+        """Compute every hop of ``data`` and return the feature DataFrame (signature and defaults of
+        stream/stream.py:198-212).  The reference writes a ``{name}-{i}.msgpack`` file every ``save_interval``
+        hops and deletes them after the run unless ``delete_ind_batch_files_after_stream=False``; the batch
+        driver only writes them when they are to be kept (``save_msgpack`` forces either way)."""
+        if is_stream_lsl or stream_lsl_name is not None:
+            raise NotImplementedError("LSL acquisition is outside the accelerated hot path (SURVEY.md section 2)")
+        if decoder is not None or backend_interface is not None or simulate_real_time:
+            raise NotImplementedError("real-time decoding / GUI back-end / real-time simulation are outside the "
+                                      "accelerated hot path (SURVEY.md section 2)")
+        if save_msgpack is None:
+            save_msgpack = not delete_ind_batch_files_after_stream
         import pandas as pd
 
         if data is not None:
@@ -130,8 +141,7 @@ class Stream:
             out = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
             out.mkdir(parents=True, exist_ok=True)
             df.to_csv(out / f"{experiment_name}_FEATURES.csv", index=False)
-        if save_csv or save_msgpack:
-            self._save_after_stream(out_dir, experiment_name)
+        self._save_after_stream(out_dir, experiment_name)   # always, like the reference (stream/stream.py:338)
         if writer is not None and delete_ind_batch_files_after_stream:
             writer.delete_ind_files()
         return df if return_df else {}
@@ -140,8 +150,9 @@ class Stream:
     def _save_after_stream(self, out_dir="", experiment_name: str = "sub") -> None:
         from . import file_writer as fw
 
+        # stream/data_processor.py:313-337: original_fs = the rate passed in, final_fs = sfreq // 1
         sidecar = {"original_fs": self.sfreq, "final_fs": self.data_processor.sfreq_raw,
-                   "sfreq": self.settings.sampling_rate_features_hz, "sess_right": self.sess_right}
+                   "sfreq": float(self.settings.sampling_rate_features_hz), "sess_right": self.sess_right}
         fw.save_sidecar(sidecar, out_dir, experiment_name)
         self.settings.save(out_dir or Path.cwd(), experiment_name)
         fw.save_channels(self.channels, out_dir, experiment_name)

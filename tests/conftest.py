@@ -36,6 +36,13 @@ def pytest_collection_modifyitems(config, items):
 
 
 @pytest.fixture(autouse=True)
+def _scratch_cwd(tmp_path, monkeypatch):
+    """Stream.run always leaves {name}_SIDECAR.json / _SETTINGS.yaml / _channels.csv under out_dir (default:
+    the working directory), like the reference (stream/stream.py:338): keep them out of the repository."""
+    monkeypatch.chdir(tmp_path)
+
+
+@pytest.fixture(autouse=True)
 def _parity_stats(request):
     from tests import parity
 

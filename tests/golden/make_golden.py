@@ -420,6 +420,55 @@ def case_resample_quirk():
     np.savez_compressed(HERE / "resample_quirk.npz", **out)
 
 
+def case_output_files():
+    """The files the reference's OWN Stream.run leaves behind (stream/stream.py:229,319-343,426-453;
+    utils/file_writer.py:53-118 MsgPackFileWriter unmodified): names, the per-interval msgpack layout, CSV
+    header and values, sidecar, channels table and the top-level keys of the settings YAML.  Stored as data
+    (strings / arrays) -- the GPU box compares what the engine's Stream.run writes with these."""
+    import msgpack
+    import yaml
+
+    s = nm.NMSettings.get_default()
+    s.reset()
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.preprocessing = ["re_referencing"]
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((3, 4300))
+    st = nm.Stream(sfreq=1000.0, data=data, settings=s, sampling_rate_features_hz=10, verbose=False)
+    with tempfile.TemporaryDirectory() as td:
+        df = st.run(data, out_dir=td, experiment_name="sub7", save_csv=True, save_interval=10,
+                    delete_ind_batch_files_after_stream=False)
+        out_dir = Path(td) / "sub7"
+        names = sorted(p.name for p in out_dir.iterdir())
+        packs = sorted(out_dir.glob("sub7-*.msgpack"), key=lambda p: int(p.stem.split("-")[1]))
+        rows_per_file, first = [], None
+        for p in packs:
+            with open(p, "rb") as f:
+                d = msgpack.unpack(f)
+            rows_per_file.append(len(d))
+            if first is None:
+                first = d
+        csv_text = (out_dir / "sub7_FEATURES.csv").read_text()
+        out = {"data": data, "settings_json": dump(st.settings), "file_names": np.array(names),
+               "df_columns": np.array(list(df.columns)), "df_values": df.to_numpy(dtype=np.float64),
+               "df_dtypes": np.array([str(t) for t in df.dtypes]),
+               "msgpack_rows_per_file": np.array(rows_per_file),
+               "msgpack_first_keys": np.array(list(first[0].keys())),
+               "msgpack_first_types": np.array([type(v).__name__ for v in first[0].values()]),
+               "csv_header": csv_text.splitlines()[0], "csv_n_lines": len(csv_text.splitlines()),
+               "sidecar_json": (out_dir / "sub7_SIDECAR.json").read_text(),
+               "channels_csv": (out_dir / "sub7_channels.csv").read_text(),
+               "settings_yaml_keys": np.array(list(yaml.safe_load((out_dir / "sub7_SETTINGS.yaml").read_text()).keys()))}
+    # default call: the per-interval files are deleted after the run (delete_ind_batch_files_after_stream=True)
+    with tempfile.TemporaryDirectory() as td:
+        st2 = nm.Stream(sfreq=1000.0, data=data, settings=s, sampling_rate_features_hz=10, verbose=False)
+        st2.run(data, out_dir=td, experiment_name="sub7")
+        out["file_names_default_call"] = np.array(sorted(p.name for p in (Path(td) / "sub7").iterdir()))
+    np.savez_compressed(HERE / "output_files.npz", **out)
+    print("output_files", names, rows_per_file)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -438,3 +487,4 @@ if __name__ == "__main__":
     case_nan_and_channels()
     case_notch()
     case_resample_quirk()
+    case_output_files()

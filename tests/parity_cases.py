@@ -480,50 +480,66 @@ def case_feature_normalizer_batches(lib):
 
 
 def case_stream_output_files(lib, tmp_path):
-    """Stream.run writes the reference's artefacts (utils/file_writer.py:26-118, stream/stream.py:426-453):
-    {name}-{i}.msgpack per save interval, {name}_FEATURES.csv, _SIDECAR.json, _SETTINGS.yaml, _channels.csv."""
+    """Stream.run leaves the files the REFERENCE's own Stream.run leaves (golden output_files.npz, written by
+    the unmodified MsgPackFileWriter / _save_after_stream: utils/file_writer.py:53-118, stream/stream.py:426-453):
+    same names, the same per-interval msgpack layout (rows per file, key order, float values), the same CSV
+    header / line count / values, identical sidecar JSON and channels table text, the same settings keys;
+    the default call deletes the per-interval files like the reference."""
     import json
 
     import msgpack
     import pandas as pd
+    import yaml
 
-    from py_neuromodulation_amd import NMSettings
     from py_neuromodulation_amd.file_writer import MsgPackFileWriter
     from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
 
-    s = NMSettings.get_default()
-    for f in s.features.get_enabled():
-        setattr(s.features, f, False)
-    s.features.fft = True
-    s.features.raw_hjorth = True
-    s.preprocessing = ["re_referencing"]
-    rng = np.random.default_rng(3)
-    data = rng.standard_normal((3, 4300))
+    g = load_golden("output_files")
+    s = settings_from_json(g["settings_json"])
+    data = g["data"]
     st = Stream(sfreq=1000.0, data=data, settings=s, sampling_rate_features_hz=10, lib=lib)
-    df = st.run(data, out_dir=tmp_path, experiment_name="sub7", save_csv=True, save_msgpack=True, save_interval=10)
-    n = len(df)
-    assert n == 34
+    df = st.run(data, out_dir=tmp_path, experiment_name="sub7", save_csv=True, save_interval=10,
+                delete_ind_batch_files_after_stream=False)
     out = tmp_path / "sub7"
+    assert sorted(p.name for p in out.iterdir()) == [str(n) for n in g["file_names"]]
+    cols = [str(c) for c in g["df_columns"]]
+    assert list(df.columns) == cols and [str(t) for t in df.dtypes] == [str(t) for t in g["df_dtypes"]]
+    want = g["df_values"]
+    got = df.to_numpy(dtype=np.float64)
+    for r in range(len(got)):
+        n_bad, rep, _ = parity.compare(cols[:-1], got[r, :-1], want[r, :-1], s, 1000.0, 4.0, 1000,
+                                       verifier=parity.Verifier(s, [c[:-len("_RawHjorth_Activity")] for c in cols[0:9:3]], 1000.0,
+                                                                lambda r=r: _car3(data[:, r * 100:r * 100 + 1000]), raw=data[:, r * 100:r * 100 + 1000]))
+        assert n_bad == 0, f"row {r}\n{rep}"
+    np.testing.assert_array_equal(got[:, -1], want[:, -1])
     packs = sorted(out.glob("sub7-*.msgpack"), key=lambda p: int(p.stem.split("-")[1]))
-    assert len(packs) == (n + 9) // 10
-    with open(packs[0], "rb") as f:
-        first = msgpack.unpack(f)
-    assert isinstance(first, list) and len(first) == 10 and list(first[0].keys()) == list(df.columns)
-    assert all(isinstance(v, float) for v in first[0].values())
+    rows_per_file = []
+    for i, p in enumerate(packs):
+        with open(p, "rb") as f:
+            d = msgpack.unpack(f)
+        rows_per_file.append(len(d))
+        if i == 0:
+            assert list(d[0].keys()) == [str(k) for k in g["msgpack_first_keys"]]
+            assert [type(v).__name__ for v in d[0].values()] == [str(t) for t in g["msgpack_first_types"]]
+    assert rows_per_file == g["msgpack_rows_per_file"].tolist()
+    csv_text = (out / "sub7_FEATURES.csv").read_text()
+    assert csv_text.splitlines()[0] == str(g["csv_header"]) and len(csv_text.splitlines()) == int(g["csv_n_lines"])
+    np.testing.assert_allclose(pd.read_csv(out / "sub7_FEATURES.csv").to_numpy(), got, rtol=1e-12, equal_nan=True)
+    assert json.loads((out / "sub7_SIDECAR.json").read_text()) == json.loads(str(g["sidecar_json"]))
+    assert (out / "sub7_SIDECAR.json").read_text() == str(g["sidecar_json"])
+    assert (out / "sub7_channels.csv").read_text() == str(g["channels_csv"])
+    assert list(yaml.safe_load((out / "sub7_SETTINGS.yaml").read_text()).keys()) == [str(k) for k in g["settings_yaml_keys"]]
+    # the reference's default call: per-interval files are removed after the run
+    st2 = Stream(sfreq=1000.0, data=data, settings=s, sampling_rate_features_hz=10, lib=lib)
+    st2.run(data, out_dir=tmp_path / "d", experiment_name="sub7")
+    assert sorted(p.name for p in (tmp_path / "d" / "sub7").iterdir()) == [str(n) for n in g["file_names_default_call"]]
+    # reading the files back / the hop-by-hop interface of the writer (the reference's call shape)
     w = MsgPackFileWriter(name="sub7", out_dir=tmp_path)
     w.idx = len(packs)
     back = w.load_all()
-    assert list(back.columns) == list(df.columns)
-    np.testing.assert_array_equal(back.to_numpy(), df.to_numpy(dtype=np.float64))
-    csv = pd.read_csv(out / "sub7_FEATURES.csv")
-    assert list(csv.columns) == list(df.columns)
-    np.testing.assert_allclose(csv.to_numpy(), df.to_numpy(dtype=np.float64), rtol=1e-12, equal_nan=True)
-    side = json.loads((out / "sub7_SIDECAR.json").read_text())
-    assert side == {"original_fs": 1000.0, "final_fs": 1000.0, "sfreq": 10, "sess_right": None}
-    assert (out / "sub7_SETTINGS.yaml").exists()
-    ch = pd.read_csv(out / "sub7_channels.csv")
-    assert list(ch["name"]) == list(st.channels["name"])
-    # hop-by-hop interface of the writer (the reference's call shape)
+    assert list(back.columns) == cols
+    np.testing.assert_array_equal(back.to_numpy(), got)
     w2 = MsgPackFileWriter(name="live", out_dir=tmp_path)
     for i in range(3):
         w2.insert_data({"a": i, "b": None})
@@ -532,6 +548,13 @@ def case_stream_output_files(lib, tmp_path):
     assert pd.read_csv(tmp_path / "live" / "live_FEATURES.csv")["b"].tolist() == [0, 0, 0]
     w2.delete_ind_files()
     assert not list((tmp_path / "live").glob("*.msgpack"))
+
+
+def _car3(w):
+    """common average of three channels (the default channel table of a 3-row array)"""
+    R = np.full((3, 3), -0.5)
+    np.fill_diagonal(R, 1.0)
+    return R @ np.asarray(w, np.float64)
 
 
 def case_bandpower_kalman_sequence(lib):
