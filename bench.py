@@ -131,8 +131,129 @@ def bank_flops_per_item(M: int, n_filters: int, seglens) -> float:
     return float(rfft + n_filters * (6 * (M / 2 + 1) + rfft) + 3 * sum(seglens))
 
 
+def config_settings(name: str):
+    """BASELINE.json configs[3] / configs[4]."""
+    from py_neuromodulation_amd import NMSettings
+
+    if name == "c4":   # 1024 ch @ 1 kHz, full oscillatory + sharp waves + notch, common average over ALL 1024 rows
+        s = NMSettings.get_default()
+        s.features.disable_all()
+        for f in ("fft", "welch", "stft", "bandpass_filter", "sharpwave_analysis"):
+            setattr(s.features, f, True)
+        s.preprocessing = ["notch_filter", "re_referencing"]
+        s.postprocessing.feature_normalization = False
+        return s, dict(C_all=1024, sfreq=1000.0, W=1000, hop=100, window=None)
+    base = NMSettings.get_default().to_dict()   # c5: 4096 ch @ 30 kHz, 512-sample windows at a 1 kHz feature rate
+    base["frequency_ranges_hz"] = {"gamma": [60, 200], "HFA": [200, 500], "MUA": [500, 3000], "spike": [3000, 7000]}
+    s = NMSettings(**base)
+    s.features.disable_all()
+    for f in ("fft", "stft", "raw_hjorth", "linelength", "return_raw", "bandpass_filter", "sharpwave_analysis"):
+        setattr(s.features, f, True)
+    s.sampling_rate_features_hz = 1000
+    s.segment_length_features_ms = 17
+    s.fft_settings.windowlength_ms = 17
+    s.stft_settings.windowlength_ms = 17
+    s.bandpass_filter_settings.segment_lengths_ms = {"gamma": 17, "HFA": 10, "MUA": 5, "spike": 3}
+    s.sharpwave_analysis_settings.filter_ranges_hz = [[500, 3000], [1000, 7000]]
+    s.preprocessing = []
+    s.postprocessing.feature_normalization = False
+    return NMSettings(**s.to_dict()), dict(C_all=4096, sfreq=30000.0, W=512, hop=30, window=512)
+
+
+def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
+    """--config c4 | c5: ONE array of C_all channels sharded over the N ranks (strong scaling): each rank holds
+    only its own channel block in HBM.  c4 is re-referenced JOINTLY: every step each rank sums its rows per
+    sample, ONE all-reduce (RCCL) of that [T] float64 row, then its structured re-reference (own row tap +
+    coefficient x the sum row) -- the only exchange step of the path.  c5 has no exchange."""
+    from py_neuromodulation_amd.data_processor import DataProcessor
+    from py_neuromodulation_amd.sharding import channel_shard
+
+    s, cfg = config_settings(args.config)
+    C_all, sfreq, W, hop = cfg["C_all"], cfg["sfreq"], cfg["W"], cfg["hop"]
+    n_win = args.windows
+    T = W + (n_win - 1) * hop
+    names = [f"ch{i}" for i in range(C_all)]
+    car = args.config == "c4"
+    channels = {"name": names, "rereference": ["average" if car else "None"] * C_all, "used": [1] * C_all,
+                "target": [0] * C_all, "type": ["ecog"] * C_all, "status": ["good"] * C_all,
+                "new_name": [f"{n}_avgref" if car else n for n in names]}
+    shard = channel_shard(C_all, world, rank)
+    dp = DataProcessor(sfreq, s, channels, line_noise=50, verbose=False, device=dev_index, window=W,
+                       channel_subset=shard, local_inputs=True)
+    eng = dp.engine
+    C = len(shard)
+    F = eng.n_outputs
+    n_rows = eng.C_in   # own rows (+ the sum row for c4)
+    x = torch.empty((n_rows, T), dtype=torch.float32, device=dev)
+    x[:C] = torch.from_numpy(synth(C, T, sfreq, 1234 + rank)).to(dev)
+    out = torch.empty((n_win, F), dtype=torch.float32, device=dev)
+    starts = np.arange(n_win, dtype=np.int64) * hop
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sum_dev = torch.device("cpu") if args.backend == "gloo" else dev
+
+    def step():
+        if car:   # the exchange step: partial column sums -> all-reduce -> sum row of this rank's input
+            part = x[:C].sum(dim=0, dtype=torch.float64)
+            if world > 1:
+                part = part.to(sum_dev)
+                dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            x[C] = part.to(device=dev, dtype=torch.float32)
+        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    names_t = ("prep", "timeosc", "bank", "bursts", "sharp", "batch")
+    kt = {k: 0.0 for k in names_t}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5)):
+            kt[name] += eng.timing_ms(idx)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    bad = int(torch.isnan(out).sum().item())
+    if rank == 0:
+        value = args.steps * n_win / dt               # windows of the WHOLE array (all ranks work on the same windows)
+        stage = max(("timeosc", "bank", "sharp", "prep"), key=lambda k: kt[k])
+        idx = {"prep": 1, "timeosc": 2, "bank": 3, "sharp": 5}[stage]
+        ms = kt[stage] / args.steps
+        algo = n_win * C * (4 * W + 4 * F / C)        # SURVEY 8(d): window in + features out, this rank's channels
+        res = {
+            "metric": f"windows/sec, BASELINE config {args.config}", "value": value, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {C_all} ch @ {sfreq:g} Hz as ONE array, W={W}, hop={hop}, {n_win} hops/step, "
+                                   f"features {list(eng.enabled)}, preprocessing {list(s.preprocessing)}",
+                       "channels_total": C_all, "channels_per_gpu": C, "windows_per_step": n_win,
+                       "features_per_window_per_gpu": F,
+                       "parallelism": f"channel-shard x{world}" + (", group sum all-reduced per step" if car else ", no collective")},
+            "features_per_sec": value * F * world,
+            "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
+            "kernels": {name: eng.kernels(i) for name, i in (("prep", 1), ("timeosc", 2), ("bank", 3), ("sharp", 5))},
+            "nan_outputs": bad,
+            "roofline": {"bound": "hbm", "kernel": eng.kernels(idx), "stage": stage,
+                         "achieved": algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0, "traffic": None,
+                         "note": "stage with the largest HIP-event time on rank 0; algorithmic bytes = the step's "
+                                 "window-in + features-out bytes of this rank's channels"},
+        }
+        print(json.dumps(res))
+    dp.engine.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="headline", choices=("headline", "c4", "c5"),
+                    help="headline = BASELINE metric (default); c4 / c5 = the multi-GPU configs as ONE sharded array")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -160,6 +281,11 @@ def main() -> None:
         dist.init_process_group(args.backend)
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.config != "headline":
+        run_config(args, torch, dist if world > 1 else None, world, rank, dev, dev_index)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from py_neuromodulation_amd import fir_design
     from py_neuromodulation_amd.engine import HotPathEngine

@@ -87,3 +87,38 @@ def reref_matrix(df) -> np.ndarray | None:
         R[i, idx] = -1.0 / len(idx)
     good = [i for i in range(n) if status[i] == "good"]
     return R[np.ix_(good, good)]
+
+
+def reref_structure(full: np.ndarray, max_taps: int = 4):
+    """Decompose the rows of a (folded) re-reference matrix into explicit taps plus a multiple of ONE group sum:
+
+        y_r = sum_k coef[r][k] * x[idx[r][k]]  +  b[r] * sum_{j in groups[g[r]]} x_j
+
+    (the host-side twin of find_reref_structure in csrc/nmx_engine.inc).  "average" rows of
+    processing/rereference.py:61-63 -- 1 on the channel itself, -1/(n-1) on every other good channel of its
+    type -- become one tap (1 + 1/(n-1)) plus b = -1/(n-1) times the sum over the WHOLE type group, shared by
+    all rows of the group; bipolar rows (:65-79) are taps only.
+    Returns (taps: list of [(col, coef), ...], g: int array (-1 = none), b: float array, groups: list of
+    sorted column arrays), or None when some row has no such structure."""
+    full = np.asarray(full, np.float64)
+    taps, g, b, groups, index = [], [], [], [], {}
+    for row in full:
+        nz = np.flatnonzero(row)
+        if len(nz) <= max_taps:
+            taps.append([(int(j), float(row[j])) for j in nz])
+            g.append(-1)
+            b.append(0.0)
+            continue
+        vals, counts = np.unique(row[nz], return_counts=True)
+        o = float(vals[np.argmax(counts)])
+        rest = [int(j) for j in nz if row[j] != o]
+        if len(rest) > max_taps:
+            return None
+        key = tuple(int(j) for j in nz)
+        if key not in index:
+            index[key] = len(groups)
+            groups.append(np.asarray(nz, dtype=np.int64))
+        taps.append([(j, float(row[j]) - o) for j in rest])
+        g.append(index[key])
+        b.append(o)
+    return taps, np.asarray(g, dtype=np.int64), np.asarray(b, dtype=np.float64), groups

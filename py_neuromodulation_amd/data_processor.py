@@ -46,7 +46,7 @@ class DataProcessor:
                  line_noise: float | None = None, path_grids=None, verbose: bool = True,
                  device: int = 0, window: int | None = None, lib=None,
                  channel_subset=None, dry_run: bool = False,
-                 resample_features_at_new_rate: bool = False) -> None:
+                 resample_features_at_new_rate: bool = False, local_inputs: bool = False) -> None:
         self.settings = NMSettings.load(settings)
         self.channels = chmod.load_channels(channels)
         self.sfreq_features = self.settings.sampling_rate_features_hz
@@ -116,12 +116,37 @@ class DataProcessor:
         # picked channels but its re-reference rows still read ALL input rows
         self.all_ch_names_used = list(self.ch_names_used)
         names = self.ch_names_used
+        self.local_rows = None      # local_inputs: the input rows this processor expects, then the group sums
+        self.local_groups = []      # local_inputs: member rows (global) of every group sum it expects
         if channel_subset is not None:
             subset = list(channel_subset)
             if full is None:
                 full = np.eye(n_all)
             full = full[subset]
             names = [self.ch_names_used[i] for i in subset]
+            if local_inputs:
+                # Channel shard WITHOUT replicating the recording: this rank is handed only the input rows its
+                # own output rows tap, plus one row per type group holding sum_{j in group} x_j (partial sums
+                # of the owners, all-reduced by the caller -- sharding.ShardedStream).  Its matrix then has a
+                # handful of non-zeros per row: taps on local rows + the coefficient of the group-sum row.
+                st_ = chmod.reref_structure(full)
+                if st_ is None:
+                    raise NotImplementedError("local_inputs needs re-reference rows made of a few named channels "
+                                              "and / or one group average (processing/rereference.py:52-86)")
+                taps, gi, gb, groups = st_
+                rows = sorted({j for t in taps for j, _ in t})
+                pos = {j: i for i, j in enumerate(rows)}
+                used_groups = sorted({int(k) for k in gi if k >= 0})
+                gpos = {k: len(rows) + i for i, k in enumerate(used_groups)}
+                loc = np.zeros((len(subset), len(rows) + len(used_groups)))
+                for r, t in enumerate(taps):
+                    for j, c in t:
+                        loc[r, pos[j]] += c
+                    if gi[r] >= 0:
+                        loc[r, gpos[int(gi[r])]] = gb[r]
+                full = loc if not (loc.shape[0] == loc.shape[1] and np.array_equal(loc, np.eye(len(loc)))) else None
+                self.local_rows = rows
+                self.local_groups = [groups[k] for k in used_groups]
         if resample_to is None:
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, window=window, lib=lib, dry_run=dry_run,

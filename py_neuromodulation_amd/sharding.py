@@ -1,11 +1,20 @@
 """Channel sharding of the hot path over the GPUs of one node.
 
-Every feature on the path is per channel and the only cross-channel operator (re-referencing)
-is a fixed linear map of the INPUT rows, so each rank computes the features of a contiguous
-block of channels from the full input: rank r applies rows [lo_r, hi_r) of the folded
-(re-reference x channel-pick) matrix on its GPU.  There is NO collective on the data path; the
-only communication is the final gather of the small feature table to rank 0 (control plane,
-``torch.distributed.gather_object``; gloo on CPU in the tests, RCCL via "nccl" on the node).
+Every feature on the path is per channel; the only cross-channel operator, re-referencing, is a fixed
+linear map of the INPUT rows.  Two ways to feed a rank:
+
+* ``local_input=False`` (replicated input): every rank is handed the whole recording and applies rows
+  [lo_r, hi_r) of the folded (re-reference x channel-pick) matrix on its GPU (structured kernel: one group
+  sum per sample).  No collective on the data path, but N x the host-to-device volume.
+* ``local_input=True``: a rank is handed ONLY the input rows of its own channel block (plus the few rows its
+  bipolar references name).  The group averages of "average" references (processing/rereference.py:61-63) need
+  one number per sample and type group from everybody: each rank sums the members it owns, ONE all-reduce
+  (RCCL over xGMI with the "nccl" backend; gloo in the CPU tests) of [n_groups, T] float64 -- 8 bytes per
+  sample and group, latency bound -- and every rank continues with its own rows + the sum rows.  This is the
+  only exchange step of the path; the NaN mask (one byte per window and channel) is all-gathered so that the
+  reference's substring NaN policy sees every channel.
+
+The final gather of the small feature table to rank 0 is control plane (``gather_object``).
 """
 
 from __future__ import annotations
@@ -35,7 +44,7 @@ class ShardedStream:
     """One rank of a channel-sharded offline stream."""
 
     def __init__(self, sfreq, channels, settings=None, line_noise=50, rank: int = 0,
-                 world_size: int = 1, device: int | None = None, lib=None) -> None:
+                 world_size: int = 1, device: int | None = None, lib=None, local_input: bool = False) -> None:
         self.sfreq = sfreq
         self.settings = NMSettings.load(settings)
         self.channels = chmod.load_channels(channels)
@@ -43,20 +52,83 @@ class ShardedStream:
         self.rank, self.world_size = rank, world_size
         self.device = rank if device is None else device
         self._lib = lib
-        names, _, _ = chmod.channel_info(self.channels)
+        names, self.feature_idx, _ = chmod.channel_info(self.channels)
         self.shard = channel_shard(len(names), world_size, rank)
+        self.local_input = local_input
+        self._dp = None
+        if local_input:   # plan the local rows up front (no GPU needed): callers slice the recording with them
+            self._dp = self._processor(None, dry_run=True)
+            self.local_rows = list(self._dp.local_rows)
+            # an input row is OWNED by the rank whose channel block holds its channel
+            self.owned_rows = [self.feature_idx[i] for i in self.shard]
 
-    def run(self, data: np.ndarray):
-        """-> (local_keys, float64[n_windows, n_local], time_ms) for this rank's channels."""
+    def _processor(self, window, dry_run=False):
+        return DataProcessor(self.sfreq, self.settings, self.channels, line_noise=self.line_noise, verbose=False,
+                             device=self.device, window=window, lib=self._lib, channel_subset=self.shard,
+                             local_inputs=self.local_input, dry_run=dry_run)
+
+    def group_sums(self, local_data: np.ndarray, group=None) -> np.ndarray:
+        """[n_groups, T] float64: sum over each group's member rows of nan_to_num(x), partial sums of the rows
+        this rank OWNS all-reduced over the ranks (the one exchange step of the sharded path)."""
+        import torch
+        import torch.distributed as dist
+
+        dp = self._dp
+        pos = {j: i for i, j in enumerate(self.local_rows)}
+        own = set(self.owned_rows)
+        part = np.zeros((len(dp.local_groups), local_data.shape[1]))
+        for g, members in enumerate(dp.local_groups):
+            idx = [pos[int(j)] for j in members if int(j) in own]
+            if idx:
+                part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float64)).sum(axis=0)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and part.size:
+            t = torch.from_numpy(part)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            part = t.numpy()
+        return part
+
+    def _gather_mask(self, mask_local: np.ndarray, n_all: int, group=None) -> np.ndarray:
+        """NaN mask over ALL input rows [n_windows, n_all] from every rank's owned rows."""
+        import torch
+        import torch.distributed as dist
+
+        pos = {j: i for i, j in enumerate(self.local_rows)}
+        mine = (np.asarray(self.owned_rows, np.int64), mask_local[:, [pos[j] for j in self.owned_rows]].astype(np.uint8))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            parts = [None] * dist.get_world_size(group)
+            dist.all_gather_object(parts, mine, group=group)
+        else:
+            parts = [mine]
+        full = np.zeros((mask_local.shape[0], n_all), dtype=bool)
+        for rows, m in parts:
+            full[:, rows] = m.astype(bool)
+        return full
+
+    def run(self, data: np.ndarray, group=None):
+        """-> (local_keys, float64[n_windows, n_local], time_ms) for this rank's channels.
+        ``data``: the whole recording [C_all, T], or -- with ``local_input`` -- only its rows
+        ``self.local_rows`` (in that order)."""
         st = self.settings
         starts, lens, times = window_schedule(data.shape[1], self.sfreq, st.sampling_rate_features_hz,
                                               st.segment_length_features_ms)
         if len(set(lens.tolist())) > 1:
             raise NotImplementedError("ragged windows are not supported in sharded mode")
-        dp = DataProcessor(self.sfreq, st, self.channels, line_noise=self.line_noise, verbose=False,
-                           device=self.device, window=int(lens[0]) if len(lens) else None,
-                           lib=self._lib, channel_subset=self.shard)
-        rows = dp.process_batch(data, starts) if len(starts) else np.empty((0, len(dp.keys)))
+        dp = self._processor(int(lens[0]) if len(lens) else None)
+        if not self.local_input:
+            rows = dp.process_batch(data, starts) if len(starts) else np.empty((0, len(dp.keys)))
+            return list(dp.keys), rows, times
+        if data.shape[0] != len(self.local_rows):
+            raise ValueError(f"local_input: expected the {len(self.local_rows)} rows ShardedStream.local_rows, "
+                             f"got {data.shape[0]}")
+        sums = self.group_sums(data, group)
+        x = np.concatenate([np.asarray(data, np.float32), sums.astype(np.float32)], axis=0)
+        if not len(starts):
+            return list(dp.keys), np.empty((0, len(dp.keys))), times
+        out, mask = dp.engine.process_batch(x, starts, want_nan_mask=True)
+        mask_all = self._gather_mask(mask, len(self.channels), group)
+        if mask_all.any() and mask_all.shape[1] != len(dp.ch_names_used):
+            raise IndexError("boolean index did not match: NaN handling needs every channel used")
+        rows = dp.postprocess_batch(out, mask_all if mask_all.any() else np.zeros((len(out), len(dp.ch_names_used)), bool))
         return list(dp.keys), rows, times
 
 

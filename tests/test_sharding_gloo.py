@@ -40,6 +40,21 @@ df = gather_dataframe(keys, rows, times, allk)
 if rank == 0:
     df.to_pickle(sys.argv[2])
 dist.barrier()
+# local input: each rank is handed ONLY the rows of its own channels (+ the rows its bipolar references
+# name); the type-group sums of the "average" references travel through ONE all-reduce, the NaN mask
+# through an all-gather.  Mixed table: ecog average group, an lfp pair referenced to named channels.
+ch2 = ch.copy()
+ch2.loc[3, "type"] = "lfp"; ch2.loc[3, "rereference"] = "ch0"; ch2.loc[3, "new_name"] = "ch3_ch0"
+ch2.loc[4, "type"] = "lfp"; ch2.loc[4, "rereference"] = "ch3&ch1"; ch2.loc[4, "new_name"] = "ch4_ch3ch1"
+data2 = data.copy()
+data2[1, 1200:1210] = np.nan
+st2 = ShardedStream(1000.0, ch2, s, line_noise=50, rank=rank, world_size=world, device=0, lib=lib, local_input=True)
+assert set(st2.owned_rows) <= set(st2.local_rows) and len(st2.local_rows) < 5
+keys2, rows2, times2 = st2.run(data2[st2.local_rows])
+df2 = gather_dataframe(keys2, rows2, times2, global_keys(1000.0, s, ch2))
+if rank == 0:
+    df2.to_pickle(sys.argv[2] + ".local")
+dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -86,3 +101,24 @@ def test_two_rank_channel_shards_equal_single_process(tmp_path):
     # same kernels, same inputs per channel -> identical up to fp32 summation order in the
     # re-reference rows (identical here: each row is computed by the same code path)
     np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+
+    # local-input mode (group sums all-reduced, masks all-gathered) == the single-process stream on the same
+    # table, incl. the NaN policy (every key containing the NaN channel's name is NaN in those windows)
+    local = pd.read_pickle(str(out) + ".local")
+    ch2 = chmod.get_default_channels_from_data(data)
+    ch2.loc[3, "type"] = "lfp"; ch2.loc[3, "rereference"] = "ch0"; ch2.loc[3, "new_name"] = "ch3_ch0"
+    ch2.loc[4, "type"] = "lfp"; ch2.loc[4, "rereference"] = "ch3&ch1"; ch2.loc[4, "new_name"] = "ch4_ch3ch1"
+    data2 = data.copy()
+    data2[1, 1200:1210] = np.nan
+    single2 = Stream(1000.0, channels=ch2, settings=s, line_noise=50, lib=lib).run(data2, save_csv=False)
+    assert list(local.columns) == list(single2.columns)
+    a2, b2 = local.to_numpy(float), single2.to_numpy(float)
+    assert np.array_equal(np.isnan(a2), np.isnan(b2)) and np.isnan(a2).any()
+    # the group sum reaches the kernel as ONE fp32 number per sample here and as a float64 partial sum in the
+    # single-process kernel: agreement to fp32 rounding of the re-referenced samples, not bit equality
+    from tests import parity
+    keys = list(single2.columns)[:-1]
+    for r in range(len(a2)):
+        ok = ~np.isnan(b2[r, :-1])
+        n_bad, rep, _ = parity.compare([k for k, o in zip(keys, ok) if o], a2[r, :-1][ok], b2[r, :-1][ok], s, 1000.0, 200.0, 1000)
+        assert n_bad == 0, f"row {r}\n{rep}"
