@@ -226,6 +226,9 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds
 }
 extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
+extern "C" void nmx_w64_launch_rd64(const NmxBankW64Args*, int, size_t, hipStream_t);
+extern "C" int nmx_w64p_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
+extern "C" int nmx_w64q_launch_notch_rd64(const NmxBankW64Args*, int, hipStream_t);
 extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64q_launch_notch_slp(const NmxBankW64Args*, int, hipStream_t);
@@ -240,7 +243,7 @@ static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, 
   static int variant = -1;
   if (variant < 0) {
     const char* v = getenv("NMX_W64_VARIANT");
-    variant = (v && v[0] == 's' && v[1] == 'l') ? 1 : 0;  // "slp" | "scalar" (default)
+    variant = (v && v[0] == 's' && v[1] == 'l') ? 1 : (v && v[0] == 's' && v[1] == 'c') ? 0 : 2;  // "slp" | "scalar" | "rd64" (default)
   }
   static int persistent = -1, n_cu = 0;
   if (persistent < 0) {
@@ -253,15 +256,18 @@ static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, 
   }
   if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
     const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)
+                 : variant == 2 ? nmx_w64p_launch_rd64(&A, n_items, n_cu, s, sharp)
                                 : nmx_w64p_launch_scalar(&A, n_items, n_cu, s, sharp);
     if (rc) return rc;
   }
   static int notch_q = -1;
   if (notch_q < 0) { const char* v = getenv("NMX_NOTCH_QUAD"); notch_q = !(v && v[0] == '0'); }
   if (notch_q && A.b.pad_mode != 0 && n_items >= 1024 &&
-      (variant == 1 ? nmx_w64q_launch_notch_slp(&A, n_items, s) : nmx_w64q_launch_notch_scalar(&A, n_items, s)))
+      (variant == 1 ? nmx_w64q_launch_notch_slp(&A, n_items, s)
+       : variant == 2 ? nmx_w64q_launch_notch_rd64(&A, n_items, s) : nmx_w64q_launch_notch_scalar(&A, n_items, s)))
     return 0;
   if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
+  else if (variant == 2) nmx_w64_launch_rd64(&A, n_items, lds, s);
   else nmx_w64_launch_scalar(&A, n_items, lds, s);
   return 0;
 }

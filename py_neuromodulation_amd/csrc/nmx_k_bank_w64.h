@@ -41,6 +41,22 @@
 #define NMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// -DNMX_BANK_PROFILE: per-phase cycle counters (s_memtime) of one wave, printed for two items -- where a wave's
+// time goes inside the filter loop (tools/exp_variants.sh with NMX_EXTRA_CXXFLAGS; never in the product build)
+#if defined(NMX_BANK_PROFILE) && !defined(NMX_HOST_EMU)
+#define NMX_PROF_DECL long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NMX_PROF(i) { const long long t_ = clock64(); pf_acc[i] += t_ - pf_t; pf_t = t_; }
+#define NMX_PROF_PRINT(w, c)                                                                                          \
+  if ((w) == 5 && ((c) == 3 || (c) == 40) && (threadIdx.x & 63) == 0)                                                  \
+    printf("bank profile w=%d c=%d: load+fwd %lld | spectral+passA %lld | passB load+dft %lld | passB store %lld | "  \
+           "passC %lld | variance %lld | series stores %lld | partners %lld (cycles, whole item, %d filters)\n", (w), (c), pf_acc[0],   \
+           pf_acc[1], pf_acc[2], pf_acc[3], pf_acc[4], pf_acc[5], pf_acc[7], pf_acc[6], A.n_filters);
+#else
+#define NMX_PROF_DECL
+#define NMX_PROF(i)
+#define NMX_PROF_PRINT(w, c)
+#endif
+
 #define NMX_W64_N 1024
 #define NMX_W64_E 16
 // register index of point l + 64 j after pass C (v[4 t + r] = y[l + 64 t + 256 r], j = t + 4 r)
@@ -91,11 +107,19 @@ NMX_DEV nmx_rsrc nmx_make_rsrc(const void* p, int bytes) {
 template <int DIR>
 NMX_DEV void nmx_dft4(nmx_c2& a0, nmx_c2& a1, nmx_c2& a2, nmx_c2& a3) {
   const nmx_c2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+#if defined(NMX_LDS_ASM) && !defined(NMX_HOST_EMU)
+  const nmx_c2 d = nmx_csub(a1, a3);   // the +-i of the odd outputs rides on the adds (nmx_device.h)
+  a0 = nmx_cadd(t0, t2);
+  a1 = nmx_add_ib<DIR>(t1, d);
+  a2 = nmx_csub(t0, t2);
+  a3 = nmx_add_ib<-DIR>(t1, d);
+#else
   const nmx_c2 t3 = nmx_mul_i<DIR>(nmx_csub(a1, a3));
   a0 = nmx_cadd(t0, t2);
   a1 = nmx_cadd(t1, t3);
   a2 = nmx_csub(t0, t2);
   a3 = nmx_csub(t1, t3);
+#endif
 }
 
 // in-register 16-point DFT: y_q = sum_r a_r w^(q r), w = exp(DIR 2 pi i / 16); in/out v[0..15]
@@ -153,6 +177,35 @@ NMX_UNROLL
 #define NMX_W64_TWB_N (15 * 16)
 #define NMX_W64_TWC_N (12 * 64)
 #define NMX_W64_TWL_FLOATS (2 * (NMX_W64_TWB_N + NMX_W64_TWC_N))
+#if defined(NMX_LDS_ASM) && !defined(NMX_HOST_EMU)
+#include <utility>
+// a whole read phase as unpaired ds_read_b64 (see nmx_device.h): v[I] = *(base + STRIDE_BYTES * I)
+template <int STRIDE, int BASE, int... I>
+NMX_DEV void nmx_ds_read_seq(nmx_c2* v, unsigned addr, std::integer_sequence<int, I...>) {
+  ((v[I] = nmx_ds_read_b64<BASE + STRIDE * I>(addr)), ...);
+}
+// pass C order: v[4 t + q] = X[lane + 64 t + 256 q]
+template <int... I>
+NMX_DEV void nmx_ds_read_passC(nmx_c2* v, unsigned addr, std::integer_sequence<int, I...>) {
+  ((v[I] = nmx_ds_read_b64<512 * (I / 4) + 2048 * (I % 4)>(addr)), ...);
+}
+// twC order: w[4 t + q] = twC[lane + 64 (4 (q - 1) + t)], q = 1..3 (slot 4 t unused)
+template <int... I>
+NMX_DEV void nmx_ds_read_twC(nmx_c2* w, unsigned addr, std::integer_sequence<int, I...>) {
+  ((w[4 * (I / 3) + 1 + (I % 3)] = nmx_ds_read_b64<512 * (4 * (I % 3) + (I / 3))>(addr)), ...);
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twB, int lane) {
+  nmx_c2 w[16];
+  nmx_ds_read_seq<544, 0>(v, nmx_lds_addr(X + lane + (lane >> 4)), std::make_integer_sequence<int, 16>{});
+  nmx_ds_read_seq<128, 0>(w + 1, nmx_lds_addr(twB + (lane & 15)), std::make_integer_sequence<int, 15>{});
+  w[0] = w[1];
+  nmx_lds_wait8(v); nmx_lds_tie8(v + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+  NMX_UNROLL
+  for (int r = 1; r < 16; ++r) v[r] = nmx_cmul_tw<(DIR > 0)>(v[r], w[r]);
+  nmx_dft16<DIR>(v);
+}
+#else
 template <int DIR>
 NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twB, int lane) {
   const nmx_c2* Xi = X + lane + (lane >> 4);
@@ -163,6 +216,42 @@ NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* tw
   for (int r = 1; r < 16; ++r) v[r] = nmx_cmul(v[r], nmx_twd<DIR>(tw[16 * (r - 1)]));
   nmx_dft16<DIR>(v);
 }
+#endif
+#if defined(NMX_LDS_ASM) && !defined(NMX_HOST_EMU)
+template <int DIR, int HALF>
+NMX_DEV void nmx_w64_passC_asm(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
+  nmx_c2 a[16], w[16];
+  nmx_ds_read_passC(a, nmx_lds_addr(X + lane), std::make_integer_sequence<int, 16>{});
+  nmx_ds_read_twC(w, nmx_lds_addr(twC + lane), std::make_integer_sequence<int, 12>{});
+  w[0] = w[4] = w[8] = w[12] = w[1];
+  nmx_lds_wait8(a); nmx_lds_tie8(a + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+NMX_UNROLL
+  for (int t = 0; t < 4; ++t) {
+    nmx_c2 a0 = a[4 * t], a1 = a[4 * t + 1], a2 = a[4 * t + 2], a3 = a[4 * t + 3];
+    a1 = nmx_cmul_tw<(DIR > 0)>(a1, w[4 * t + 1]);
+    a2 = nmx_cmul_tw<(DIR > 0)>(a2, w[4 * t + 2]);
+    a3 = nmx_cmul_tw<(DIR > 0)>(a3, w[4 * t + 3]);
+    if (HALF) {
+      const nmx_c2 t0 = nmx_cadd(a0, a2), t1 = nmx_csub(a0, a2), t2 = nmx_cadd(a1, a3);
+      v[4 * t] = nmx_cadd(t0, t2);
+      v[4 * t + 1] = nmx_add_ib<DIR>(t1, nmx_csub(a1, a3));
+    } else {
+      nmx_dft4<DIR>(a0, a1, a2, a3);
+      v[4 * t] = a0; v[4 * t + 1] = a1; v[4 * t + 2] = a2; v[4 * t + 3] = a3;
+    }
+  }
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passC_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
+  nmx_w64_passC_asm<DIR, 0>(v, X, twC, lane);
+}
+template <int DIR>
+NMX_DEV void nmx_w64_passC_lds_half(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
+  nmx_w64_passC_asm<DIR, 1>(v, X, twC, lane);
+}
+#define NMX_W64_PASSC_DEFINED 1
+#endif
+#ifndef NMX_W64_PASSC_DEFINED
 template <int DIR>
 NMX_DEV void nmx_w64_passC_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
   const nmx_c2* tw = twC + lane;
@@ -196,6 +285,7 @@ NMX_UNROLL
     v[4 * t + 1] = nmx_cadd(t1, t3);
   }
 }
+#endif
 
 // tail-range mask of a register that straddles the band-pass segment boundary: kept out of line so
 // that the compiler does not if-convert it into 16 x 2 lane predicates (64-bit masks that were
@@ -243,6 +333,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   // otherwise -- every variant computes bit-identical results
   const nmx_c2* twB = TAB ? (const nmx_c2*)(tab + (size_t)A.n_filters * 2 * NMX_W64_N) : (const nmx_c2*)AA.twl;
   const nmx_c2* twC = twB + NMX_W64_TWB_N;
+  NMX_PROF_DECL
 
   // ---- forward: window -> registers (packed complex, lane-consecutive) -> pass A ------------
   if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
@@ -332,6 +423,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     for (int i = 0; i < 16; ++i) zr[NMX_LI][i] = vv[i];
   }
   NMX_WSYNC();
+  NMX_PROF(0)
 
 #ifndef NMX_HOST_EMU
   // conjugate partners Z[n - k] of this lane's points: one cross-lane read per point, ONCE per item (they
@@ -348,6 +440,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     }
   }
 #endif
+  NMX_PROF(6)
   const int yoff = (PAD == 1) ? A.pad_half : 0;
   for (int fi = 0; fi < A.n_filters; ++fi) {
     const NmxFilterDev& F = A.f[fi];
@@ -382,14 +475,18 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       nmx_w64_passA<+1>(vv, X, l);
     }
     NMX_WSYNC();
+    NMX_PROF(1)
     NMX_LANE_LOOP { nmx_w64_passB_load_lds<+1>(v[NMX_LI], X, twB, l); }
     NMX_WSYNC();
+    NMX_PROF(2)
     NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
     NMX_WSYNC();
+    NMX_PROF(3)
     NMX_LANE_LOOP {
       if (HALF) nmx_w64_passC_lds_half<+1>(v[NMX_LI], X, twC, l);
       else nmx_w64_passC_lds<+1>(v[NMX_LI], X, twC, l);
     }
+    NMX_PROF(4)
     // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
 
     if (F.bp_seglen > 0) {
@@ -405,6 +502,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         float part[NMX_LANES], part2[NMX_LANES];
         NMX_LANE_LOOP {
           nmx_c2 acc = nmx_mk2(0.f, 0.f), acc2 = nmx_mk2(0.f, 0.f);
+#if defined(NMX_HOST_EMU)
           NMX_UNROLL
           for (int i = 0; i < 16; ++i) {
             if (HALF && (i & 3) >= 2) continue;
@@ -415,6 +513,25 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
             acc = nmx_cadd(acc, val);
             acc2 = nmx_c2_fma(val, val, acc2);
           }
+#else
+          // BRANCH-FREE: every register is weighed per lane by [lo <= sample < hi] (one unsigned compare per
+          // sample) and always accumulated -- adding the zeros of the registers outside the tail changes no
+          // bit.  The wave-uniform skip / straddle tests this replaces were ~20 scalar branches and up to three
+          // out-of-line calls per filter: measured (s_memtime, -DNMX_BANK_PROFILE) at ~2 400 cycles per filter,
+          // a quarter of the whole item, for 16 packed operations of arithmetic.
+          const unsigned span = (unsigned)(hi - lo);
+          const int s_l = 2 * l - lo;
+          NMX_UNROLL
+          for (int i = 0; i < 16; ++i) {
+            if (HALF && (i & 3) >= 2) continue;
+            const int sb = s_l + 2 * (64 * (i >> 2) + 256 * (i & 3));
+            nmx_c2 val = v[NMX_LI][i];
+            val.x = (unsigned)sb < span ? val.x : 0.f;
+            val.y = (unsigned)(sb + 1) < span ? val.y : 0.f;
+            acc = nmx_cadd(acc, val);
+            acc2 = nmx_c2_fma(val, val, acc2);
+          }
+#endif
           part[NMX_LI] = acc.x + acc.y;
           part2[NMX_LI] = acc2.x + acc2.y;
         }
@@ -467,6 +584,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         }
       }
     }
+    NMX_PROF(5)
     // ---- fused sharp-wave analysis: the series goes registers -> LDS, never to HBM ---------------
     bool sw_done = false;
 #ifndef NMX_HOST_EMU
@@ -577,7 +695,9 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       }
     }
     NMX_WSYNC();
+    NMX_PROF(7)
   }
+  NMX_PROF_PRINT(w, c)
 }
 
 // ---- Hilbert envelope kernel: y[item][W] -> |analytic(y)| (exact length-W transforms) ----------

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "nmx_k_bank_w64.h"
+#include "nmx_k_bank_w64p.h"
 
 #ifndef NMX_W64_NAME
 #error "define NMX_W64_NAME"
@@ -41,6 +42,28 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // the kernel's time), then every wave walks its own items with wave-local fences only.
 // HIL = 1: Hilbert envelopes of the burst bands inside the kernel (tables after the twiddles in LDS).
 // HALF = 1: windows of at most 1024 samples -- the upper half of each inverse transform's outputs is never formed.
+#ifdef NMX_LDS_ASM
+// Pipelined persistent kernel (nmx_k_bank_w64p.h): the A / B tables are staged INTERLEAVED ((A_k, B_k) pairs: one
+// 8-byte read per point), everything else as below.
+template <int HALF>
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)(const NmxBankW64Args A, int n_items,
+                                                                                    int x_floats) {
+  float* tab = nmx_smem_w64;
+  const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
+  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
+    const int fi = i / (2 * n), j = i - fi * 2 * n;
+    tab[i] = (j & 1) ? A.Hd[fi][j >> 1] : A.Hs[fi][j >> 1];
+  }
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
+#pragma nounroll
+  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
+    nmx_bank_w64_item_pipe<HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+}
+#endif
+
 template <int WAVES, int FUSE, int HIL, int HALF = 0>
 __global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
                                                                                      int n_items, int x_floats,
@@ -157,6 +180,12 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   if (nw < want) return 0;
   static unsigned long long seen = 0;
   if (nmx_first_on_device(seen)) {
+#ifdef NMX_LDS_ASM
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>,
@@ -184,6 +213,20 @@ extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
     return 3;
   } else {
     static const NmxSharpArgs none{};
+#ifdef NMX_LDS_ASM
+    static int pipe_ok = -1;
+    if (pipe_ok < 0) { const char* pv = getenv("NMX_W64_PIPE"); pipe_ok = !(pv && pv[0] == '0'); }
+    if (pipe_ok && nw == 8 && !hil && (A->b.W & 1) == 0) {   // software-pipelined item (nmx_k_bank_w64p.h)
+      if (A->b.W <= 1024 && half_ok) {
+        hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
+        NMX_KNAME("nmx_kern_bank_w64pp_", "<1>");
+      } else {
+        hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
+        NMX_KNAME("nmx_kern_bank_w64pp_", "<0>");
+      }
+      return 1;
+    }
+#endif
     if (nw == 12) {
       hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
                          n_items, x_floats, none);
