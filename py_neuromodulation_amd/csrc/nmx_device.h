@@ -213,6 +213,7 @@ NMX_DEV nmx_c2 nmx_c2_axpby_swap(float a, nmx_c2 z, float b, nmx_c2 zc) {
 #endif
 
 #ifndef NMX_HOST_EMU
+#include <utility>
 // ---- LDS reads the compiler cannot pair up ------------------------------------------------------
 // On gfx950 a wave's ds_read_b64 is serviced in 2 LDS cycles (256 B/clk/CU); ds_read2_b64 / ds_read2st64_*
 // -- what the load/store optimiser makes of two 8-byte reads off one base register -- take the older
@@ -267,6 +268,15 @@ NMX_DEV nmx_c2 nmx_axpby_swap_pair(nmx_c2 ab, nmx_c2 z, nmx_c2 zc) {
                "+v"((a)[6]), "+v"((a)[7]) : : "memory")
 NMX_DEV void nmx_lds_wait8(nmx_c2* a) { NMX_TIE8("s_waitcnt lgkmcnt(0)", a); }
 NMX_DEV void nmx_lds_tie8(nmx_c2* a) { NMX_TIE8("", a); }
+NMX_DEV void nmx_lds_tie2(nmx_c2& a, nmx_c2& b) { asm volatile("" : "+v"(a), "+v"(b) : : "memory"); }
+NMX_DEV void nmx_lds_wait5(nmx_c2& a, nmx_c2& b, nmx_c2& c, nmx_c2& d, nmx_c2& e) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory");
+}
+// v[I] = *(addr + BASE + STRIDE * I) as unpaired ds_read_b64, I = 0 .. N - 1
+template <int STRIDE, int BASE, int... I>
+NMX_DEV void nmx_ds_read_seq(nmx_c2* v, unsigned addr, std::integer_sequence<int, I...>) {
+  ((v[I] = nmx_ds_read_b64<BASE + STRIDE * I>(addr)), ...);
+}
 #endif
 
 // ---------------------------------------------------------------------------------------

@@ -179,11 +179,6 @@ NMX_UNROLL
 #define NMX_W64_TWL_FLOATS (2 * (NMX_W64_TWB_N + NMX_W64_TWC_N))
 #if defined(NMX_LDS_ASM) && !defined(NMX_HOST_EMU)
 #include <utility>
-// a whole read phase as unpaired ds_read_b64 (see nmx_device.h): v[I] = *(base + STRIDE_BYTES * I)
-template <int STRIDE, int BASE, int... I>
-NMX_DEV void nmx_ds_read_seq(nmx_c2* v, unsigned addr, std::integer_sequence<int, I...>) {
-  ((v[I] = nmx_ds_read_b64<BASE + STRIDE * I>(addr)), ...);
-}
 // pass C order: v[4 t + q] = X[lane + 64 t + 256 q]
 template <int... I>
 NMX_DEV void nmx_ds_read_passC(nmx_c2* v, unsigned addr, std::integer_sequence<int, I...>) {

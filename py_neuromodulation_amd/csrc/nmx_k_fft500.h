@@ -50,10 +50,10 @@ NMX_DEV void nmx_dft5_c2(nmx_c2& x0, nmx_c2& x1, nmx_c2& x2, nmx_c2& x3, nmx_c2&
   const nmx_c2 t1 = x1 + x4, t2 = x2 + x3, d1 = x1 - x4, d2 = x2 - x3;
   const nmx_c2 m1 = x0 + c1 * t1 + c2 * t2, m2 = x0 + c2 * t1 + c1 * t2;
   const nmx_c2 u1 = s1 * d1 + s2 * d2, u2 = s2 * d1 - s1 * d2;
-  const nmx_c2 n1 = {-u1.y, u1.x}, n2 = {-u2.y, u2.x};
   x0 = x0 + t1 + t2;
-  x1 = m1 + n1; x4 = m1 - n1;
-  x2 = m2 + n2; x3 = m2 - n2;
+  // m +- i u: the +-i rides on the add (nmx_add_ib: op_sel / neg modifiers, one instruction)
+  x1 = nmx_add_ib<+1>(m1, u1); x4 = nmx_add_ib<-1>(m1, u1);
+  x2 = nmx_add_ib<+1>(m2, u2); x3 = nmx_add_ib<-1>(m2, u2);
 }
 
 // 10-point DFT of v[0..9] in place (output index q in natural order), 10 = 2 x 5
@@ -77,9 +77,9 @@ template <int DIR, typename TW>
 NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T, int lane) {
   nmx_c2 v[10];
   if (lane < 50) {
-    // stage 1: R = 10, Ns = 1: in[j + 50 r] -> a[10 j + r]
-#pragma unroll
-    for (int r = 0; r < 10; ++r) v[r] = in[lane + 50 * r];
+    // stage 1: R = 10, Ns = 1: in[j + 50 r] -> a[10 j + r]   (unpaired ds_read_b64: nmx_device.h)
+    nmx_ds_read_seq<400, 0>(v, nmx_lds_addr(in + lane), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]);
     nmx_dft10_c2<DIR>(v);
     nmx_c2* o = a + 10 * lane;
 #pragma unroll
@@ -88,10 +88,10 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T
   NMX_WAVE_FENCE();
   if (lane < 50) {
     // stage 2: R = 10, Ns = 10: a[j + 50 r] * w^(5 k r) -> b[100 q + k + 10 r],  q = j / 10, k = j % 10
+    nmx_ds_read_seq<400, 0>(v, nmx_lds_addr(a + lane), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) v[r] = a[lane + 50 * r];
-#pragma unroll
-    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul(v[r], nmx_twd<DIR>(T.get(r - 1)));
+    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul_tw<(DIR > 0)>(v[r], T.get(r - 1));
     nmx_dft10_c2<DIR>(v);
     const int q = lane / 10, k = lane - 10 * q;
     nmx_c2* o = b + 100 * q + k;
@@ -103,12 +103,14 @@ NMX_DEV nmx_c2* nmx_w500_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T
     // stage 3: R = 5, Ns = 100: b[j + 100 r] * w^(j r) -> a[j + 100 r],  j = lane and lane + 50
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const nmx_c2* src = b + lane + 50 * h;
-      nmx_c2 x0 = src[0], x1 = src[100], x2 = src[200], x3 = src[300], x4 = src[400];
-      x1 = nmx_cmul(x1, nmx_twd<DIR>(T.get(9 + 4 * h)));
-      x2 = nmx_cmul(x2, nmx_twd<DIR>(T.get(10 + 4 * h)));
-      x3 = nmx_cmul(x3, nmx_twd<DIR>(T.get(11 + 4 * h)));
-      x4 = nmx_cmul(x4, nmx_twd<DIR>(T.get(12 + 4 * h)));
+      nmx_c2 x[5];
+      nmx_ds_read_seq<800, 0>(x, nmx_lds_addr(b + lane + 50 * h), std::make_integer_sequence<int, 5>{});
+      nmx_lds_wait5(x[0], x[1], x[2], x[3], x[4]);
+      nmx_c2 x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], x4 = x[4];
+      x1 = nmx_cmul_tw<(DIR > 0)>(x1, T.get(9 + 4 * h));
+      x2 = nmx_cmul_tw<(DIR > 0)>(x2, T.get(10 + 4 * h));
+      x3 = nmx_cmul_tw<(DIR > 0)>(x3, T.get(11 + 4 * h));
+      x4 = nmx_cmul_tw<(DIR > 0)>(x4, T.get(12 + 4 * h));
       nmx_dft5_c2<DIR>(x0, x1, x2, x3, x4);
       nmx_c2* o = a + lane + 50 * h;
       o[0] = x0; o[100] = x1; o[200] = x2; o[300] = x3; o[400] = x4;
@@ -126,8 +128,8 @@ template <typename TW>
 NMX_DEV nmx_c2* nmx_w500_fft_fwd_low(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T, int lane, int k_hi) {
   nmx_c2 v[10];
   if (lane < 50) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) v[r] = in[lane + 50 * r];
+    nmx_ds_read_seq<400, 0>(v, nmx_lds_addr(in + lane), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]);
     nmx_dft10_c2<-1>(v);
     nmx_c2* o = a + 10 * lane;
 #pragma unroll
@@ -135,10 +137,10 @@ NMX_DEV nmx_c2* nmx_w500_fft_fwd_low(const nmx_c2* in, nmx_c2* a, nmx_c2* b, con
   }
   NMX_WAVE_FENCE();
   if (lane < 50) {
+    nmx_ds_read_seq<400, 0>(v, nmx_lds_addr(a + lane), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) v[r] = a[lane + 50 * r];
-#pragma unroll
-    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul(v[r], T.get(r - 1));
+    for (int r = 1; r < 10; ++r) v[r] = nmx_cmul_tw<0>(v[r], T.get(r - 1));
     nmx_dft10_c2<-1>(v);
     const int q = lane / 10, k = lane - 10 * q;
     nmx_c2* o = b + 100 * q + k;
@@ -156,18 +158,17 @@ NMX_DEV nmx_c2* nmx_w500_fft_fwd_low(const nmx_c2* in, nmx_c2* a, nmx_c2* b, con
       if (!(lo || hi)) continue;
       const nmx_c2* src = b + j;
       nmx_c2 x0 = src[0], x1 = src[100], x2 = src[200], x3 = src[300], x4 = src[400];
-      x1 = nmx_cmul(x1, T.get(9 + 4 * h));
-      x2 = nmx_cmul(x2, T.get(10 + 4 * h));
-      x3 = nmx_cmul(x3, T.get(11 + 4 * h));
-      x4 = nmx_cmul(x4, T.get(12 + 4 * h));
+      x1 = nmx_cmul_tw<0>(x1, T.get(9 + 4 * h));
+      x2 = nmx_cmul_tw<0>(x2, T.get(10 + 4 * h));
+      x3 = nmx_cmul_tw<0>(x3, T.get(11 + 4 * h));
+      x4 = nmx_cmul_tw<0>(x4, T.get(12 + 4 * h));
       const nmx_c2 t1 = x1 + x4, t2 = x2 + x3;
       if (lo) a[j] = x0 + t1 + t2;
       if (hi) {
         const nmx_c2 d1 = x1 - x4, d2 = x2 - x3;
         const nmx_c2 m1 = x0 + c1 * t1 + c2 * t2;
         const nmx_c2 u1 = s1 * d1 + s2 * d2;
-        const nmx_c2 n1 = {-u1.y, u1.x};
-        a[j + 400] = m1 - n1;
+        a[j + 400] = nmx_add_ib<-1>(m1, u1);
       }
     }
   }
