@@ -189,19 +189,27 @@ template <int... I>
 NMX_DEV void nmx_ds_read_twC(nmx_c2* w, unsigned addr, std::integer_sequence<int, I...>) {
   ((w[4 * (I / 3) + 1 + (I % 3)] = nmx_ds_read_b64<512 * (4 * (I % 3) + (I / 3))>(addr)), ...);
 }
-template <int DIR>
+// TWLDS: the twiddle table is the LDS copy of the persistent / quad kernels (else global memory, L2)
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twB, int lane) {
   nmx_c2 w[16];
   nmx_ds_read_seq<544, 0>(v, nmx_lds_addr(X + lane + (lane >> 4)), std::make_integer_sequence<int, 16>{});
-  nmx_ds_read_seq<128, 0>(w + 1, nmx_lds_addr(twB + (lane & 15)), std::make_integer_sequence<int, 15>{});
-  w[0] = w[1];
-  nmx_lds_wait8(v); nmx_lds_tie8(v + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+  if (TWLDS) {
+    nmx_ds_read_seq<128, 0>(w + 1, nmx_lds_addr(twB + (lane & 15)), std::make_integer_sequence<int, 15>{});
+    w[0] = w[1];
+    nmx_lds_wait8(v); nmx_lds_tie8(v + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+  } else {
+    const nmx_c2* tw = twB + (lane & 15);
+    NMX_UNROLL
+    for (int r = 1; r < 16; ++r) w[r] = tw[16 * (r - 1)];
+    nmx_lds_wait8(v); nmx_lds_tie8(v + 8);
+  }
   NMX_UNROLL
   for (int r = 1; r < 16; ++r) v[r] = nmx_cmul_tw<(DIR > 0)>(v[r], w[r]);
   nmx_dft16<DIR>(v);
 }
 #else
-template <int DIR>
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twB, int lane) {
   const nmx_c2* Xi = X + lane + (lane >> 4);
   NMX_UNROLL
@@ -213,13 +221,20 @@ NMX_DEV void nmx_w64_passB_load_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* tw
 }
 #endif
 #if defined(NMX_LDS_ASM) && !defined(NMX_HOST_EMU)
-template <int DIR, int HALF>
+template <int DIR, int HALF, int TWLDS>
 NMX_DEV void nmx_w64_passC_asm(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
   nmx_c2 a[16], w[16];
   nmx_ds_read_passC(a, nmx_lds_addr(X + lane), std::make_integer_sequence<int, 16>{});
-  nmx_ds_read_twC(w, nmx_lds_addr(twC + lane), std::make_integer_sequence<int, 12>{});
-  w[0] = w[4] = w[8] = w[12] = w[1];
-  nmx_lds_wait8(a); nmx_lds_tie8(a + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+  if (TWLDS) {
+    nmx_ds_read_twC(w, nmx_lds_addr(twC + lane), std::make_integer_sequence<int, 12>{});
+    w[0] = w[4] = w[8] = w[12] = w[1];
+    nmx_lds_wait8(a); nmx_lds_tie8(a + 8); nmx_lds_tie8(w); nmx_lds_tie8(w + 8);
+  } else {
+    const nmx_c2* tw = twC + lane;
+    NMX_UNROLL
+    for (int t = 0; t < 4; ++t) { w[4 * t + 1] = tw[64 * t]; w[4 * t + 2] = tw[64 * (4 + t)]; w[4 * t + 3] = tw[64 * (8 + t)]; }
+    nmx_lds_wait8(a); nmx_lds_tie8(a + 8);
+  }
 NMX_UNROLL
   for (int t = 0; t < 4; ++t) {
     nmx_c2 a0 = a[4 * t], a1 = a[4 * t + 1], a2 = a[4 * t + 2], a3 = a[4 * t + 3];
@@ -236,18 +251,18 @@ NMX_UNROLL
     }
   }
 }
-template <int DIR>
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passC_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
-  nmx_w64_passC_asm<DIR, 0>(v, X, twC, lane);
+  nmx_w64_passC_asm<DIR, 0, TWLDS>(v, X, twC, lane);
 }
-template <int DIR>
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passC_lds_half(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
-  nmx_w64_passC_asm<DIR, 1>(v, X, twC, lane);
+  nmx_w64_passC_asm<DIR, 1, TWLDS>(v, X, twC, lane);
 }
 #define NMX_W64_PASSC_DEFINED 1
 #endif
 #ifndef NMX_W64_PASSC_DEFINED
-template <int DIR>
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passC_lds(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
   const nmx_c2* tw = twC + lane;
 NMX_UNROLL
@@ -264,7 +279,7 @@ NMX_UNROLL
 
 // Inverse pass C when only the first half of the outputs is read (W <= 1024 samples = packed index
 // m < 512 = the r = 0, 1 outputs of each 4-point butterfly): two of the four outputs, 6 instead of 8 adds.
-template <int DIR>
+template <int DIR, int TWLDS = 1>
 NMX_DEV void nmx_w64_passC_lds_half(nmx_c2* v, const nmx_c2* X, const nmx_c2* twC, int lane) {
   const nmx_c2* tw = twC + lane;
 NMX_UNROLL
@@ -407,13 +422,13 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   NMX_WSYNC();  // (pad_mode 1: everyone has read xs before X is overwritten)
   NMX_LANE_LOOP { nmx_w64_passA<-1>(v[NMX_LI], X, l); }
   NMX_WSYNC();
-  NMX_LANE_LOOP { nmx_w64_passB_load_lds<-1>(v[NMX_LI], X, twB, l); }
+  NMX_LANE_LOOP { nmx_w64_passB_load_lds<-1, TAB>(v[NMX_LI], X, twB, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP {
     nmx_c2* vv = v[NMX_LI];
-    nmx_w64_passC_lds<-1>(vv, X, twC, l);
+    nmx_w64_passC_lds<-1, TAB>(vv, X, twC, l);
     NMX_UNROLL
     for (int i = 0; i < 16; ++i) zr[NMX_LI][i] = vv[i];
   }
@@ -471,15 +486,15 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     }
     NMX_WSYNC();
     NMX_PROF(1)
-    NMX_LANE_LOOP { nmx_w64_passB_load_lds<+1>(v[NMX_LI], X, twB, l); }
+    NMX_LANE_LOOP { nmx_w64_passB_load_lds<+1, TAB>(v[NMX_LI], X, twB, l); }
     NMX_WSYNC();
     NMX_PROF(2)
     NMX_LANE_LOOP { nmx_w64_passB_store(v[NMX_LI], X, l); }
     NMX_WSYNC();
     NMX_PROF(3)
     NMX_LANE_LOOP {
-      if (HALF) nmx_w64_passC_lds_half<+1>(v[NMX_LI], X, twC, l);
-      else nmx_w64_passC_lds<+1>(v[NMX_LI], X, twC, l);
+      if (HALF) nmx_w64_passC_lds_half<+1, TAB>(v[NMX_LI], X, twC, l);
+      else nmx_w64_passC_lds<+1, TAB>(v[NMX_LI], X, twC, l);
     }
     NMX_PROF(4)
     // now lane l holds y[2 m], y[2 m + 1] in v[4 t + r] for m = l + 64 t + 256 r
