@@ -275,6 +275,19 @@ int nmx_norm_state_size(const nmx_norm* norm, int64_t* n_bytes);
 int nmx_norm_state_export(nmx_norm* norm, void* dst, int64_t n_bytes);
 int nmx_norm_state_import(nmx_norm* norm, const void* src, int64_t n_bytes);
 
+/* The feature normaliser INSIDE the launch sequence: once attached, every nmx_process_batch /
+ * nmx_process_window of `plan` normalises its output rows on the device (same stream, hop order, chunk by
+ * chunk) before they are copied back -- the features never make the extra host round trip of a separate
+ * nmx_norm_process call.  norm == NULL detaches.  The normaliser must live on the plan's device and have
+ * n_cols == the plan's n_outputs; the plan does not own it. */
+int nmx_plan_attach_norm(nmx_plan* plan, nmx_norm* norm);
+
+/* Page-locked host memory for the buffers handed to memspace-0 calls: copies from / to it run at the full
+ * PCIe rate and truly asynchronously (pageable memory is staged by the runtime at a fraction of that and
+ * blocks the calling thread).  Plain pointers; free with nmx_host_free. */
+int nmx_host_alloc(int64_t n_bytes, void** out);
+int nmx_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

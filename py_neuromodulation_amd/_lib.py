@@ -84,6 +84,7 @@ _EXPORTS = [
     "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms", "nmx_last_kernels",
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
+    "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free",
 ]
 
 
@@ -137,6 +138,9 @@ class NmxLibrary:
         L.nmx_norm_state_size.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.nmx_norm_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.nmx_norm_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.nmx_plan_attach_norm.argtypes = [C.c_void_p, C.c_void_p]
+        L.nmx_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+        L.nmx_host_free.argtypes = [C.c_void_p]
         if L.nmx_abi_version() != NMX_ABI_VERSION:
             raise NmxError("libnmx ABI version mismatch")
 

@@ -47,11 +47,12 @@ def load_channels(channels):
 
 def channel_info(df):
     """stream/data_processor.py:141-160 -> (ch_names_used, feature_idx, target_idx)."""
-    sel = (df["used"] == 1) & (df["status"] == "good")
-    ch_names_used = df.loc[sel, "new_name"].tolist()
-    feature_idx = [i for i in np.where(df["used"].astype(bool) & ~df["target"].astype(bool))[0].tolist()
-                   if df.loc[i, "status"] == "good"]
-    target_idx = np.where(df["target"] == 1)[0].tolist()
+    used = df["used"].to_numpy() == 1
+    good = df["status"].to_numpy() == "good"
+    target = df["target"].to_numpy() == 1
+    ch_names_used = df["new_name"].to_numpy()[used & good].tolist()
+    feature_idx = np.flatnonzero(df["used"].to_numpy().astype(bool) & ~df["target"].to_numpy().astype(bool) & good).tolist()
+    target_idx = np.flatnonzero(target).tolist()
     return ch_names_used, feature_idx, target_idx
 
 
@@ -67,6 +68,8 @@ def reref_matrix(df) -> np.ndarray | None:
     status = sub["status"].tolist()
     refs = sub["rereference"].tolist()
     R = np.zeros((n, n))
+    types_a, good_a = np.asarray(types, dtype=object), np.asarray(status, dtype=object) == "good"
+    same_type_good = {t: np.flatnonzero((types_a == t) & good_a) for t in set(types)}   # one scan per type, not per row
     for i in range(n):
         R[i, i] = 1.0
         ref = refs[i]
@@ -74,7 +77,8 @@ def reref_matrix(df) -> np.ndarray | None:
                 or status[i] != "good":
             continue
         if ref.lower() == "average":
-            idx = [j for j in range(n) if types[j] == types[i] and status[j] == "good" and j != i]
+            grp = same_type_good[types[i]]
+            idx = grp[grp != i]
         else:
             idx = []
             for rc in ref.split("&"):

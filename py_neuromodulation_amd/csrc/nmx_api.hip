@@ -119,6 +119,12 @@ static void* be_alloc(size_t n) {
   return p;
 }
 static void be_free(void* p) { (void)hipFree(p); }
+static void* be_host_alloc(size_t n) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+static void be_host_free(void* p) { (void)hipHostFree(p); }
 static void be_h2d_sync(void* d, const void* s, size_t n) { BE_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); }
 static void be_d2h_sync(void* d, const void* s, size_t n) { BE_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); }
 static void be_memset_sync(void* d, int v, size_t n) { BE_TRY(hipMemset(d, v, n)); }

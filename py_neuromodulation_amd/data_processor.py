@@ -166,6 +166,7 @@ class DataProcessor:
         self.feature_normalizer = None
         self.non_psd_indices = None
         self.device_normalizer = None
+        self._norm_in_engine = False
         if st.postprocessing.feature_normalization:
             fs = st.feature_normalization_settings
             if not fs.normalize_psd:
@@ -179,6 +180,9 @@ class DataProcessor:
                     mask[self.non_psd_indices] = 1
                 self.device_normalizer = DeviceFeatureNormalizer(st, len(self.keys), colmask=mask,
                                                                  device=device, lib=lib)
+                # inside the engine's launch sequence: rows come back normalised (no second round trip)
+                self.engine.attach_normalizer(self.device_normalizer)
+                self._norm_in_engine = True
             else:  # median / scikit-learn methods: host NumPy, hop by hop like the reference
                 self.feature_normalizer = FeatureNormalizer(st)
         # NaN policy: columns whose key contains the channel's new_name (substring, as the reference);
@@ -186,10 +190,21 @@ class DataProcessor:
         # and a NaN channel is the exception)
         self._nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
         self.cnt_samples = 0
+        self.settings_token = None
+
+    def reset(self) -> None:
+        """Forget everything carried across hops (burst history, Kalman filters, raw and feature normaliser
+        histories): the state of a freshly constructed processor."""
+        self.engine.reset_state()
+        if self.device_normalizer is not None:
+            self.device_normalizer.reset()
+        if self.feature_normalizer is not None:
+            self.feature_normalizer = FeatureNormalizer(self.settings)
+        self.cnt_samples = 0
 
     # ------------------------------------------------------------------------------------
     def _postprocess_row(self, row: np.ndarray, nan_rows: np.ndarray) -> np.ndarray:
-        if self.device_normalizer is not None:
+        if self.device_normalizer is not None and not self._norm_in_engine:
             row = self.device_normalizer.process(row)
         if self.feature_normalizer is not None:
             if self.non_psd_indices is not None:
@@ -219,14 +234,19 @@ class DataProcessor:
     def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
         """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
         applied hop by hop because the normaliser is sequential)."""
-        out, mask = self.engine.process_batch(data, starts, want_nan_mask=True)
-        return self.postprocess_batch(out, mask)
+        out, mask = self.engine.process_batch(data, starts, want_nan_mask=True, staged_output=True)
+        return self.postprocess_batch(out, mask, normalised=self._norm_in_engine)
 
-    def postprocess_batch(self, out: np.ndarray, mask: np.ndarray) -> np.ndarray:
-        """Normalisation + NaN policy for raw engine rows ``out[n, F]`` (hop order)."""
-        if self.device_normalizer is not None:
+    def postprocess_batch(self, out: np.ndarray, mask: np.ndarray, normalised: bool = False) -> np.ndarray:
+        """Normalisation + NaN policy for engine rows ``out[n, F]`` (hop order); ``normalised``: the
+        attached device normaliser already ran inside the engine."""
+        from .engine import parallel_cast
+
+        if self.device_normalizer is not None and not normalised:
             out = self.device_normalizer.process_batch(out)
-        out = out.astype(np.float64)
+        o64 = np.empty(out.shape, np.float64)
+        parallel_cast(o64, out)
+        out = o64
         if self.feature_normalizer is None and not mask.any():
             return out
         if self.feature_normalizer is None:

@@ -42,6 +42,75 @@ def _cols(base=0, ch=0, a=0, b=0) -> Cols:
     return Cols(int(base), int(ch), int(a), int(b))
 
 
+_POOL = None
+
+
+def _pool():
+    """A few host threads for the dtype conversions around a batch (NumPy's casting loops release the GIL):
+    float64 recording -> float32 staging and float32 features -> float64 table are 100+ MB each."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
+def parallel_cast(dst: np.ndarray, src: np.ndarray) -> None:
+    """dst[...] = src (with cast), first axis split over the conversion threads."""
+    n = dst.shape[0]
+    if dst.size < (1 << 20) or n < 2:
+        dst[...] = src
+        return
+    k = min(n, 8)
+    edges = [(i * n) // k for i in range(k + 1)]
+
+    def job(i):
+        dst[edges[i]:edges[i + 1]] = src[edges[i]:edges[i + 1]]
+
+    list(_pool().map(job, range(k)))
+
+
+_STAGING: dict = {}
+
+
+def _staging(lib) -> "_Pinned":
+    """ONE staging pool per loaded library, shared by every engine (page-locking ~170 MB costs tens of
+    milliseconds -- Stream.run builds a fresh engine per run, like the reference builds a fresh
+    DataProcessor).  Engines are not re-entrant (include/nmx.h), neither is the pool."""
+    key = str(lib.path)
+    if key not in _STAGING:
+        _STAGING[key] = _Pinned(lib)
+    return _STAGING[key]
+
+
+class _Pinned:
+    """Page-locked staging arrays (nmx_host_alloc), grown on demand and reused across calls."""
+
+    def __init__(self, lib) -> None:
+        self.lib, self._bufs = lib, {}
+
+    def array(self, name: str, shape, dtype) -> np.ndarray:
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr, cap = self._bufs.get(name, (None, 0))
+        if cap < n:
+            if ptr:
+                self.lib.lib.nmx_host_free(ptr)
+            p = C.c_void_p()
+            self.lib.check(self.lib.lib.nmx_host_alloc(n + n // 8 + 64, C.byref(p)))
+            ptr, cap = p.value, n + n // 8 + 64
+            self._bufs[name] = (ptr, cap)
+        buf = (C.c_char * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self) -> None:
+        for ptr, _ in self._bufs.values():
+            if ptr:
+                self.lib.lib.nmx_host_free(ptr)
+        self._bufs = {}
+
+
 class HotPathEngine:
     """One plan on one GPU for ``len(ch_names)`` channels."""
 
@@ -99,8 +168,10 @@ class HotPathEngine:
         self.n_outputs = len(self.keys)
         self.C_in = int(self.desc.n_channels_in)
         self._plan = C.c_void_p()
+        self._pinned = None
         if not dry_run:
             self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
+            self._pinned = _staging(self.lib)
 
     # ------------------------------------------------------------------------------------
     def _dptr(self, arr: np.ndarray):
@@ -378,6 +449,7 @@ class HotPathEngine:
         if getattr(self, "_plan", None) is not None and self._plan.value:
             self.lib.lib.nmx_plan_destroy(self._plan)
             self._plan = C.c_void_p()
+        self._pinned = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -412,19 +484,50 @@ class HotPathEngine:
             mask.ctypes.data if mask is not None else None))
         return (out, mask.astype(bool)) if want_nan_mask else out
 
-    def process_batch(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False):
-        """data[C_in, T] host array, starts[n] window start samples -> float32[n, n_outputs]."""
+    def attach_normalizer(self, norm) -> None:
+        """Run ``norm`` (a DeviceFeatureNormalizer or None) inside this plan's launch sequence: every batch /
+        window comes back already normalised, without a second host round trip (nmx_plan_attach_norm)."""
+        self.lib.check(self.lib.lib.nmx_plan_attach_norm(self._plan, norm._h if norm is not None else None))
+        self._norm = norm   # keep it alive
+
+    def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+        """A page-locked array of the caller's own (lives as long as the library's staging pool): inputs /
+        ``out=`` buffers allocated here move at the full PCIe rate, asynchronously."""
+        self._n_user = getattr(self, "_n_user", 0) + 1
+        return self._pinned.array(f"user{id(self)}_{self._n_user}", tuple(shape), dtype)
+
+    def process_batch(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False,
+                      staged_output: bool = False, out: np.ndarray | None = None):
+        """data[C_in, T] host array, starts[n] window start samples -> float32[n, n_outputs].
+
+        A recording that is not contiguous float32 is cast into a page-locked staging array (first axis
+        split over a few threads): the host -> device copies then run at the PCIe rate next to the kernels;
+        contiguous float32 input is handed over as it is (allocate it with ``pinned_empty`` for the same
+        effect).  ``out``: caller's float32[n, n_outputs] buffer.  ``staged_output=True`` returns a VIEW of
+        the library's page-locked output staging array (valid until the next call) instead of a fresh
+        array -- for callers that convert / consume the rows right away."""
         data = np.asarray(data)
-        if data.dtype != np.float32 or data.strides[1] != 4:
-            data = np.ascontiguousarray(data, dtype=np.float32)
         if data.ndim != 2 or data.shape[0] != self.C_in:
             raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
         starts = np.ascontiguousarray(starts, dtype=np.int64)
         n = len(starts)
-        out = np.empty((n, self.n_outputs), np.float32)
+        if data.dtype == np.float32 and data.strides[1] == 4:
+            x = data
+        elif data.size >= (1 << 18):
+            x = self._pinned.array("x", data.shape, np.float32)
+            parallel_cast(x, data)
+        else:
+            x = np.ascontiguousarray(data, dtype=np.float32)
+        if out is not None:
+            if out.dtype != np.float32 or out.shape != (n, self.n_outputs) or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a C-contiguous float32 array of shape ({n}, {self.n_outputs})")
+        elif staged_output and n * self.n_outputs >= (1 << 18):
+            out = self._pinned.array("out", (n, self.n_outputs), np.float32)
+        else:
+            out = np.empty((n, self.n_outputs), np.float32)
         mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
         self.lib.check(self.lib.lib.nmx_process_batch(
-            self._plan, data.ctypes.data, data.strides[0] // 4, data.shape[1], starts.ctypes.data, n,
+            self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
             out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
         return (out, mask.astype(bool)) if want_nan_mask else out
 

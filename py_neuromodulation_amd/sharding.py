@@ -128,7 +128,8 @@ class ShardedStream:
         mask_all = self._gather_mask(mask, len(self.channels), group)
         if mask_all.any() and mask_all.shape[1] != len(dp.ch_names_used):
             raise IndexError("boolean index did not match: NaN handling needs every channel used")
-        rows = dp.postprocess_batch(out, mask_all if mask_all.any() else np.zeros((len(out), len(dp.ch_names_used)), bool))
+        rows = dp.postprocess_batch(out, mask_all if mask_all.any() else np.zeros((len(out), len(dp.ch_names_used)), bool),
+                                    normalised=dp._norm_in_engine)
         return list(dp.keys), rows, times
 
 

@@ -54,11 +54,19 @@ class Stream:
         # fail early like the reference (it builds a DataProcessor in __init__, :130)
         self.data_processor = self._make_processor(None)
 
+    def _settings_token(self):
+        """Changes whenever the settings / channel table the processor was built from change."""
+        import json
+
+        return json.dumps(self.settings.to_dict(), sort_keys=True, default=str) + self.channels.to_json()
+
     def _make_processor(self, window):
-        return DataProcessor(sfreq=self.sfreq, settings=self.settings, channels=self.channels,
-                             line_noise=self.line_noise, verbose=self.verbose, device=self.device,
-                             window=window, lib=self._lib,
-                             resample_features_at_new_rate=self._resample_new_rate)
+        dp = DataProcessor(sfreq=self.sfreq, settings=self.settings, channels=self.channels,
+                           line_noise=self.line_noise, verbose=self.verbose, device=self.device,
+                           window=window, lib=self._lib,
+                           resample_features_at_new_rate=self._resample_new_rate)
+        dp.settings_token = self._settings_token()
+        return dp
 
     def _handle_data(self, data) -> np.ndarray:
         names_expected = self.channels["name"].to_list()
@@ -109,14 +117,28 @@ class Stream:
             groups = sorted(set(int(x) for x in lens))
             if len(groups) > 1 and "bursts" in st.features.get_enabled():
                 raise NotImplementedError("bursts with a non-integer hop (ragged windows) is not supported")
-            # a fresh DataProcessor per run, like the reference (:233-242), one per window length
-            procs = {w: self._make_processor(w) for w in groups}
+            # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
+            # processor per window length.  The processor built by __init__ (or by the previous run) is
+            # reused with its state reset when it fits -- same results, no second plan build.
+            procs = {}
+            for w in groups:
+                dp = self.data_processor
+                if (len(groups) == 1 and dp is not None and dp.engine.W_in == w and dp.settings_token == self._settings_token()):
+                    dp.reset()
+                    procs[w] = dp
+                else:
+                    procs[w] = self._make_processor(w)
             self.data_processor = procs[groups[0]]
             keys = list(self.data_processor.keys)
             if len(groups) == 1:
                 rows = self.data_processor.process_batch(data, starts)
             else:
-                # ragged windows (float sampling rate): the normaliser is sequential over ALL hops
+                # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
+                # cannot run inside the per-length engines: detach, normalise the merged rows afterwards
+                for p in procs.values():
+                    if p._norm_in_engine:
+                        p.engine.attach_normalizer(None)
+                        p._norm_in_engine = False
                 raw = np.empty((len(starts), len(keys)), dtype=np.float32)
                 masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
                 for w, p in procs.items():

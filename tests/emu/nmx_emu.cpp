@@ -32,6 +32,8 @@ static int be_device_count() { return 1; }
 static int be_set_device(int) { return 0; }
 static void* be_alloc(size_t n) { return calloc(1, n ? n : 4); }
 static void be_free(void* p) { free(p); }
+static void* be_host_alloc(size_t n) { return malloc(n ? n : 4); }
+static void be_host_free(void* p) { free(p); }
 static void be_h2d_sync(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 static void be_d2h_sync(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 static void be_memset_sync(void* d, int v, size_t n) { memset(d, v, n); }
