@@ -31,8 +31,11 @@ def run(eng, C, W, hop, n, dev, torch, steps=4):
         eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, st)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
+    stages = (("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5))
     return {"windows_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "hops_per_batch": n,
-            "channels": C, "features_per_window": eng.n_outputs, "nan_outputs": int(torch.isnan(out).sum().item())}
+            "channels": C, "features_per_window": eng.n_outputs, "nan_outputs": int(torch.isnan(out).sum().item()),
+            "stage_ms": {k: round(eng.timing_ms(i), 3) for k, i in stages},
+            "kernels": {k: eng.kernels(i) for k, i in stages if eng.kernels(i)}}
 
 
 def main():
