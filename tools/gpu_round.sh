@@ -8,16 +8,16 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O
-if [[ $STEPS == all || $STEPS == *test* ]]; then
+if [[ $STEPS == *all* || $STEPS == *test* ]]; then
   timeout 1200 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu.log 2>&1; tail -3 $O/${TAG}_pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log
 fi
-if [[ $STEPS == all || $STEPS == *bench* ]]; then
+if [[ $STEPS == *all* || $STEPS == *bench* ]]; then
   timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   tail -c 600 $O/${TAG}_bench.json
   NMX_OVERLAP=0 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start > $O/${TAG}_bench_nooverlap.json 2>/dev/null
 fi
-if [[ $STEPS == all || $STEPS == *prof* ]]; then
+if [[ $STEPS == *all* || $STEPS == *prof* ]]; then
   rm -rf $O/prof_$TAG $O/pmc_fetch_$TAG $O/pmc_write_$TAG
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o p -- python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start > $O/${TAG}_prof.log 2>&1
   python tools/rocpd_summary.py $(ls $O/prof_$TAG/*.db | head -1) $O/${TAG}_kernel_stats.csv | head -16
