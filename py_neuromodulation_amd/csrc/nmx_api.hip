@@ -235,6 +235,7 @@ extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStr
 extern "C" void nmx_w64_launch_rd64(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" int nmx_w64p_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64q_launch_notch_rd64(const NmxBankW64Args*, int, hipStream_t);
+extern "C" int nmx_w64x2_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64q_launch_notch_slp(const NmxBankW64Args*, int, hipStream_t);
@@ -259,6 +260,10 @@ static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, 
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       n_cu = prop.multiProcessorCount;
+  }
+  if (A.tw2) {   // M = 4096 path (nmx_k_bank_w64x2.h): one kernel for every batch size
+    if (!nmx_w64x2_launch_rd64(&A, n_items, n_cu, s)) g_be_rc = nmx_fail(NMX_E_INVALID, "M = 4096 FIR path: LDS budget");
+    return 0;
   }
   if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
     const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)

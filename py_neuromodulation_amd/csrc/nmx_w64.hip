@@ -9,6 +9,7 @@
 
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_bank_w64p.h"
+#include "nmx_k_bank_w64x2.h"
 
 #ifndef NMX_W64_NAME
 #error "define NMX_W64_NAME"
@@ -122,6 +123,53 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_
   nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels,
                              nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats, tab);
 }
+
+#ifdef NMX_LDS_ASM
+// M = 4096 (nmx_k_bank_w64x2.h): persistent workgroups of `nw` waves; LDS = tables of the first n_tab filters,
+// pass B / C twiddles, w^k, one exchange tile per wave
+template <int HALF>
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)(const NmxBankW64Args A, int n_items,
+                                                                                    int x_floats, int n_tab) {
+  float* tab = nmx_smem_w64;
+  const int tab_floats = n_tab * 4096;
+  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) tab[i] = A.Hs[i >> 12][i & 4095];
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) tab[tab_floats + NMX_W64_TWL_FLOATS + i] = A.tw2[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + 2048 + wave * x_floats;
+#pragma nounroll
+  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
+    nmx_bank_w64x2_item<HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, n_tab);
+}
+
+extern "C" int NMX_CAT(nmx_w64x2_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)<0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)<1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  static int nw_env = 0;
+  if (!nw_env) { const char* v = getenv("NMX_W64X2_WAVES"); nw_env = (v && atoi(v) >= 1 && atoi(v) <= 8) ? atoi(v) : 8; }
+  const int nw = nw_env, x_floats = A->lds_floats;
+  int n_tab = (160 * 1024 / 4 - NMX_W64_TWL_FLOATS - 2048 - nw * x_floats) / 4096;
+  if (n_tab > A->b.n_filters) n_tab = A->b.n_filters;
+  if (n_tab < 0) return 0;
+  const size_t lds = (size_t)(n_tab * 4096 + NMX_W64_TWL_FLOATS + 2048 + nw * x_floats) * 4;
+  int grid = n_cu > 0 ? n_cu : 256;
+  if (grid * nw > n_items) grid = (n_items + nw - 1) / nw;
+  if (A->b.W <= 2048) {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats, n_tab);
+    NMX_KNAME("nmx_kern_bank_w64x2_", "<1>");
+  } else {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats, n_tab);
+    NMX_KNAME("nmx_kern_bank_w64x2_", "<0>");
+  }
+  return 1;
+}
+#endif
 
 // returns 0 when the configuration does not fit (caller falls back to one wave per workgroup)
 extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, hipStream_t s) {
