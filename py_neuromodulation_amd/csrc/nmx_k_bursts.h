@@ -361,9 +361,11 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
 //     (binary search in the sorted pending list in LDS) -- all loads independent, no dependent chains.
 // 17 KB of LDS and one wave per sequence.  Same values as nmx_burst_thr_item, bit for bit.
 #define NMX_THRW_PF 16
-#define NMX_THRW_I 128
+#define NMX_THRW_I 256
 // + K / 64 + 2 block counters (launcher)
-#define NMX_THRW_LDS_FLOATS (2 * NMX_THR_F + 3 * NMX_THR_P + NMX_THRW_I + NMX_THRW_PF * 128)
+// NR = registers per lane holding a hop's new samples: 2 (overlap <= 128) or 4 (overlap <= 256: 2 kHz at 10 Hz)
+#define NMX_THRW_LDS_FLOATS_NR(NR) (2 * 256 * (NR) + 3 * NMX_THR_P + NMX_THRW_I + NMX_THRW_PF * 64 * (NR))
+#define NMX_THRW_LDS_FLOATS NMX_THRW_LDS_FLOATS_NR(2)
 
 // number of entries of the DESCENDING list l[0..n) that are > v
 NMX_DEV int nmx_count_gt_lds(const float* l, int n, float v) {
@@ -377,13 +379,14 @@ NMX_DEV int nmx_count_gt_lds(const float* l, int n, float v) {
 
 // host-side test: may the wave kernel take this batch?  (first hop already in the steady regime)
 static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long windows_seen) {
-  if (windows_seen <= 0 || A.overlap > 128 || A.overlap + 8 >= NMX_THR_FREFILL) return false;
+  const int nr = A.overlap <= 128 ? 2 : 4;   // registers per lane -> fringe capacity 256 nr, refill 192 nr
+  if (windows_seen <= 0 || A.overlap > 256 || A.overlap + 8 >= 192 * nr) return false;
   const long long total = (long long)A.W + (windows_seen - 1) * (long long)A.overlap;
   const long long m_ring = A.n_ring;
   const double pos_ring = A.q * (double)(m_ring - 1);
   const long long lo_ring = (long long)floor(pos_ring);
   const int ia_ring = (int)(m_ring - 1 - lo_ring);
-  return A.K > 2 * NMX_THR_F && total >= m_ring && ia_ring >= A.K - 3 && ia_ring < A.K;
+  return A.K > 2 * 256 * nr && total >= m_ring && ia_ring >= A.K - 3 && ia_ring < A.K;
 }
 
 #ifdef NMX_THRW_PROFILE
@@ -391,20 +394,24 @@ static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long win
 #else
 #define NMX_TP(i)
 #endif
+template <int NR>
 NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
   const int lane = (int)(threadIdx.x & 63);
+  // fringe capacity scales with the samples a hop brings: a stationary signal accepts ~(1 - q) of them, each
+  // evicts one fringe entry, and a flush (sort + stream of the whole top-K list) is due when the fringe runs low
+  constexpr int TF = 256 * NR, TREFILL = 192 * NR;
 #ifdef NMX_THRW_PROFILE
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
   int n_ins = 0, n_flush = 0;
 #endif
-  float* F = smem;                          // [NMX_THR_F] ascending fringe: entries F[fh .. fh + nF)
-  float* F2 = F + NMX_THR_F;
-  float* Pp = F2 + NMX_THR_F;               // [NMX_THR_P] pending, unsorted
+  float* F = smem;                          // [TF] ascending fringe: entries F[fh .. fh + nF)
+  float* F2 = F + TF;
+  float* Pp = F2 + TF;               // [NMX_THR_P] pending, unsorted
   float* ps = Pp + NMX_THR_P;               // [NMX_THR_P] pending, sorted descending (flush)
   int* ins = (int*)(ps + NMX_THR_P);        // [NMX_THR_P] insertion indices (flush)
   float* I = (float*)(ins + NMX_THR_P);     // [NMX_THRW_I] this hop's fringe inserts
-  float* stage = I + NMX_THRW_I;            // [NMX_THRW_PF][128] new samples of the current group of hops
-  int* cb = (int*)(stage + NMX_THRW_PF * 128);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
+  float* stage = I + NMX_THRW_I;            // [NMX_THRW_PF][64 NR] new samples of the current group of hops
+  int* cb = (int*)(stage + NMX_THRW_PF * 64 * NR);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
   const int K = A.K, W = A.W, ov = A.overlap;
   const long long sidx = (long long)c * A.n_bands + bi;
   float* L = A.top + sidx * K;              // descending top-K list (global, L2 resident)
@@ -417,7 +424,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
   const int ja = K - 1 - (int)(m_ring - 1 - lo_ring);   // ascending fringe index of s[lo]: 0, 1 or 2
 
   // enter: cut the fringe from the list's tail
-  int nF = NMX_THR_FREFILL, fh = 0, Lm = K - nF, nP = 0;
+  int nF = TREFILL, fh = 0, Lm = K - nF, nP = 0;
   for (int j = lane; j < nF; j += 64) F[j] = L[K - 1 - j];
   NMX_WAVE_FENCE();
   float T = F[0], Fmax = F[nF - 1];
@@ -425,27 +432,29 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
 
   const long long hop_stride = (long long)A.n_channels * A.n_bands * W;
   const float* e0 = A.env + ((long long)c * A.n_bands + bi) * W + (W - ov);
-  const bool v0 = lane < ov, v1 = lane + 64 < ov;
-  float na[NMX_THRW_PF], nb[NMX_THRW_PF];   // samples of the next NMX_THRW_PF hops
+  float nx[NR][NMX_THRW_PF];   // samples of the next NMX_THRW_PF hops, register q of a lane = sample lane + 64 q
 #pragma unroll
   for (int u = 0; u < NMX_THRW_PF; ++u) {
     const float* e = e0 + (long long)u * hop_stride;
     const bool in = u < A.n_windows;
-    na[u] = (in && v0) ? e[lane] : -INFINITY;
-    nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) nx[q][u] = (in && lane + 64 * q < ov) ? e[lane + 64 * q] : -INFINITY;
   }
   for (int w0 = 0; w0 < A.n_windows; w0 += NMX_THRW_PF) {
     // the group's samples go to LDS so that the hop loop below stays ROLLED (one copy of the insert and
     // flush code)
 #pragma unroll
-    for (int u = 0; u < NMX_THRW_PF; ++u) { stage[128 * u + lane] = na[u]; stage[128 * u + 64 + lane] = nb[u]; }
+    for (int u = 0; u < NMX_THRW_PF; ++u) {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) stage[64 * NR * u + 64 * q + lane] = nx[q][u];
+    }
 #pragma unroll
     for (int u = 0; u < NMX_THRW_PF; ++u) {   // in flight while this group of hops is processed
       const int w = w0 + NMX_THRW_PF + u;
       const float* e = e0 + (long long)w * hop_stride;
       const bool in = w < A.n_windows;
-      na[u] = (in && v0) ? e[lane] : -INFINITY;
-      nb[u] = (in && v1) ? e[lane + 64] : -INFINITY;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) nx[q][u] = (in && lane + 64 * q < ov) ? e[lane + 64 * q] : -INFINITY;
     }
     NMX_WAVE_FENCE();
     NMX_TP(0)   // group top: wait for the prefetched samples, stage them, issue the next loads
@@ -453,28 +462,50 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
 #pragma nounroll
     for (int u = 0; u < ng; ++u) {
       const int w = w0 + u;
-      const float x0 = stage[128 * u + lane], x1 = stage[128 * u + 64 + lane];
-      const bool c0 = x0 > T, c1 = x1 > T;
-      const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
-      const int a = __popcll(b0) + __popcll(b1);
+      float x[NR];
+      bool cc[NR];
+      unsigned long long bm[NR];
+      int a = 0;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        x[q] = stage[64 * NR * u + 64 * q + lane];
+        cc[q] = x[q] > T;
+        bm[q] = __ballot(cc[q]);
+        a += __popcll(bm[q]);
+      }
       NMX_TP(1)   // classify
       if (a) {
-        const bool i0 = c0 && x0 <= Fmax, i1 = c1 && x1 <= Fmax;
-        const unsigned long long bi0 = __ballot(i0), bi1 = __ballot(i1);
-        const unsigned long long bp0 = b0 & ~bi0, bp1 = b1 & ~bi1;
-        const int nI = __popcll(bi0) + __popcll(bi1);
+        // accepted samples either fall inside the fringe (inserts, list I) or above it (pending list P);
+        // both lists are filled in sample order: register q before q + 1, lanes ascending (mbcnt compaction)
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (c0 && !i0) Pp[nP + __popcll(bp0 & below)] = x0;
-        if (c1 && !i1) Pp[nP + __popcll(bp0) + __popcll(bp1 & below)] = x1;
-        nP += __popcll(bp0) + __popcll(bp1);
+        bool ii[NR];
+        unsigned long long bim[NR];
+        int nI = 0, np_new = 0;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          ii[q] = cc[q] && x[q] <= Fmax;
+          bim[q] = __ballot(ii[q]);
+          const unsigned long long bpm = bm[q] & ~bim[q];
+          if (cc[q] && !ii[q]) Pp[nP + np_new + __popcll(bpm & below)] = x[q];
+          np_new += __popcll(bpm);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) nI += __popcll(bim[q]);
+        nP += np_new;
         if (nI == 0) {
           // every accepted sample lies above the fringe: the a smallest fringe entries are evicted and
           // nothing moves -- advance the head
           fh += a;
           nF -= a;
         } else {
-          if (i0) I[__popcll(bi0 & below)] = x0;
-          if (i1) I[__popcll(bi0) + __popcll(bi1 & below)] = x1;
+          {
+            int at = 0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+              if (ii[q]) I[at + __popcll(bim[q] & below)] = x[q];
+              at += __popcll(bim[q]);
+            }
+          }
           NMX_WAVE_FENCE();
           // new fringe = (F u I) minus its a smallest; ties: fringe entries first
           const float* Fc = F + fh;
@@ -485,14 +516,14 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
             float iv[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) iv[r] = r < nI ? I[r] : INFINITY;
-            float fv[NMX_THR_F / 64];
+            float fv[TF / 64];
 #pragma unroll
-            for (int q = 0; q < NMX_THR_F / 64; ++q) fv[q] = (lane + 64 * q < nF) ? Fc[lane + 64 * q] : INFINITY;
+            for (int q = 0; q < TF / 64; ++q) fv[q] = (lane + 64 * q < nF) ? Fc[lane + 64 * q] : INFINITY;
             int le[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) le[r] = 0;
 #pragma unroll
-            for (int q = 0; q < NMX_THR_F / 64; ++q) {
+            for (int q = 0; q < TF / 64; ++q) {
               if (64 * q >= nF) break;
               const float v = fv[q];
               int lt = 0;
@@ -637,7 +668,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
         for (int j = lane; j < nF; j += 64) L[Lm + j] = F[fh + nF - 1 - j];
         // (Lm + nF == K by construction)
         __threadfence();   // the re-cut below reads what this wave just stored
-        nF = NMX_THR_FREFILL;
+        nF = TREFILL;
         fh = 0;
         Lm = K - nF;
         nP = 0;

@@ -34,17 +34,27 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
 }
 
-// threshold walk, steady regime: one wave per (channel, band)
+// threshold walk, steady regime: one wave per (channel, band); NR = registers per lane for a hop's new samples
+template <int NR>
 __global__ void __launch_bounds__(64) nmx_kern_burst_thr_wave(const NmxBurstThrArgs A) {
   __builtin_amdgcn_s_setprio(3);   // sequential and on the critical path: win issue arbitration
   const int item = blockIdx.x;
-  nmx_burst_thr_wave_item(A, item / A.n_bands, item % A.n_bands, nmx_smem_wave);
+  nmx_burst_thr_wave_item<NR>(A, item / A.n_bands, item % A.n_bands, nmx_smem_wave);
 }
 
 extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s) {
-  const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS + A->K / 64 + 4) * 4;
-  hipLaunchKernelGGL(nmx_kern_burst_thr_wave, dim3(n_items), dim3(64), lds, s, *A);
-  nmxi_note_kernel("nmx_kern_burst_thr_wave");
+  if (A->overlap <= 128) {
+    const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS_NR(2) + A->K / 64 + 4) * 4;
+    hipLaunchKernelGGL(nmx_kern_burst_thr_wave<2>, dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel("nmx_kern_burst_thr_wave<2>");
+  } else {
+    static unsigned long long seen = 0;
+    if (nmx_first_on_device(seen))
+      (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS_NR(4) + A->K / 64 + 4) * 4;
+    hipLaunchKernelGGL(nmx_kern_burst_thr_wave<4>, dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel("nmx_kern_burst_thr_wave<4>");
+  }
 }
 
 // Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)

@@ -480,7 +480,8 @@ def test_linearity_of_the_filter_stages(gpu_lib):
     eng.close()
 
 
-def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("sfreq,ring_s,n_hops", [(1000.0, 30, 900), (2000.0, 3, 400)])
+def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch, sfreq, ring_s, n_hops):
     """The burst threshold walk has two implementations: the 256-thread workgroup kernel (fill regime and
     transitions) and the barrier-free one-wave kernel used when the 30 s ring is already full at the first
     hop of a batch.  Both move the same values around, so every burst feature must agree BIT FOR BIT over a
@@ -490,8 +491,10 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
     from py_neuromodulation_amd.engine import HotPathEngine
 
     s = NMSettings.get_default()
-    sfreq, C, n_hops = 1000.0, 3, 900
-    T = 1000 + (n_hops - 1) * 100
+    s.bursts_settings.time_duration_s = ring_s   # (2 kHz: 200 new samples per hop -> four registers per lane in the wave kernel)
+    s = s.validate()
+    C, W, hop = 3, int(sfreq), int(sfreq / 10)
+    T = W + (n_hops - 1) * hop
     rng = np.random.default_rng(5)
     t = np.arange(T) / sfreq
     amp = 1 + 0.8 * np.sin(2 * np.pi * 0.05 * t) + 2 * t / t[-1]          # slowly growing power: steady inserts
@@ -499,7 +502,7 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
     data[1] *= 1e-3                                                        # tiny amplitudes
     data[2] = np.round(data[2])                                            # many equal values (ties)
     ch = [f"ch{i}" for i in range(C)]
-    starts = np.arange(n_hops) * 100
+    starts = np.arange(n_hops) * hop
     monkeypatch.setenv("NMX_CHUNK_WINDOWS", "128")
 
     def run(wave, plan, export_at=None):
@@ -520,8 +523,9 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch):
     want = run(False, [n_hops])
     assert not np.isnan(want).any()
     np.testing.assert_array_equal(run(True, [n_hops]), want)
-    np.testing.assert_array_equal(run(True, [300, 1, 7, 292, 300]), want)
-    np.testing.assert_array_equal(run(True, [450, 450], export_at=450), want)
+    a, b = n_hops // 3, n_hops // 2
+    np.testing.assert_array_equal(run(True, [a, 1, 7, n_hops - 2 * a - 8, a]), want)
+    np.testing.assert_array_equal(run(True, [b, n_hops - b], export_at=b), want)
 
 
 @pytest.mark.parametrize("W", [800, 901])
