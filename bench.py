@@ -131,6 +131,14 @@ def bank_flops_per_item(M: int, n_filters: int, seglens) -> float:
     return float(rfft + n_filters * (6 * (M / 2 + 1) + rfft) + 3 * sum(seglens))
 
 
+def bank_flops_per_item_pair(M: int, n_filters: int, seglens) -> float:
+    """The channel-pair kernel (nmx_k_bank_w64c.h): per PAIR of channels one complex FFT(M) forward, per filter a
+    real-by-complex spectral product (2 M) and a complex inverse FFT(M), tail variances 3 seglen per channel;
+    complex FFT(M) ~ 5 M log2 M.  Returned per item (one channel)."""
+    cfft = 5.0 * M * np.log2(M)
+    return float(0.5 * (cfft + n_filters * (2 * M + cfft)) + 3 * sum(seglens))
+
+
 def config_settings(name: str):
     """BASELINE.json configs[3] / configs[4]."""
     from py_neuromodulation_amd import NMSettings
@@ -205,12 +213,12 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
-    names_t = ("prep", "timeosc", "bank", "bursts", "sharp", "batch")
+    names_t = ("prep", "timeosc", "bank", "bank_sw", "bursts", "sharp", "batch")
     kt = {k: 0.0 for k in names_t}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5)):
+        for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("bursts", 4), ("sharp", 5)):
             kt[name] += eng.timing_ms(idx)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -238,7 +246,7 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
                        "parallelism": f"channel-shard x{world}" + (", group sum all-reduced per step" if car else ", no collective")},
             "features_per_sec": value * F * world,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
-            "kernels": {name: eng.kernels(i) for name, i in (("prep", 1), ("timeosc", 2), ("bank", 3), ("sharp", 5))},
+            "kernels": {name: eng.kernels(i) for name, i in (("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("sharp", 5))},
             "nan_outputs": bad,
             "roofline": {"bound": "hbm", "kernel": eng.kernels(idx), "stage": stage,
                          "achieved": algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -328,12 +336,12 @@ def main() -> None:
         step()
     torch.cuda.synchronize(dev)
     barrier()
-    kt = {k: 0.0 for k in ("prep", "timeosc", "bank", "bursts", "sharp", "batch")}
+    kt = {k: 0.0 for k in ("prep", "timeosc", "bank", "bank_sw", "bursts", "sharp", "batch")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         # HIP-event timers of this launch sequence (recorded on the launch stream inside libnmx)
-        for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5)):
+        for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("bursts", 4), ("sharp", 5)):
             kt[name] += eng.timing_ms(idx)
     torch.cuda.synchronize(dev)
     barrier()
@@ -369,7 +377,12 @@ def main() -> None:
             except Exception:
                 traffic = None
         nf = int(eng.desc.n_filters)
-        flops_item = bank_flops_per_item(2048, nf, [eng.desc.filters[i].bp_seglen for i in range(nf)])
+        if "w64c" in kernel:   # the M = 1536 channel-pair kernel took the filters with W + (L - 1) / 2 <= 1536
+            sel = [i for i in range(nf) if W + (int(eng.desc.filters[i].n_taps) - 1) // 2 <= 1536]
+            nf = len(sel)
+            flops_item = bank_flops_per_item_pair(1536, nf, [eng.desc.filters[i].bp_seglen for i in sel])
+        else:
+            flops_item = bank_flops_per_item(2048, nf, [eng.desc.filters[i].bp_seglen for i in range(nf)])
         tflops = n_win * C * flops_item / (bank_ms * 1e-3) / 1e12 if bank_ms > 0 else 0.0
         res = {
             "metric": "windows/sec (all features), 256 ch @ 1 kHz", "value": value, "unit": "windows/s",
@@ -385,7 +398,7 @@ def main() -> None:
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
             "nan_outputs": bad,
             "kernels": {name: eng.kernels(idx) for name, idx in
-                        (("prep", 1), ("timeosc", 2), ("bank", 3), ("bursts", 4), ("sharp", 5))},
+                        (("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("bursts", 4), ("sharp", 5))},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_at_commit": traffic_at,
@@ -393,7 +406,10 @@ def main() -> None:
                          "fp32": {"flops_per_item": flops_item, "filters": nf, "achieved_TFLOPs": tflops,
                                   "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": tflops / FP32_VECTOR_PEAK_TFLOPS},
                          "note": "the FIR bank is FP32-vector / LDS bound (SURVEY 8d): frac is vs the HBM roof as "
-                                 "the contract asks, fp32.frac vs the roof that binds"},
+                                 "the contract asks, fp32.frac vs the roof that binds; kernel = the band-pass bank "
+                                 "(window in, band-pass features out); filters whose taps are too long for it (the "
+                                 "two 1651-tap sharp-wave filters of the default settings) run in a second launch, "
+                                 "kernels.bank_sw / kernel_ms_per_step.bank_sw"},
             "cold_start_ms": cold_ms,
             "regime": "steady state: warm-up steps fill the 30 s burst history; cold_start_ms = first step of a fresh plan",
         }

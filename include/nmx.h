@@ -237,11 +237,12 @@ int nmx_state_import(nmx_plan* plan, const void* src, int64_t n_bytes);
 
 /* Timing of the last nmx_process_batch, measured with HIP events on the launch stream:
  * which = 0 whole batch, 1 pre-processing, 2 time/oscillatory kernel, 3 FIR-bank kernel,
- * 4 bursts kernels, 5 sharp-wave kernel.  Blocks until the events have completed. */
+ * 4 bursts kernels, 5 sharp-wave kernel, 6 second FIR-bank launch (the filters whose taps are too long for the
+ * M = 1536 channel-pair kernel; 0 when there is none).  Blocks until the events have completed. */
 int nmx_last_timing_ms(nmx_plan* plan, int which, float* ms);
 
 /* Names of the kernels the first launch sequence of the last nmx_process_batch ran in stage `which`
- * (1..5 as above; several kernels are joined by " + "), spelled as rocprofv3 --kernel-trace prints them
+ * (1..6 as above; several kernels are joined by " + "), spelled as rocprofv3 --kernel-trace prints them
  * (template arguments included).  Which variant runs depends on the shape, the batch size and the tuning
  * knobs, so measurement code names the kernel from here instead of hard-coding it.  NUL-terminated,
  * truncated to n - 1 characters. */

@@ -72,6 +72,9 @@ struct NmxBankW64Args {
   // envelope goes to b.env_out [n_windows][C][Bb][W]; table layout: nmx_k_fft500.h
   const float* hil_tab;
   const float* twl;       // NMX_W64_TWL_FLOATS floats: per-lane twiddles of passes B and C (persistent kernel)
+  const float* hc;        // M = 1536 channel-pair path (nmx_k_bank_w64c.h): [n_filters][12][64] pairs of the REAL spectrum in
+                          // register order; twc = [24][64] complex pass-A twiddles, then [8][8] complex exp(-2 pi i a b / 64)
+  const float* twc;
   const float* tw2;       // M = 4096 path (nmx_k_bank_w64x2.h): [1024] complex exp(-2 pi i k / 2048); Hs[f] then holds the
                           // INTERLEAVED (A_k, B_k) table of filter f, 2048 pairs
   // fused sharp-wave analysis (persistent kernel): list offsets inside the exchange tile (floats,

@@ -10,6 +10,7 @@
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_bank_w64p.h"
 #include "nmx_k_bank_w64x2.h"
+#include "nmx_k_bank_w64c.h"
 
 #ifndef NMX_W64_NAME
 #error "define NMX_W64_NAME"
@@ -167,6 +168,53 @@ extern "C" int NMX_CAT(nmx_w64x2_launch_, NMX_W64_NAME)(const NmxBankW64Args* A,
     hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats, n_tab);
     NMX_KNAME("nmx_kern_bank_w64x2_", "<0>");
   }
+  return 1;
+}
+#endif
+
+#ifdef NMX_LDS_ASM
+// M = 1536, one wave per (window, channel pair) (nmx_k_bank_w64c.h): workgroups of `nw` waves; LDS = the real spectra of
+// all filters, the pass-A twiddles, one exchange tile per wave.  A wave walks a CONTIGUOUS run of `chunk` items in the
+// order (channel pair, window): consecutive items are consecutive hops of the same two channels, whose windows
+// overlap by W - hop samples -- after the first item of a run most of the window comes from L2.
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64c_, NMX_W64_NAME)(const NmxBankW64Args A, int n_windows,
+                                                                                   int n_pairs, int chunk) {
+  float* tab = nmx_smem_w64;
+  const int hf = A.b.n_filters * NMX_W64C_H_FLOATS;
+  for (int i = threadIdx.x; i < hf; i += blockDim.x) tab[i] = A.hc[i];
+  for (int i = threadIdx.x; i < NMX_W64C_TWA_FLOATS; i += blockDim.x) tab[hf + i] = A.twc[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  NmxW64cLane Ln;
+  nmx_w64c_lane_setup(Ln, tab + hf + NMX_W64C_TWA_FLOATS + wave * NMX_W64C_TILE_FLOATS, tab + hf,
+                      A.twc + NMX_W64C_TWA_FLOATS, (int)(threadIdx.x & 63));
+  const int q0 = (blockIdx.x * nw + wave) * chunk;
+  const int q1 = q0 + chunk < n_pairs ? q0 + chunk : n_pairs;
+#pragma nounroll
+  for (int q = q0; q < q1; ++q) {
+    const int cp = q / n_windows;
+    nmx_bank_w64c_item(A, q - cp * n_windows, 2 * cp, Ln, tab);
+  }
+}
+
+// returns 0 when the tables do not fit next to at least six tiles (caller falls back to the M = 2048 kernels)
+extern "C" int NMX_CAT(nmx_w64c_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen))
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64c_, NMX_W64_NAME),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int C = A->b.n_channels, n_windows = n_items / C, n_pairs = n_windows * ((C + 1) / 2);
+  const int fixed = A->b.n_filters * NMX_W64C_H_FLOATS + NMX_W64C_TWA_FLOATS;
+  int nw = (160 * 1024 / 4 - fixed) / NMX_W64C_TILE_FLOATS;
+  if (nw < 6) return 0;
+  if (nw > 8) nw = 8;
+  if (n_pairs < 2048) nw = 2;   // a hop or two: spread the few items over many CUs
+  const size_t lds = (size_t)(fixed + nw * NMX_W64C_TILE_FLOATS) * 4;
+  int grid = n_cu > 0 ? n_cu : 256;
+  if (grid * nw > n_pairs) grid = (n_pairs + nw - 1) / nw;
+  const int chunk = (n_pairs + grid * nw - 1) / (grid * nw);
+  hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64c_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk);
+  NMX_KNAME("nmx_kern_bank_w64c_", "");
   return 1;
 }
 #endif

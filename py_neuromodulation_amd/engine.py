@@ -562,7 +562,8 @@ class HotPathEngine:
 
     def kernels(self, which: int) -> str:
         """Kernels the last batch launched in stage ``which`` (1 prep, 2 time/osc, 3 FIR bank, 4 bursts,
-        5 sharp waves), named as rocprofv3 prints them."""
+        5 sharp waves, 6 the FIR-bank filters left to a second launch: taps too long for the M = 1536 kernel),
+        named as rocprofv3 prints them."""
         buf = C.create_string_buffer(512)
         self.lib.check(self.lib.lib.nmx_last_kernels(self._plan, which, buf, 512))
         return buf.value.decode()

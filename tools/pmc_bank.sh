@@ -8,5 +8,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
   i=$((i+1))
   rm -rf gpurun_out/pmcb_$i
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcb_$i -o p -- python tools/run_bank_only.py > gpurun_out/pmcb_$i.log 2>&1
-  python tools/rocpd_pmc.py $(ls gpurun_out/pmcb_$i/*.db | head -1) | grep -A8 "bank_w64p"
+  python tools/rocpd_pmc.py $(ls gpurun_out/pmcb_$i/*.db | head -1) | grep -A8 "bank_w64c"
 done
