@@ -375,6 +375,29 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
   for (int s = 0; s < p.nstages; ++s) {
     const int R = p.st[s].radix, m = p.st[s].m, ns = p.st[s].ns, tstep = p.st[s].tw_step;
     const unsigned magic = p.st[s].magic;
+    if (R > 5 && !(R10 && R == 10)) {
+      // generic prime radix, O(R^2): ONE OUTPUT per work item -- m R of them, so a 17-point stage of a 255-point
+      // transform (510-sample windows at 30 kHz) keeps 255 lanes busy instead of 15 -- inputs re-read from LDS
+      // (consecutive lanes read consecutive points), stage twiddle and butterfly root in ONE table lookup
+      const int pstep = p.n / R;
+      for (int idx = NMX_TID; idx < m * R; idx += NMX_NT) {
+        const int qq = idx / m, j = idx - qq * m;
+        const int q = (ns == 1) ? j : (int)nmx_umulhi((unsigned)j, magic);
+        const int k = j - q * ns;
+        const int tb = k * tstep;
+        float2 acc = in[j];
+        int e = 0, rt = 0;   // (qq * r) mod R;  r * tb  (< n)
+        for (int r = 1; r < R; ++r) {
+          e += qq;
+          if (e >= R) e -= R;
+          rt += tb;
+          int t = e * pstep + rt;
+          if (t >= p.n) t -= p.n;
+          acc = nmx_cadd(acc, nmx_cmul(in[j + r * m], nmx_tw<DIR>(tw, t)));
+        }
+        out[q * ns * R + k + qq * ns] = acc;
+      }
+    } else
     for (int j = NMX_TID; j < m; j += NMX_NT) {
       const int q = (ns == 1) ? j : (int)nmx_umulhi((unsigned)j, magic);
       const int k = j - q * ns;
@@ -475,21 +498,6 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
         out[o] = nmx_cadd(a0, t);
         out[o + ns] = nmx_cadd(u, v);
         out[o + 2 * ns] = nmx_csub(u, v);
-      } else {
-        // generic prime radix: O(R^2), inputs re-read from LDS (no register array)
-        const int pstep = p.n / R;
-        for (int qq = 0; qq < R; ++qq) {
-          float2 acc = in[j];
-          int e = 0;  // (qq * r) mod R
-          for (int r = 1; r < R; ++r) {
-            e += qq;
-            if (e >= R) e -= R;
-            float2 v = in[j + r * m];
-            if (ns > 1) v = nmx_cmul(v, nmx_tw<DIR>(tw, r * tb));
-            acc = nmx_cadd(acc, nmx_cmul(v, nmx_tw<DIR>(tw, e * pstep)));
-          }
-          out[o + qq * ns] = acc;
-        }
       }
     }
     NMX_SYNC();

@@ -287,7 +287,10 @@ NMX_DEV void nmx_bank_w64c_item(const NmxBankW64Args& AA, int w, int c, const Nm
   }
   NMX_UNROLL
   for (int j = 0; j < 16; ++j) v[j].y = __builtin_amdgcn_ldexpf(v[j].y, e);
-  const nmx_c2 unscale = nmx_mk2(1.f, __builtin_amdgcn_ldexpf(1.f, -e));
+  // a channel that is identically zero (flat, zero-filled, or the missing partner of the last odd channel) must
+  // come out EXACTLY zero, as it does alone (log10(0) -> -inf -> nan_to_num in the reference): its half of the
+  // result would otherwise hold the partner's rounding noise
+  const nmx_c2 unscale = nmx_mk2(m1 > 0.f ? 1.f : 0.f, m2 > 0.f ? __builtin_amdgcn_ldexpf(1.f, -e) : 0.f);
 
   NMX_PROF(0)
   nmx_w64c_forward(v, Ln);

@@ -443,15 +443,61 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
             assert b == 0, f"{tag} hop {i}\n{rep}"
 
     check("default", default)
-    for knob, val in (("NMX_SW_DENSE", "0"), ("NMX_SW_DENSE_FIRST", "0"), ("NMX_CAR_FAST", "0"), ("NMX_OVERLAP", "0"),
-                      ("NMX_FUSE_SHARP", "1"), ("NMX_FUSE_HILBERT", "1"), ("NMX_THR_LIST_GLOBAL", "1"), ("NMX_STFT_PER_WAVE", "0"),
-                      ("NMX_TIMEOSC_W1000", "0"), ("NMX_SHARP_FIRST", "1"),
-                      ("NMX_CHUNK_WINDOWS", "9")):
-        monkeypatch.setenv(knob, val)
+    m2048 = {"NMX_BANK_W64C": "0"}   # every filter on the M = 2048 one-channel kernels (and their fused variants)
+    for knobs in ({"NMX_SW_DENSE": "0"}, {"NMX_SW_DENSE_FIRST": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
+                  m2048, {**m2048, "NMX_FUSE_SHARP": "1"}, {**m2048, "NMX_FUSE_HILBERT": "1"}, {**m2048, "NMX_W64_PIPE": "0"},
+                  {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_STFT_PER_WAVE": "0"}, {"NMX_TIMEOSC_W1000": "0"},
+                  {"NMX_SHARP_FIRST": "1"}, {"NMX_CHUNK_WINDOWS": "9"}):
+        for knob, val in knobs.items():
+            monkeypatch.setenv(knob, val)
         _, keys2, got = run()
-        monkeypatch.delenv(knob)
+        for knob in knobs:
+            monkeypatch.delenv(knob)
         assert keys2 == keys
-        check(f"{knob}={val}", got)
+        check(" ".join(f"{k}={v}" for k, v in knobs.items()), got)
+
+
+def test_channel_pair_bank_odd_count_and_unequal_scales(gpu_lib):
+    """The M = 1536 FIR-bank kernel carries two channels in one complex transform (nmx_k_bank_w64c.h).  An ODD
+    channel count leaves the last channel alone in its transform; neighbours whose amplitudes differ by 10^4 and
+    10^-3 must each keep the accuracy they would have alone (the second channel is rescaled by a power of two);
+    a flat channel next to a live one stays exactly flat.  Against the float64 oracle under the standard policy,
+    and batch == window-by-window bit for bit (the pairing does not depend on how hops are batched)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    C, n_hops, W = 7, 6, 1000
+    T = W + (n_hops - 1) * 100
+    rng = np.random.default_rng(123)
+    t = np.arange(T) / 1000.0
+    x = rng.standard_normal((C, T)) * 30 + 8 * np.sin(2 * np.pi * 21 * t)
+    x[1] *= 1e4       # loud second half of pair (0, 1)
+    x[2] *= 1e4       # loud first half of pair (2, 3)
+    x[5] *= 1e-3      # quiet second half of pair (4, 5)
+    x[4] = 0.0        # flat first half
+    x = x.astype(np.float32)
+    starts = np.arange(n_hops) * 100
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.bandpass_filter = True
+    names = [f"ch{i}" for i in range(C)]
+    eng = HotPathEngine(s, names, 1000.0, lib=gpu_lib)
+    got = eng.process_batch(x, starts)
+    assert "w64c" in eng.kernels(3)
+    keys = list(eng.keys)
+    one = np.stack([eng.process_batch(x[:, a:a + W].copy(), np.zeros(1, dtype=np.int64))[0] for a in starts])
+    np.testing.assert_array_equal(got, one)
+    eng.close()
+    feats = [orc._FEATURE_CLS[n](s, names, 1000.0) for n in s.features.get_enabled()]
+    for i, a in enumerate(starts):
+        want: dict = {}
+        for f in feats:
+            want.update(f.calc_feature(x[:, a:a + W].astype(np.float64)))
+        assert list(want) == keys
+        ver = parity.Verifier(s, names, 1000.0, x[:, a:a + W].astype(np.float64))
+        b, rep, _ = parity.compare(keys, got[i], [want[k] for k in keys], s, 1000.0, 400.0, W, verifier=ver)
+        assert b == 0, f"hop {i}\n{rep}"
 
 
 def test_linearity_of_the_filter_stages(gpu_lib):
