@@ -836,6 +836,64 @@ class Resampler:
 # --------------------------------------------------------------------------------------
 
 
+# scikit-learn based methods (processing/normalization.py:57-70,166-186): every hop the reference FITS the
+# scaler on nan_to_num(history) and transforms the current rows.  scikit-learn is a third-party dependency of the
+# reference (pyproject: scikit-learn >= 1.x; 1.7.2 in this image); its published algorithms are restated here with
+# NumPy and pinned by tests/golden/norm_methods.npz, which tests/golden/make_golden.py generates by running the
+# reference's own Normalizer (with scikit-learn) in the build container:
+#   RobustScaler        center = nanmedian, scale = nanpercentile 75 - 25 (linear), scale < 10 eps -> 1; (x - c) / s
+#   MinMaxScaler        scale = 1 / (max - min) (range < 10 eps -> 1), min_ = -min * scale; x * scale + min_
+#   QuantileTransformer(n_quantiles = 300, uniform): n_q = min(300, n_samples); quantiles = running maximum of
+#       nanpercentile(history, linspace(0, 1, n_q) * 100); y = (interp(x, q, r) - interp(-x, -q[::-1], -r[::-1])) / 2,
+#       x == q[0] -> 0, x == q[-1] -> 1.  Histories of more than 10 000 rows are randomly subsampled by
+#       scikit-learn (subsample = 10 000, random_state = None): the reference itself is not reproducible there.
+#   PowerTransformer    (Yeo-Johnson, lambda by maximum likelihood through scipy.stats.yeojohnson) is NOT restated.
+_SK_EPS10 = 10 * np.finfo(np.float64).eps
+
+
+def _sk_fit_transform(method, prev, cur):
+    X = np.nan_to_num(np.asarray(prev, np.float64))
+    cur = np.array(cur, dtype=np.float64)
+    one_d = cur.ndim == 1
+    Y = cur[None] if one_d else cur
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if method == "robust":
+            center = np.nanmedian(X, axis=0)
+            q = np.nanpercentile(X, (25.0, 75.0), axis=0)
+            scale = q[1] - q[0]
+            scale[scale < _SK_EPS10] = 1.0
+            out = (Y - center) / scale
+        elif method == "minmax":
+            lo, hi = np.nanmin(X, axis=0), np.nanmax(X, axis=0)
+            rng = hi - lo
+            rng[rng < _SK_EPS10] = 1.0
+            scale = 1.0 / rng
+            out = Y * scale + (0.0 - lo * scale)
+        elif method == "quantile":
+            n = X.shape[0]
+            if n > 10000:
+                raise NotImplementedError("QuantileTransformer subsamples histories of more than 10 000 rows at random")
+            nq = min(300, n)
+            refs = np.linspace(0, 1, nq, endpoint=True)
+            quant = np.maximum.accumulate(np.nanpercentile(X, refs * 100, axis=0))
+            out = np.empty_like(Y)
+            for j in range(Y.shape[1]):
+                col, qj = Y[:, j].copy(), quant[:, j]
+                lower, upper = col == qj[0], col == qj[-1]
+                fin = ~np.isnan(col)
+                cf = col[fin]
+                col[fin] = 0.5 * (np.interp(cf, qj, refs) - np.interp(-cf, -qj[::-1], -refs[::-1]))
+                col[upper] = 1.0
+                col[lower] = 0.0
+                out[:, j] = col
+        else:
+            raise NotImplementedError(method)
+    return out[0] if one_d else out
+
+
+_SK_METHODS = ("robust", "minmax", "quantile")
+
+
 class RawNormalizer:
     """processing/normalization.py:31-116 with type "raw": history = the first window plus the last
     int(sfreq / feat_hz) samples of every later window, statistics over it incl. the current tail,
@@ -855,17 +913,23 @@ class RawNormalizer:
             return data
         cur = data.T
         self.prev = np.vstack((self.prev, cur[-self.add:]))
-        has_nan = np.any(np.isnan(sum(self.prev)))
-        mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)
-        std = (np.nanstd if has_nan else np.std)(self.prev, axis=0)
-        std[std == 0] = 1
-        with np.errstate(divide="ignore", invalid="ignore"):
-            if self.method == "mean":
-                out = (cur - mean) / mean
-            elif self.method == "zscore":
-                out = (cur - mean) / std
-            else:
-                raise NotImplementedError(self.method)
+        if self.method in _SK_METHODS:
+            out = _sk_fit_transform(self.method, self.prev, cur)
+        else:
+            has_nan = np.any(np.isnan(sum(self.prev)))
+            mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)
+            std = (np.nanstd if has_nan else np.std)(self.prev, axis=0)
+            std[std == 0] = 1
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if self.method == "mean":
+                    out = (cur - mean) / mean
+                elif self.method == "zscore":
+                    out = (cur - mean) / std
+                elif self.method in ("median", "zscore-median"):
+                    med = (np.nanmedian if has_nan else np.median)(self.prev, axis=0)
+                    out = (cur - med) / (med if self.method == "median" else std)
+                else:
+                    raise NotImplementedError(self.method)
         if self.clip:
             out = out.clip(min=-self.clip, max=self.clip)
         self.prev = self.prev[-self.n + 1:]
@@ -873,7 +937,7 @@ class RawNormalizer:
 
 
 class FeatureNormalizer:
-    """processing/normalization.py:31-111 for mean / median / zscore / zscore-median."""
+    """processing/normalization.py:31-111 for mean / median / zscore / zscore-median / robust / minmax / quantile."""
 
     def __init__(self, settings) -> None:
         s = settings.feature_normalization_settings
@@ -887,6 +951,12 @@ class FeatureNormalizer:
             self.prev = cur
             return cur
         self.prev = np.vstack((self.prev, cur))
+        if self.method in _SK_METHODS:
+            out = _sk_fit_transform(self.method, self.prev, cur)
+            if self.clip:
+                out = out.clip(min=-self.clip, max=self.clip)
+            self.prev = self.prev[-self.n + 1:]
+            return np.nan_to_num(out)
         has_nan = np.any(np.isnan(sum(self.prev)))
         mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)
         med = (np.nanmedian if has_nan else np.median)(self.prev, axis=0)

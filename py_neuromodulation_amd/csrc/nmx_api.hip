@@ -55,6 +55,10 @@ __global__ void __launch_bounds__(256) nmx_kern_resample(const NmxResampleArgs A
 __global__ void __launch_bounds__(64) nmx_kern_rawnorm_stats(const NmxRawNormArgs A) {
   nmx_rawnorm_stats_item(A, (int)blockIdx.x);
 }
+__global__ void __launch_bounds__(NMX_RAWNORM_ORDER_NT) nmx_kern_rawnorm_order(const NmxRawNormArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float nmx_smem_rn[];
+  nmx_rawnorm_order_item(A, (int)blockIdx.x, nmx_smem_rn);
+}
 __global__ void __launch_bounds__(256) nmx_kern_rawnorm_apply(const NmxRawNormArgs A) {
   nmx_rawnorm_apply(A, (long long)blockIdx.x * 256 + threadIdx.x);
 }
@@ -336,6 +340,14 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, si
   nmxi_note_kernel("nmx_kern_resample");
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
+  if (A.method >= NMX_RAWNORM_MEDIAN) {
+    const size_t lds = (size_t)24 * A.max_list + 8 * NMX_RAWNORM_ORDER_NT;
+    hipLaunchKernelGGL(nmx_kern_rawnorm_order, dim3(A.n_channels), dim3(NMX_RAWNORM_ORDER_NT), lds, s, A);
+    const long long n = (long long)A.n_windows * A.n_channels * A.W;
+    hipLaunchKernelGGL(nmx_kern_rawnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    nmxi_note_kernel("nmx_kern_rawnorm_order + nmx_kern_rawnorm_apply");
+    return;
+  }
   hipLaunchKernelGGL(nmx_kern_rawnorm_stats, dim3(A.n_channels), dim3(64), 0, s, A);
   const long long n = (long long)A.n_windows * A.n_channels * A.W;
   hipLaunchKernelGGL(nmx_kern_rawnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);

@@ -26,6 +26,12 @@
 #define NMX_NORM_ZSCORE 1
 #define NMX_NORM_MEDIAN 2
 #define NMX_NORM_ZSCORE_MEDIAN 3
+// the scikit-learn based methods (processing/normalization.py:57-70,166-186: the scaler is FITTED on
+// nan_to_num(history) every hop and transforms the current row).  Restated from scikit-learn's published
+// algorithms (oracle/nm_oracle.py: _sk_fit_transform, pinned against the reference in tests/golden/norm_methods.npz):
+#define NMX_NORM_ROBUST 4      // RobustScaler: (x - nanmedian) / (percentile 75 - 25), scale < 10 eps -> 1
+#define NMX_NORM_MINMAX 5      // MinMaxScaler: x * s + (0 - min * s), s = 1 / (max - min), range < 10 eps -> 1
+#define NMX_NORM_QUANTILE 6    // QuantileTransformer(n_quantiles = 300), uniform output
 
 struct NmxNormArgs {
   float* rows;                 // [n_rows][ld]  in place
@@ -98,10 +104,92 @@ NMX_DEV void nmx_norm_replace(float* S, int n_cols, int j, int n, float o, float
     S[(long long)px * n_cols + j] = x;
   }
 }
+// scikit-learn methods: the history is nan_to_num'ed in FLOAT64 by the reference, so +-inf features count as
+// +-DBL_MAX there; the fp32 sorted copy holds +-FLT_MAX for them -- widened back when read (WIDE)
+NMX_DEV double nmx_norm_wide(float v) {
+  return v >= 3.402823466e+38f ? 1.7976931348623157e308 : (v <= -3.402823466e+38f ? -1.7976931348623157e308 : (double)v);
+}
+template <bool WIDE = false>
+NMX_DEV double nmx_norm_at(const float* S, int n_cols, int j, int k) {
+  const float v = S[(long long)k * n_cols + j];
+  return WIDE ? nmx_norm_wide(v) : (double)v;
+}
+template <bool WIDE = false>
 NMX_DEV double nmx_norm_median(const float* S, int n_cols, int j, int n) {
   if (n == 0) return NAN;
-  const double hi = (double)S[(long long)(n >> 1) * n_cols + j];
-  return (n & 1) ? hi : 0.5 * ((double)S[(long long)((n >> 1) - 1) * n_cols + j] + hi);
+  const double hi = nmx_norm_at<WIDE>(S, n_cols, j, n >> 1);
+  return (n & 1) ? hi : 0.5 * (nmx_norm_at<WIDE>(S, n_cols, j, (n >> 1) - 1) + hi);
+}
+
+// np.percentile(S, 100 q) of the sorted column (method "linear", NumPy's _lerp: a + (b - a) t, from the upper end
+// when t >= 0.5); n >= 1
+NMX_DEV double nmx_norm_quantile(const float* S, int n_cols, int j, int n, double q) {
+  const double vi = (double)(n - 1) * q;
+  if (vi >= (double)(n - 1)) return nmx_norm_at<true>(S, n_cols, j, n - 1);
+  if (vi < 0.0) return nmx_norm_at<true>(S, n_cols, j, 0);
+  const double fl = floor(vi);
+  const int lo = (int)fl;
+  const double t = vi - fl;
+  const double a = nmx_norm_at<true>(S, n_cols, j, lo), b = nmx_norm_at<true>(S, n_cols, j, lo + 1);
+  const double d = b - a;
+  return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+// i-th of the nq quantiles QuantileTransformer fits: references = linspace(0, 1, nq), percentile(references * 100)
+NMX_DEV double nmx_norm_ref(int i, int nq) { return (i < nq - 1) ? (double)i * (1.0 / (double)(nq - 1)) : 1.0; }
+NMX_DEV double nmx_norm_qt(const float* S, int n_cols, int j, int n, int i, int nq) {
+  if (nq == 1) return nmx_norm_at<true>(S, n_cols, j, 0);
+  return nmx_norm_quantile(S, n_cols, j, n, nmx_norm_ref(i, nq) * 100.0 / 100.0);
+}
+NMX_DEV double nmx_norm_sklearn(const NmxNormArgs& A, int j, int n, double x) {
+  const float* S = A.sorted;
+  const int nc = A.n_cols;
+  const double eps10 = 10.0 * 2.220446049250313e-16;
+  if (A.method == NMX_NORM_ROBUST) {
+    const double c = nmx_norm_median<true>(S, nc, j, n);
+    double sc = nmx_norm_quantile(S, nc, j, n, 0.75) - nmx_norm_quantile(S, nc, j, n, 0.25);
+    if (sc < eps10) sc = 1.0;
+    return (x - c) / sc;
+  }
+  if (A.method == NMX_NORM_MINMAX) {
+    const double lo = nmx_norm_at<true>(S, nc, j, 0), hi = nmx_norm_at<true>(S, nc, j, n - 1);
+    double rng = hi - lo;
+    if (rng < eps10) rng = 1.0;
+    const double sc = 1.0 / rng;
+    return x * sc + (0.0 - lo * sc);
+  }
+  // quantile: y = (interp(x, Q, R) - interp(-x, -Q[::-1], -R[::-1])) / 2; x == Q[0] -> 0, x == Q[-1] -> 1
+  if (x != x) return x;
+  const int nq = n < 300 ? n : 300;
+  const double q0 = nmx_norm_qt(S, nc, j, n, 0, nq), q1 = nmx_norm_qt(S, nc, j, n, nq - 1, nq);
+  if (x == q0) return 0.0;
+  if (x == q1) return 1.0;
+  if (x < q0) return 0.0;
+  if (x > q1) return 1.0;
+  // a: LAST index with Q[a] <= x (ascending interp);  b: FIRST index with Q[b] >= x (the reversed, negated one)
+  int lo = 0, hi = nq - 1;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nmx_norm_qt(S, nc, j, n, mid, nq) <= x) lo = mid; else hi = mid; }
+  const int a = lo;
+  lo = 0; hi = nq - 1;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nmx_norm_qt(S, nc, j, n, mid, nq) >= x) hi = mid; else lo = mid; }
+  const int b = hi;
+  double r1, r2;
+  {
+    const double xa = nmx_norm_qt(S, nc, j, n, a, nq), ra = nmx_norm_ref(a, nq);
+    if (xa == x) r1 = ra;
+    else {
+      const double xb = nmx_norm_qt(S, nc, j, n, a + 1, nq), rb = nmx_norm_ref(a + 1, nq);
+      r1 = (rb - ra) / (xb - xa) * (x - xa) + ra;
+    }
+  }
+  {   // xp = -Q[::-1], fp = -R[::-1], at -x: j' = nq - 1 - b
+    const double xb = nmx_norm_qt(S, nc, j, n, b, nq), rb = nmx_norm_ref(b, nq);
+    if (xb == x) r2 = -rb;
+    else {
+      const double xa = nmx_norm_qt(S, nc, j, n, b - 1, nq), ra = nmx_norm_ref(b - 1, nq);
+      r2 = ((-ra) - (-rb)) / ((-xa) - (-xb)) * ((-x) - (-xb)) + (-rb);
+    }
+  }
+  return 0.5 * (r1 - r2);
 }
 
 NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
@@ -118,11 +206,13 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     else if (h == h) ++ninf;
   }
   const bool med = A.method >= NMX_NORM_MEDIAN;
-  int ns = 0;   // entries of the sorted copy (== cnt)
+  const bool sk = A.method >= NMX_NORM_ROBUST;   // history = nan_to_num(history): EVERY row is in the sorted copy
+  int ns = 0;   // entries of the sorted copy (== cnt; sk: == len)
   if (med)
     for (long long q = A.seq0 - have; q < A.seq0; ++q) {
       const float h = A.ring[(q % cap) * A.n_cols + j];
-      if (h == h) nmx_norm_insert(A.sorted, A.n_cols, j, ns, h);
+      if (sk) nmx_norm_insert(A.sorted, A.n_cols, j, ns, nmx_clean(h));
+      else if (h == h) nmx_norm_insert(A.sorted, A.n_cols, j, ns, h);
     }
   bool pend = false;   // median methods: the value trimmed after the previous hop leaves the sorted copy
   float pend_val = 0.f;   //   together with the next insertion (nothing reads the copy in between)
@@ -134,10 +224,10 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       const float o = A.ring[((q - cap) % cap) * A.n_cols + j];
       if (o == o) {
         if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
-        if (med) {
-          if (pend) { nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val); pend = false; }
-          nmx_norm_remove(A.sorted, A.n_cols, j, ns, o);
-        }
+      }
+      if (med && (sk || o == o)) {
+        if (pend) { nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val); pend = false; }
+        nmx_norm_remove(A.sorted, A.n_cols, j, ns, sk ? nmx_clean(o) : o);
       }
       --len;
     }
@@ -145,15 +235,19 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     if (nmx_norm_finite(x)) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
     else if (x == x) ++ninf;
     if (med) {
-      if (x == x && pend) nmx_norm_replace(A.sorted, A.n_cols, j, ns, pend_val, x);
-      else if (x == x) nmx_norm_insert(A.sorted, A.n_cols, j, ns, x);
+      const bool in_s = sk || x == x;
+      const float xs = sk ? nmx_clean(x) : x;
+      if (in_s && pend) nmx_norm_replace(A.sorted, A.n_cols, j, ns, pend_val, xs);
+      else if (in_s) nmx_norm_insert(A.sorted, A.n_cols, j, ns, xs);
       else if (pend) nmx_norm_remove(A.sorted, A.n_cols, j, ns, pend_val);
       pend = false;
     }
     ++len;
     if (q > 0) {  // the first row ever is returned as it came
       double out;
-      if (cnt + ninf == 0 || (ninf > 0 && A.method != NMX_NORM_MEDIAN)) {
+      if (sk) {
+        out = nmx_norm_sklearn(A, j, ns, (double)x);
+      } else if (cnt + ninf == 0 || (ninf > 0 && A.method != NMX_NORM_MEDIAN)) {
         out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
       } else if (A.method == NMX_NORM_MEDIAN) {
         const double m = nmx_norm_median(A.sorted, A.n_cols, j, ns);
@@ -189,8 +283,8 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       const float o = A.ring[((q - (cap - 1)) % cap) * A.n_cols + j];
       if (o == o) {
         if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
-        if (med) { pend = true; pend_val = o; }
       }
+      if (med && (sk || o == o)) { pend = true; pend_val = sk ? nmx_clean(o) : o; }
       --len;
     }
   }

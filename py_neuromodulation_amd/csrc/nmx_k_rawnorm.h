@@ -19,6 +19,11 @@
 
 #define NMX_RAWNORM_MEAN 1
 #define NMX_RAWNORM_ZSCORE 2
+// order-statistic methods (nmx_rawnorm_order_item): the history of every channel is ALSO kept sorted
+#define NMX_RAWNORM_MEDIAN 3          // (x - nanmedian) / nanmedian            normalization.py:155-157
+#define NMX_RAWNORM_ZSCORE_MEDIAN 4   // (x - nanmedian) / nanstd               normalization.py:166-169
+#define NMX_RAWNORM_ROBUST 5          // sklearn RobustScaler  fitted on the history every hop (:57-70,172-186)
+#define NMX_RAWNORM_MINMAX 6          // sklearn MinMaxScaler
 
 struct NmxRawNormArgs {
   const float* x;            // windows: stream + starts, or materialised [n][C][W]
@@ -38,6 +43,12 @@ struct NmxRawNormArgs {
   int* len;                  // [C] current history length
   float* mean;               // [n_windows][C]
   float* scale;              // [n_windows][C]  1 / std or 1 / mean; 0 = pass-through
+  // order-statistic methods: the history sorted ascending, double-buffered [C][2][cap]; cur[c] = buffer in use;
+  // sorted_valid = 0: rebuild it from the ring first (fresh plan, reset, imported state)
+  float* sorted;
+  int* cur;
+  int sorted_valid;
+  int max_list;              // LDS list capacity: W + add (inserted / dropped values of one hop)
 };
 
 #ifdef NMX_HOST_EMU
@@ -113,6 +124,229 @@ NMX_DEV void nmx_rawnorm_stats_item(const NmxRawNormArgs& A, int c) {
     }
   }
   if (NMX_TID == 0) { A.count[c] = cnt; A.len[c] = len; }
+}
+
+// ---- order-statistic methods ---------------------------------------------------------------------------
+// One WORKGROUP per channel walks the hops of the batch in order.  Next to the ring (time order: which samples
+// leave) the history is kept SORTED in global memory; per hop ONE merge pass removes the samples that left after
+// the previous hop and inserts this hop's new ones:
+//   * the <= W + add inserted and dropped values are rank-sorted in LDS;
+//   * a thread per dropped value finds its position in the sorted history (binary search; equal values: the j-th
+//     of a run of equals takes the j-th slot of the run), a thread per new value its insertion point;
+//   * every element then moves to  i - #{dropped before i} + #{inserted before i}  (two binary searches in LDS).
+// The median / quartiles / extremes of the hop are reads of the merged array.  O(history) per hop -- the methods
+// are not on by default -- but every access is a coalesced stream and 256 channels run side by side.
+#define NMX_RAWNORM_ORDER_NT 1024
+NMX_DEV double nmx_rawnorm_block_sum_d(double v, double* red) {
+#ifdef NMX_HOST_EMU
+  (void)red;
+  return v;
+#else
+  red[NMX_TID] = v;
+  __syncthreads();
+  for (int o = NMX_NT >> 1; o > 0; o >>= 1) {
+    if (NMX_TID < o) red[NMX_TID] += red[NMX_TID + o];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+#endif
+}
+// sort v[0..n) ascending into o[0..n) by ranks (ties keep their order); n <= a few hundred after the first hop
+NMX_DEV void nmx_rawnorm_rank_sort(const float* v, float* o, int n) {
+  for (int i = NMX_TID; i < n; i += NMX_NT) {
+    const float x = v[i];
+    int r = 0;
+    for (int k = 0; k < n; ++k) r += (v[k] < x) || (v[k] == x && k < i);
+    o[r] = x;
+  }
+}
+NMX_DEV int nmx_rawnorm_lower(const float* S, int n, float x) {   // first index with S[i] >= x
+  int lo = 0, hi = n;
+  while (lo < hi) { const int m = (lo + hi) >> 1; if (S[m] < x) lo = m + 1; else hi = m; }
+  return lo;
+}
+NMX_DEV int nmx_rawnorm_upper(const float* S, int n, float x) {   // first index with S[i] > x
+  int lo = 0, hi = n;
+  while (lo < hi) { const int m = (lo + hi) >> 1; if (S[m] <= x) lo = m + 1; else hi = m; }
+  return lo;
+}
+NMX_DEV int nmx_rawnorm_count_lt(const int* P, int n, int i) {    // #{P[k] < i}, P ascending
+  int lo = 0, hi = n;
+  while (lo < hi) { const int m = (lo + hi) >> 1; if (P[m] < i) lo = m + 1; else hi = m; }
+  return lo;
+}
+NMX_DEV int nmx_rawnorm_count_le(const int* P, int n, int i) {    // #{P[k] <= i}
+  int lo = 0, hi = n;
+  while (lo < hi) { const int m = (lo + hi) >> 1; if (P[m] <= i) lo = m + 1; else hi = m; }
+  return lo;
+}
+// np.percentile (linear, NumPy's _lerp) of the sorted history
+NMX_DEV double nmx_rawnorm_quantile(const float* S, int n, double q) {
+  const double vi = (double)(n - 1) * q;
+  if (vi >= (double)(n - 1)) return (double)S[n - 1];
+  const double fl = floor(vi);
+  const int lo = (int)fl;
+  const double t = vi - fl, a = (double)S[lo], b = (double)S[lo + 1], d = b - a;
+  return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+
+NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem) {
+  float* ring = A.ring + (long long)c * A.cap;
+  float* Sbuf = A.sorted + (long long)c * 2 * A.cap;
+  const int ML = A.max_list;
+  float* in_raw = smem;              // [ML] this hop's new samples, time order
+  float* in_s = in_raw + ML;         // [ML] sorted
+  float* dr_raw = in_s + ML;         // [ML] samples that left after the previous hop
+  float* dr_s = dr_raw + ML;         // [ML] sorted
+  int* P = (int*)(dr_s + ML);        // [ML] positions of the dropped values in the sorted history
+  int* Q = P + ML;                   // [ML] insertion points of the new values
+  double* red = (double*)(Q + ML);   // [NT] reduction scratch (8-byte aligned: ML is a multiple of 2)
+  long long cnt = A.count[c];
+  int len = A.len[c];
+  int cur = A.cur[c];
+  float* S = Sbuf + (long long)cur * A.cap;
+  if (!A.sorted_valid) {   // rebuild: copy the kept history and sort it (bitonic, padded with +inf)
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    cur = 0;      // n2 < 2 len <= 2 cap: the padded sort runs over BOTH (contiguous) buffers, the result sits in buffer 0
+    S = Sbuf;
+    for (int i = NMX_TID; i < n2; i += NMX_NT) S[i] = i < len ? ring[(cnt - len + i) % A.cap] : INFINITY;
+    NMX_SYNC();
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        for (int i = NMX_TID; i < n2; i += NMX_NT) {
+          const int l = i ^ jj;
+          if (l > i) {
+            const float a = S[i], b = S[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { S[i] = b; S[l] = a; }
+          }
+        }
+        NMX_SYNC();
+      }
+  }
+  // sliding float64 sums for the standard deviation (zscore-median)
+  double s1 = 0.0, s2 = 0.0;
+  if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) {
+    for (int i = NMX_TID; i < len; i += NMX_NT) {
+      const double v = (double)ring[(cnt - len + i) % A.cap];
+      s1 += v; s2 += v * v;
+    }
+    s1 = nmx_rawnorm_block_sum_d(s1, red); s2 = nmx_rawnorm_block_sum_d(s2, red);
+  }
+  int n_sorted = len;   // entries of S
+  int n_drop = 0;       // pending removals (values in dr_raw)
+  for (int w = 0; w <= A.n_windows; ++w) {
+    const bool flush = w == A.n_windows;   // after the last hop: only the pending removals
+    const bool first = !flush && (A.hop0 + w) == 0;
+    const int n_new = flush ? 0 : (first ? A.W : A.add);
+    if (flush && n_drop == 0) break;
+    if (!flush) {
+      const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? A.starts[w] : 0ll);
+      const float* tail = src + (A.W - n_new);
+      double a1 = 0.0, a2 = 0.0;
+      for (int i = NMX_TID; i < n_new; i += NMX_NT) {
+        const float v = A.clean_on_load ? nmx_clean(tail[i]) : tail[i];
+        ring[(cnt + i) % A.cap] = v;
+        in_raw[i] = v;
+        a1 += (double)v; a2 += (double)v * (double)v;
+      }
+      if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) { s1 += nmx_rawnorm_block_sum_d(a1, red); s2 += nmx_rawnorm_block_sum_d(a2, red); }
+      cnt += n_new; len += n_new;
+    }
+    NMX_SYNC();
+    // ---- one merge pass: S - dropped + new -> S' -----------------------------------------------------------
+    nmx_rawnorm_rank_sort(in_raw, in_s, n_new);
+    nmx_rawnorm_rank_sort(dr_raw, dr_s, n_drop);
+    NMX_SYNC();
+    for (int j = NMX_TID; j < n_drop; j += NMX_NT) {
+      const float d = dr_s[j];
+      int t = 0;
+      while (j - t - 1 >= 0 && dr_s[j - t - 1] == d) ++t;   // the t-th of a run of equal dropped values
+      P[j] = nmx_rawnorm_lower(S, n_sorted, d) + t;
+    }
+    for (int j = NMX_TID; j < n_new; j += NMX_NT) Q[j] = nmx_rawnorm_upper(S, n_sorted, in_s[j]);
+    NMX_SYNC();
+    float* S2 = Sbuf + (long long)(1 - cur) * A.cap;
+    {   // a thread's indices only grow: #{P < i} and #{Q <= i} advance instead of being searched for; eight loads
+        // are in flight per thread (the walk is sequential over hops: memory latency is the whole cost)
+      int nd = 0, ni = 0;
+      for (int i0 = NMX_TID; i0 < n_sorted; i0 += 8 * NMX_NT) {
+        float v[8];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NMX_NT; v[u] = i < n_sorted ? S[i] : 0.f; }
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * NMX_NT;
+          if (i >= n_sorted) break;
+          while (nd < n_drop && P[nd] < i) ++nd;
+          while (ni < n_new && Q[ni] <= i) ++ni;
+          if (nd < n_drop && P[nd] == i) continue;   // this element leaves
+          S2[i - nd + ni] = v[u];
+        }
+      }
+    }
+    for (int j = NMX_TID; j < n_new; j += NMX_NT) S2[Q[j] - nmx_rawnorm_count_lt(P, n_drop, Q[j]) + j] = in_s[j];
+    NMX_SYNC();
+    n_sorted += n_new - n_drop;
+    cur = 1 - cur;
+    S = S2;
+    n_drop = 0;
+    if (flush) break;
+    // ---- statistics of the hop ------------------------------------------------------------------------------
+    if (NMX_TID == 0) {
+      float center = 0.f, scale = 0.f;
+      if (!first) {
+        const int n = n_sorted;
+        const double med = (n & 1) ? (double)S[n >> 1] : 0.5 * ((double)S[(n >> 1) - 1] + (double)S[n >> 1]);
+        if (A.method == NMX_RAWNORM_MEDIAN) {
+          center = (float)med; scale = (float)(1.0 / med);
+        } else if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) {
+          const double m = s1 / (double)len;
+          double var = s2 / (double)len - m * m;
+          if (var < 1e-9 * m * m) {   // cancellation (rare): two-pass over the sorted copy
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) { const double d = (double)S[i] - m; acc += d * d; }
+            var = acc / (double)n;
+          }
+          const double sd = var > 0.0 ? sqrt(var) : 0.0;
+          center = (float)med; scale = (float)(1.0 / (sd == 0.0 ? 1.0 : sd));
+        } else if (A.method == NMX_RAWNORM_ROBUST) {
+          double sc = nmx_rawnorm_quantile(S, n, 0.75) - nmx_rawnorm_quantile(S, n, 0.25);
+          if (sc < 10.0 * 2.220446049250313e-16) sc = 1.0;
+          center = (float)med; scale = (float)(1.0 / sc);
+        } else {   // minmax: x * s + (0 - lo * s) = (x - lo) * s up to rounding
+          double rng = (double)S[n - 1] - (double)S[0];
+          if (rng < 10.0 * 2.220446049250313e-16) rng = 1.0;
+          center = S[0]; scale = (float)(1.0 / rng);
+        }
+        if (scale == 0.f) scale = 1e-45f;   // (0 is the pass-through marker; a huge spread rounds to the smallest float)
+      }
+      A.mean[(long long)w * A.n_channels + c] = center;
+      A.scale[(long long)w * A.n_channels + c] = first ? 0.f : scale;
+    }
+    // ---- the history keeps its last N - 1 samples: they leave the sorted copy with the next merge ------------
+    const int drop = (!first && len > A.keep) ? len - A.keep : 0;
+    if (drop > 0) {
+      double d1 = 0.0, d2 = 0.0;
+      for (int i = NMX_TID; i < drop; i += NMX_NT) {
+        const float v = ring[(cnt - len + i) % A.cap];
+        dr_raw[i] = v;
+        d1 += (double)v; d2 += (double)v * (double)v;
+      }
+      if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) { s1 -= nmx_rawnorm_block_sum_d(d1, red); s2 -= nmx_rawnorm_block_sum_d(d2, red); }
+      len -= drop;
+      n_drop = drop;
+    }
+    NMX_SYNC();
+  }
+  if (NMX_TID == 0) { A.count[c] = cnt; A.len[c] = len; A.cur[c] = cur; }
 }
 
 // element i of window (w, c)

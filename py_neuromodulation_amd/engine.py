@@ -237,9 +237,15 @@ class HotPathEngine:
             d.resample_ratio = float(self.resample_ratio)
         if self._raw_norm is not None:              # raw_normalization, last pre-processor
             method, clip, n_hist, add = self._raw_norm
-            if method not in ("mean", "zscore"):
+            codes = {"mean": 1, "zscore": 2, "median": 3, "zscore-median": 4, "robust": 5, "minmax": 6}
+            if method == "quantile":
+                raise NotImplementedError(
+                    "raw_normalization method 'quantile': scikit-learn's QuantileTransformer draws a random subsample "
+                    "of histories longer than 10 000 samples (random_state=None), so the reference itself is not "
+                    "reproducible for raw data; not implemented")
+            if method not in codes:
                 raise NotImplementedError(f"raw_normalization method {method!r} has no device implementation")
-            d.raw_norm_method = {"mean": 1, "zscore": 2}[method]
+            d.raw_norm_method = codes[method]
             d.raw_norm_clip = float(clip) if clip else 0.0
             d.raw_norm_n, d.raw_norm_add = int(n_hist), int(add)
         d.n_pre_filters = len(self._pre_taps)       # preprocessing_filter stages, before the notch

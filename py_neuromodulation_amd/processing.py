@@ -3,13 +3,15 @@
   NotchFilter   filter/notch_filter.py:9-93     process(data[C, W]) -> data   (HIP FIR kernel)
   ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
   PreprocessingFilter processing/filter_preprocessing.py:44-94  chained single FIRs (HIP FIR kernel)
-  RawNormalizer processing/normalization.py:113-116  mean / zscore of the raw window against its history
+  RawNormalizer processing/normalization.py:113-116  mean / zscore / median / zscore-median / robust / minmax of the
+                raw window against its history
   Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
                                                 algorithm, parity unpinned); identity at ratio 1
-  FeatureNormalizer processing/normalization.py:31-111 -- host NumPy version (all methods incl.
-                the median / scikit-learn ones), one call per hop like the reference.
-  DeviceFeatureNormalizer  the same post-processing for the "mean" and "zscore" (default) methods as
-                a HIP scan over a whole batch of hops (libnmx nmx_norm_*, SURVEY 8f "next" #1).
+  FeatureNormalizer processing/normalization.py:31-111 -- host version, one call per hop like the reference;
+                DataProcessor uses it only for normalization_method "power" (scikit-learn's PowerTransformer).
+  DeviceFeatureNormalizer  the same post-processing for every other method (mean, median, zscore (default),
+                zscore-median, robust, minmax, quantile) as a HIP scan over a whole batch of hops
+                (libnmx nmx_norm_*, SURVEY 8f "next" #1).
 """
 
 from __future__ import annotations
@@ -98,17 +100,20 @@ class PreprocessingFilter:
 
 
 class RawNormalizer:
-    """processing/normalization.py:113-116 (Normalizer with type "raw") for the "mean" and "zscore"
-    methods on the device; stateful like the reference (one instance = one stream)."""
+    """processing/normalization.py:113-116 (Normalizer with type "raw") on the device for "mean", "zscore",
+    "median", "zscore-median" and the scikit-learn based "robust" / "minmax" (nmx_k_rawnorm.h: sliding sums, and
+    for the order statistics a sorted copy of the history merged once per hop); stateful like the reference
+    (one instance = one stream)."""
 
     def __init__(self, sfreq: float, settings, **kwargs) -> None:
         rs = settings.raw_normalization_settings
         self.sfreq = float(sfreq)
         self._spec = (rs.normalization_method, rs.clip, int(rs.normalization_time_s * sfreq),
                       int(sfreq / settings.sampling_rate_features_hz))
-        if rs.normalization_method not in ("mean", "zscore"):
+        if rs.normalization_method not in ("mean", "zscore", "median", "zscore-median", "robust", "minmax"):
             raise NotImplementedError(f"raw_normalization method {rs.normalization_method!r} has no device "
-                                      "implementation")
+                                      "implementation (quantile: the reference subsamples histories of more than "
+                                      "10 000 samples at random; power: Yeo-Johnson likelihood fit)")
         self._engine = None
 
     def process(self, data: np.ndarray) -> np.ndarray:
@@ -189,15 +194,19 @@ class FeatureNormalizer:
 
 
 class DeviceFeatureNormalizer:
-    """processing/normalization.py:31-111 for normalization_method in {"mean", "median", "zscore",
-    "zscore-median"} on the GPU (the scikit-learn based methods stay on the host: ``FeatureNormalizer``).
+    """processing/normalization.py:31-111 on the GPU for normalization_method in {"mean", "median", "zscore",
+    "zscore-median"} and the scikit-learn based "robust", "minmax" and "quantile" (RobustScaler / MinMaxScaler /
+    QuantileTransformer(n_quantiles=300) fitted on nan_to_num(history) every hop: restated in nmx_k_norm.h; histories
+    are at most N = normalization_time_s * sampling_rate_features_hz rows, far below QuantileTransformer's random
+    subsampling threshold of 10 000).  Only "power" (Yeo-Johnson, lambda by maximum likelihood inside
+    scipy.stats) has no device implementation: ``FeatureNormalizer`` calls scikit-learn for it like the reference.
 
     ``process(row)`` keeps the reference's call shape (one feature vector per hop);
     ``process_batch(rows)`` normalises ``rows[n_hops, n_features]`` with the same hop-by-hop
     semantics in one kernel launch (rows may also be a device pointer, see ``process_device``).
     """
 
-    METHODS = {"mean": 0, "zscore": 1, "median": 2, "zscore-median": 3}
+    METHODS = {"mean": 0, "zscore": 1, "median": 2, "zscore-median": 3, "robust": 4, "minmax": 5, "quantile": 6}
 
     def __init__(self, settings, n_features: int, colmask=None, device: int = 0, lib=None) -> None:
         import ctypes as C

@@ -121,6 +121,10 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int, size_
   for (int it = 0; it < n_items; ++it) nmx_resample_item(A, it / A.n_channels, it % A.n_channels, sm.data());
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t) {
+  if (A.method >= NMX_RAWNORM_MEDIAN) {
+    std::vector<float> sm(6 * (size_t)A.max_list + 2 * NMX_RAWNORM_ORDER_NT + 16);
+    for (int c = 0; c < A.n_channels; ++c) nmx_rawnorm_order_item(A, c, sm.data());
+  } else
   for (int c = 0; c < A.n_channels; ++c) nmx_rawnorm_stats_item(A, c);
   const long long n = (long long)A.n_windows * A.n_channels * A.W;
   for (long long i = 0; i < n; ++i) nmx_rawnorm_apply(A, i);

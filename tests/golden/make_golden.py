@@ -393,6 +393,49 @@ def case_raw_normalizer():
     print("raw_normalizer", {k: np.shape(v) for k, v in out.items() if k.endswith("_y")})
 
 
+def case_norm_methods():
+    """Every normalization_method the reference lists (processing/normalization.py:57-70) through its own
+    Normalizer, scikit-learn included: FeatureNormalizer over 160 hops x 9 columns (N = 50: trims, NaN cells, a
+    constant column, ties) and RawNormalizer over 14 windows of 3 channels (N = 700 samples)."""
+    rng = np.random.default_rng(99)
+    n, F = 160, 9
+    rows = rng.standard_normal((n, F)) * rng.uniform(0.05, 20, F) + rng.uniform(-30, 30, F)
+    rows[:, 2] = 1.25                                      # constant column
+    rows[:, 3] = np.round(rows[:, 3])                      # ties (repeated quantiles)
+    rows[rng.integers(0, n, 12), rng.integers(4, 7, 12)] = np.nan
+    rows[:, 7] = np.exp(rows[:, 7] / 20)                   # skewed, positive
+    out = {"rows": rows}
+    for method in nm.NMSettings.list_normalization_methods():
+        for clip in (3, 0):
+            s = nm.NMSettings.get_default()
+            s.sampling_rate_features_hz = 10
+            s.feature_normalization_settings.normalization_time_s = 5
+            s.feature_normalization_settings.normalization_method = method
+            s.feature_normalization_settings.clip = clip
+            fnorm = nm.processing.FeatureNormalizer(s)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out[f"feature_{method}_clip{clip}"] = np.stack([np.array(fnorm.process(r.copy())) for r in rows])
+    sfreq, C, T = 1000, 3, 2300
+    data = synth(C, T, sfreq, 43)
+    data[1] = np.round(data[1] / 5) * 5                    # coarse quantisation: many equal samples
+    out["raw_data"] = data
+    for method in nm.NMSettings.list_normalization_methods():
+        s = nm.NMSettings.get_default()
+        s.raw_normalization_settings.normalization_time_s = 0.7
+        s.raw_normalization_settings.normalization_method = method
+        s.raw_normalization_settings.clip = 3
+        s.preprocessing = ["raw_normalization"]
+        s = s.validate()
+        rn = nm.processing.RawNormalizer(sfreq, s)
+        gen = nm.stream.generator.RawDataGenerator(data, sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[f"raw_{method}"] = np.stack([np.array(rn.process(np.array(w, dtype=np.float64))) for _, w in gen])[:, :, ::4]
+    np.savez_compressed(HERE / "norm_methods.npz", **out)
+    print("norm_methods", sorted(k for k in out if k.startswith(("feature_", "raw_"))))
+
+
 def case_resample_quirk():
     """Recordings that are NOT sampled at raw_resampling_settings.resample_freq_hz (1000 Hz) under the default
     pre-processing: the reference resamples every window (processing/resample.py:42-60) but keeps building
@@ -477,6 +520,7 @@ if __name__ == "__main__":
     case_bandpower_kalman()
     case_preprocessing_filter()
     case_raw_normalizer()
+    case_norm_methods()
     case_schedule()
     case_feat_1k()
     case_feat_2k()

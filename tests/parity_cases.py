@@ -3,6 +3,7 @@ tests/test_gpu_parity.py (-m gpu, the real libnmx.so on the MI355X).  Each takes
 library binding; see tests/parity.py for the tolerance policy."""
 
 import numpy as np
+import pytest
 
 from tests import parity
 
@@ -430,8 +431,8 @@ def case_reference_property_tests(lib):
 
 
 def case_feature_normalizer_batches(lib):
-    """nmx_norm_* (batch scan) == the reference's hop-by-hop Normalizer for "zscore", "mean", "median" and
-    "zscore-median":
+    """nmx_norm_* (batch scan) == the reference's hop-by-hop Normalizer for "zscore", "mean", "median",
+    "zscore-median" and the scikit-learn based "robust", "minmax", "quantile" (fitted on nan_to_num(history)):
     history carried across batches and through export/import, N - 1 trimming, NaN-aware statistics,
     constant columns (std 0 -> 1), the untouched first row, clip, and the "psd" column mask.
     Tolerance: statistics are float64 on both sides, values are fp32 -> 1e-5 rel / 2e-6 abs."""
@@ -456,7 +457,9 @@ def case_feature_normalizer_batches(lib):
         return a
     mask = np.ones(F, dtype=np.uint8)
     mask[20:24] = 0
-    for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0), ("median", 3), ("zscore-median", 3), ("median", 0)):
+    rows[:, 15] = np.round(rows[:, 15])                # ties: repeated quantiles
+    for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0), ("median", 3), ("zscore-median", 3), ("median", 0),
+                         ("robust", 3), ("robust", 0), ("minmax", 3), ("quantile", 3), ("quantile", 0)):
         s = NMSettings.get_default()
         s.sampling_rate_features_hz = 10
         s.feature_normalization_settings.normalization_time_s = 5
@@ -766,6 +769,52 @@ def case_config5_30khz_512pt(lib):
                                        verifier=parity.Verifier(s, ch, sfreq, w))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def case_raw_normalizer_order_methods(lib):
+    """raw_normalization "median", "zscore-median" and the scikit-learn based "robust" / "minmax" vs the
+    REFERENCE golden norm_methods.npz (14 windows, 0.7 s history: trims of 401 then 100 samples, a coarsely quantised
+    channel with long runs of equal values): window by window through the drop-in class, and as two batches with the
+    state carried through export / import (the sorted copy is rebuilt from the imported ring).  fp32 samples
+    against float64 order statistics: 1e-5 relative + 2e-6 absolute."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.processing import RawNormalizer
+    from tests.helpers import load_golden
+
+    g = load_golden("norm_methods")
+    data, sfreq = g["raw_data"], 1000.0
+    C = data.shape[0]
+    for method in ("median", "zscore-median", "robust", "minmax"):
+        s = NMSettings.get_default()
+        s.raw_normalization_settings.normalization_time_s = 0.7
+        s.raw_normalization_settings.normalization_method = method
+        s.raw_normalization_settings.clip = 3
+        starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        want = g[f"raw_{method}"]
+        rn = RawNormalizer(sfreq, s)
+        mk = lambda feats=("return_raw",): HotPathEngine(NMSettings.get_default(), [f"c{i}" for i in range(C)], sfreq,   # noqa: E731
+                                                          features=list(feats), raw_norm=rn._spec, window=1000, lib=lib)
+        rn._engine = mk()
+        for i, (a, b) in enumerate(zip(starts, ends)):
+            y = rn.process(data[:, a:b])
+            np.testing.assert_allclose(y[:, ::4], want[i], rtol=1e-5, atol=2e-6, err_msg=f"{method} hop {i}")
+        rn._engine.close()
+        # batches + state: the normalised LAST sample of each window is the return_raw feature
+        e1 = mk()
+        got = [e1.process_batch(data, starts[:6])]
+        e2 = mk()
+        e2.import_state(e1.export_state())
+        got.append(e2.process_batch(data, starts[6:]))
+        got = np.concatenate(got)
+        ref = orc.RawNormalizer(sfreq, s)
+        last = np.stack([ref.process(data[:, a:b])[:, -1] for a, b in zip(starts, ends)])
+        np.testing.assert_allclose(got, last, rtol=1e-5, atol=2e-6, err_msg=f"{method} batched")
+        e1.close(); e2.close()
+    with pytest.raises(NotImplementedError, match="random subsample"):
+        s = NMSettings.get_default()
+        HotPathEngine(s, ["c0"], sfreq, features=["return_raw"], raw_norm=("quantile", 3, 700, 100), window=1000, lib=lib)
 
 
 def case_raw_normalizer(lib):

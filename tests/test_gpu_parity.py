@@ -389,6 +389,10 @@ def test_raw_normalizer(gpu_lib):
     pc.case_raw_normalizer(gpu_lib)
 
 
+def test_raw_normalizer_order_methods(gpu_lib):
+    pc.case_raw_normalizer_order_methods(gpu_lib)
+
+
 def test_psd_keys_skip_normalisation(gpu_lib):
     pc.case_psd_keys_skip_normalisation(gpu_lib)
 

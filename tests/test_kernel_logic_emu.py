@@ -106,6 +106,10 @@ def test_raw_normalizer(emu_lib):
     pc.case_raw_normalizer(emu_lib)
 
 
+def test_raw_normalizer_order_methods(emu_lib):
+    pc.case_raw_normalizer_order_methods(emu_lib)
+
+
 def test_psd_keys_skip_normalisation(emu_lib):
     pc.case_psd_keys_skip_normalisation(emu_lib)
 
