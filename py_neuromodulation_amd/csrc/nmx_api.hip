@@ -241,6 +241,7 @@ extern "C" int nmx_w64p_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t
 extern "C" int nmx_w64q_launch_notch_rd64(const NmxBankW64Args*, int, hipStream_t);
 extern "C" int nmx_w64x2_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64c_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
+extern "C" int nmx_w64d_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
 extern "C" int nmx_w64q_launch_notch_slp(const NmxBankW64Args*, int, hipStream_t);
@@ -270,7 +271,8 @@ static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, 
     if (!nmx_w64x2_launch_rd64(&A, n_items, n_cu, s)) g_be_rc = nmx_fail(NMX_E_INVALID, "M = 4096 FIR path: LDS budget");
     return 0;
   }
-  if (A.hc && nmx_w64c_launch_rd64(&A, n_items, n_cu, s)) return 0;   // M = 1536 channel-pair path: one kernel for every batch size
+  // channel-pair paths (M = 1536 / M = 1024): one kernel for every batch size
+  if (A.hc && (A.pair_m == 1024 ? nmx_w64d_launch_rd64(&A, n_items, n_cu, s) : nmx_w64c_launch_rd64(&A, n_items, n_cu, s))) return 0;
   if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
     const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)
                  : variant == 2 ? nmx_w64p_launch_rd64(&A, n_items, n_cu, s, sharp)

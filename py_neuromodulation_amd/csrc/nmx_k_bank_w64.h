@@ -75,6 +75,8 @@ struct NmxBankW64Args {
   const float* hc;        // M = 1536 channel-pair path (nmx_k_bank_w64c.h): [n_filters][12][64] pairs of the REAL spectrum in
                           // register order; twc = [24][64] complex pass-A twiddles, then [8][8] complex exp(-2 pi i a b / 64)
   const float* twc;
+  int pair_m;             // 1536 (nmx_k_bank_w64c.h) or 1024 (nmx_k_bank_w64d.h: hc = [n_filters][8][64] pairs in natural order,
+                          // twiddles = twl)
   const float* tw2;       // M = 4096 path (nmx_k_bank_w64x2.h): [1024] complex exp(-2 pi i k / 2048); Hs[f] then holds the
                           // INTERLEAVED (A_k, B_k) table of filter f, 2048 pairs
   // fused sharp-wave analysis (persistent kernel): list offsets inside the exchange tile (floats,

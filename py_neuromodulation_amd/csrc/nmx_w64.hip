@@ -11,6 +11,7 @@
 #include "nmx_k_bank_w64p.h"
 #include "nmx_k_bank_w64x2.h"
 #include "nmx_k_bank_w64c.h"
+#include "nmx_k_bank_w64d.h"
 
 #ifndef NMX_W64_NAME
 #error "define NMX_W64_NAME"
@@ -195,6 +196,57 @@ __global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64c_, NMX_W64_N
     const int cp = q / n_windows;
     nmx_bank_w64c_item(A, q - cp * n_windows, 2 * cp, Ln, tab);
   }
+}
+
+// M = 1024, one wave per (window, channel pair) (nmx_k_bank_w64d.h): LDS = real spectra of all filters, pass B / C
+// twiddles, one exchange tile per wave; the same contiguous runs of hops per wave
+template <int HALF>
+__global__ void __launch_bounds__(64 * (HALF ? 12 : 8)) NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)(const NmxBankW64Args A, int n_windows,
+                                                                                   int n_pairs, int chunk, int x_floats) {
+  float* tab = nmx_smem_w64;
+  const int hf = A.b.n_filters * NMX_W64D_H_FLOATS;
+  for (int i = threadIdx.x; i < hf; i += blockDim.x) tab[i] = A.hc[i];
+  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[hf + i] = A.twl[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  float* mine = tab + hf + NMX_W64_TWL_FLOATS + wave * x_floats;
+  const int q0 = (blockIdx.x * nw + wave) * chunk;
+  const int q1 = q0 + chunk < n_pairs ? q0 + chunk : n_pairs;
+#pragma nounroll
+  for (int q = q0; q < q1; ++q) {
+    const int cp = q / n_windows;
+    nmx_bank_w64d_item<HALF>(A, q - cp * n_windows, 2 * cp, mine, tab);
+  }
+}
+
+extern "C" int NMX_CAT(nmx_w64d_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int C = A->b.n_channels, n_windows = n_items / C, n_pairs = n_windows * ((C + 1) / 2);
+  const int x_floats = A->lds_floats;
+  const int fixed = A->b.n_filters * NMX_W64D_H_FLOATS + NMX_W64_TWL_FLOATS;
+  int nw = (160 * 1024 / 4 - fixed) / x_floats;
+  if (nw < 6) return 0;
+  static int want = 0;
+  if (!want) { const char* v = getenv("NMX_W64D_WAVES"); want = (v && atoi(v) >= 1 && atoi(v) <= 12) ? atoi(v) : 12; }
+  const int cap = A->b.W <= 512 ? want : (want < 8 ? want : 8);   // W <= 512: 114 VGPRs, three waves per SIMD fit
+  if (nw > cap) nw = cap;
+  if (n_pairs < 2048) nw = 2;
+  const size_t lds = (size_t)(fixed + nw * x_floats) * 4;
+  int grid = n_cu > 0 ? n_cu : 256;
+  if (grid * nw > n_pairs) grid = (n_pairs + nw - 1) / nw;
+  const int chunk = (n_pairs + grid * nw - 1) / (grid * nw);
+  if (A->b.W <= 512) {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk, x_floats);
+    NMX_KNAME("nmx_kern_bank_w64d_", "<1>");
+  } else {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk, x_floats);
+    NMX_KNAME("nmx_kern_bank_w64d_", "<0>");
+  }
+  return 1;
 }
 
 // returns 0 when the tables do not fit next to at least six tiles (caller falls back to the M = 2048 kernels)
