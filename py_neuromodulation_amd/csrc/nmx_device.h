@@ -375,10 +375,49 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
   for (int s = 0; s < p.nstages; ++s) {
     const int R = p.st[s].radix, m = p.st[s].m, ns = p.st[s].ns, tstep = p.st[s].tw_step;
     const unsigned magic = p.st[s].magic;
-    if (R > 5 && !(R10 && R == 10)) {
-      // generic prime radix, O(R^2): ONE OUTPUT per work item -- m R of them, so a 17-point stage of a 255-point
-      // transform (510-sample windows at 30 kHz) keeps 255 lanes busy instead of 15 -- inputs re-read from LDS
-      // (consecutive lanes read consecutive points), stage twiddle and butterfly root in ONE table lookup
+    if (R > 5 && !(R10 && R == 10) && (R & 1)) {
+      // generic odd (prime) radix.  Outputs h and R - h of a butterfly share everything but a sign:
+      //     y_h, y_{R-h} = x_0 + SA +- i SB,   SA = sum_n (x_n + x_{R-n}) cos(phi_n),  SB = sum_n (x_n - x_{R-n}) sin(phi_n),
+      //     phi_n = DIR 2 pi h n / R,  n = 1 .. (R - 1) / 2
+      // (real coefficients: 2 fused multiply-adds per term instead of a complex multiplication and an addition), and
+      // y_0 = x_0 + sum_n (x_n + x_{R-n}) falls out of the sums every work item forms anyway.  ONE WORK ITEM per
+      // (butterfly, h >= 1): m (R - 1) / 2 of them -- the 17-point stage of a 255-point transform (510-sample windows
+      // at 30 kHz) is 120 items for 128 threads, where one thread per butterfly kept 15 busy.  Inputs are re-read from
+      // LDS (consecutive lanes read consecutive points), roots from the table (L1 / L2).
+      const int pstep = p.n / R, Rh = (R - 1) >> 1;
+      for (int idx = NMX_TID; idx < m * Rh; idx += NMX_NT) {
+        const int hh = idx / m, j = idx - hh * m, h = hh + 1;
+        const int q = (ns == 1) ? j : (int)nmx_umulhi((unsigned)j, magic);
+        const int k = j - q * ns;
+        const int tb = k * tstep;
+        const float2 x0 = in[j];
+        float2 sa = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f), s0 = make_float2(0.f, 0.f);
+        int e = 0, rt = 0;   // (h n) mod R;  n tb (< p.n)
+        for (int n = 1; n <= Rh; ++n) {
+          e += h;
+          if (e >= R) e -= R;
+          rt += tb;
+          float2 xa = in[j + n * m], xb = in[j + (R - n) * m];
+          if (ns > 1) {   // stage twiddles w^(n tb) and w^((R - n) tb)
+            xa = nmx_cmul(xa, nmx_tw<DIR>(tw, rt));
+            int t2 = R * tb - rt;   // (R - n) tb < p.n
+            xb = nmx_cmul(xb, nmx_tw<DIR>(tw, t2));
+          }
+          const float2 a = nmx_cadd(xa, xb), b = nmx_csub(xa, xb);
+          const float2 r = tw[e * pstep];   // (cos, -sin) of 2 pi e / R
+          const float cs = r.x, sn = -(float)DIR * r.y;
+          s0 = nmx_cadd(s0, a);
+          sa.x += a.x * cs; sa.y += a.y * cs;
+          sb.x += b.x * sn; sb.y += b.y * sn;
+        }
+        const int o = q * ns * R + k;
+        const float2 base = nmx_cadd(x0, sa);
+        out[o + h * ns] = make_float2(base.x - sb.y, base.y + sb.x);          // x_0 + SA + i SB
+        out[o + (R - h) * ns] = make_float2(base.x + sb.y, base.y - sb.x);    // x_0 + SA - i SB
+        if (h == 1) out[o] = nmx_cadd(x0, s0);
+      }
+    } else if (R > 5 && !(R10 && R == 10)) {
+      // generic even composite radix left over by the plan builder (not produced today): one output per work item
       const int pstep = p.n / R;
       for (int idx = NMX_TID; idx < m * R; idx += NMX_NT) {
         const int qq = idx / m, j = idx - qq * m;
@@ -386,7 +425,7 @@ NMX_DEV float2* nmx_fft(const NmxFft& p, const float2* in0, float2* a, float2* b
         const int k = j - q * ns;
         const int tb = k * tstep;
         float2 acc = in[j];
-        int e = 0, rt = 0;   // (qq * r) mod R;  r * tb  (< n)
+        int e = 0, rt = 0;
         for (int r = 1; r < R; ++r) {
           e += qq;
           if (e >= R) e -= R;
