@@ -156,6 +156,7 @@ struct NmxTimeOscArgs {
   // LDS carve (float offsets)
   int off_x, off_a, off_b, off_spec, off_red, lds_floats;
   const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h), else NULL
+  const unsigned short* w510_tab;   // 510-sample transforms: position tables of the prime-factor wave kernel (nmx_k_timeosc_w510.h)
 };
 
 #define NMXD_F_HJORTH (1u << 0)
