@@ -135,6 +135,43 @@ NMX_DEV void nmx_pfa510_phase17(float2* bufA, float2* bufB, bool two, const unsi
   for (int c = 0; c < 17; ++c) buf[pos[c]] = x[c];
 }
 
+// short STFT segments: one segment per lane and round, NBK bins (k_lo + b0 ...) from one pass over its windowed samples
+template <int NB, int NBK>
+NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2* rootsL, const float* winL, int W, int nb,
+                                 int b0, int lane, NmxBandAcc<NB>& acc_s) {
+  const int N = OS.n, h = OS.half;
+  for (int sgi = lane; sgi < OS.nseg; sgi += 64) {
+    const int s0 = sgi * OS.step;
+    float re[NBK], im[NBK];
+    int m[NBK];
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) { re[b] = 0.f; im[b] = 0.f; m[b] = 0; }
+    for (int i = 0; i < N; ++i) {
+      const int e = s0 + i;
+      float v;
+      if (e < h) v = xs[h - e];
+      else if (e < h + W) v = xs[e - h];
+      else if (e < 2 * h + W) v = xs[W - 2 - (e - h - W)];
+      else v = 0.f;
+      v *= winL[i];
+#pragma unroll
+      for (int b = 0; b < NBK; ++b) {
+        const float2 r = rootsL[m[b]];
+        re[b] += v * r.x;
+        im[b] += v * r.y;
+        m[b] += OS.k_lo + b0 + b;
+        if (m[b] >= N) m[b] -= N;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+      float v = sqrtf(re[b] * re[b] + im[b] * im[b]) * OS.scale;
+      if (OS.log_transform) v = log10f(v);
+      acc_s.add(OS, nb, OS.k_lo + b0 + b, v);
+    }
+  }
+}
+
 template <int NB>
 NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short* tab, int w, int c, float* smem) {
   w = nmx_uniform_i(w);
@@ -226,36 +263,32 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
     NMX_WAVE_FENCE();
   }
   if (A.stft.enabled && !stft_long) {
-    // short segments (17 samples at 30 kHz: dozens of segments per window): one (segment, bin) pair per lane and round,
-    // direct N-term DFT with the roots exp(-2 pi i m / N) from the plan's table (the generic kernel evaluated a
-    // sincospi per term)
+    // short segments (17 samples at 30 kHz: dozens of segments per window): ONE SEGMENT per lane and round, all its
+    // bins (up to eight at a time) from one pass over the windowed samples; the roots exp(-2 pi i m / N) and the
+    // window sit in LDS (the generic kernel evaluated a sincospi per term and (segment, bin) pair)
     const int N = OS.n, nbins = OS.k_hi - OS.k_lo;
-    const float2* roots = OS.fft.tw;   // [N] when the segment length is odd (full-length plan), [N / 2] of the HALF length otherwise
-    const bool full = OS.complex_full != 0;
-    for (int idx = lane; idx < OS.nseg * nbins; idx += 64) {
-      const int sgi = idx / nbins, k = OS.k_lo + (idx - sgi * nbins);
-      const int s0 = sgi * OS.step;
-      float re = 0.f, im = 0.f;
-      int m = 0;   // (k i) mod N
-      for (int i = 0; i < N; ++i) {
-        const int e = s0 + i;
-        float v;
-        if (e < h) v = xs[h - e];
-        else if (e < h + W) v = xs[e - h];
-        else if (e < 2 * h + W) v = xs[W - 2 - (e - h - W)];
-        else v = 0.f;
-        v *= OS.win[i];
-        float cs, sn;
-        if (full) { const float2 r = roots[m]; cs = r.x; sn = r.y; }
-        else sincospif(-2.f * (float)m / (float)N, &sn, &cs);
-        re += v * cs;
-        im += v * sn;
-        m += k;
-        if (m >= N) m -= N;
+    float2* rootsL = bufB;                 // [N]
+    float* winL = (float*)(bufB + 64);     // [N]
+    NMX_WAVE_FENCE();
+    if (lane < N) {
+      float sn, cs;
+      sincospif(-2.f * (float)lane / (float)N, &sn, &cs);
+      rootsL[lane] = OS.complex_full ? OS.fft.tw[lane] : make_float2(cs, sn);   // (odd N: the plan's exactly rounded table)
+      winL[lane] = OS.win[lane];
+    }
+    NMX_WAVE_FENCE();
+    for (int b0 = 0; b0 < nbins; b0 += 8) {
+      const int nbk = nbins - b0 < 8 ? nbins - b0 : 8;
+      switch (nbk) {   // compile-time bin count: no per-term predicates
+        case 1: nmx_w510_short_stft<NB, 1>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 2: nmx_w510_short_stft<NB, 2>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 3: nmx_w510_short_stft<NB, 3>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 4: nmx_w510_short_stft<NB, 4>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 5: nmx_w510_short_stft<NB, 5>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 6: nmx_w510_short_stft<NB, 6>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        case 7: nmx_w510_short_stft<NB, 7>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
+        default: nmx_w510_short_stft<NB, 8>(OS, xs, rootsL, winL, W, nb, b0, lane, acc_s); break;
       }
-      float v = sqrtf(re * re + im * im) * OS.scale;
-      if (OS.log_transform) v = log10f(v);
-      acc_s.add(OS, nb, k, v);
     }
   }
   if (A.fft.enabled) acc_f.emit(A.fft, nb, 1, out_row, c, lane);

@@ -97,10 +97,6 @@ __global__ void __launch_bounds__(64) nmx_kern_timeosc_w510(const NmxTimeOscArgs
   nmx_timeosc_w510_item<NB>(A, A.w510_tab, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
 }
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
-  if (getenv("NMX_DEBUG_W510"))
-    fprintf(stderr, "w510? tab=%p W=%d nb=%d welch=%d fft(en=%d n=%d klo=%d khi=%d cf=%d est=%u rs=%d) stft(en=%d n=%d step=%d half=%d nseg=%d klo=%d khi=%d cf=%d est=%u rs=%d)\n",
-            (const void*)A->w510_tab, A->W, A->n_bands, A->welch.enabled, A->fft.enabled, A->fft.n, A->fft.k_lo, A->fft.k_hi, A->fft.complex_full, A->fft.estimators, A->fft.return_spectrum,
-            A->stft.enabled, A->stft.n, A->stft.step, A->stft.half, A->stft.nseg, A->stft.k_lo, A->stft.k_hi, A->stft.complex_full, A->stft.estimators, A->stft.return_spectrum);
   if (!nmx_timeosc_w510_ok(*A, A->w510_tab)) return 0;
   if (A->n_bands <= 4) {
     hipLaunchKernelGGL(nmx_kern_timeosc_w510<4>, dim3(n_items), dim3(64), (size_t)NMX_TO510_LDS_FLOATS * 4, s, *A);
