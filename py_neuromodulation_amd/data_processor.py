@@ -183,7 +183,7 @@ class DataProcessor:
                 # inside the engine's launch sequence: rows come back normalised (no second round trip)
                 self.engine.attach_normalizer(self.device_normalizer)
                 self._norm_in_engine = True
-            else:  # median / scikit-learn methods: host NumPy, hop by hop like the reference
+            elif not dry_run:   # "power": no device implementation and no host fall-back (raises, naming the setting)
                 self.feature_normalizer = FeatureNormalizer(st)
         # NaN policy: columns whose key contains the channel's new_name (substring, as the reference);
         # built on first use per channel (256 channels x 8 000 keys of substring tests cost 50 ms up front,

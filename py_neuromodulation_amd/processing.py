@@ -7,8 +7,8 @@
                 raw window against its history
   Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
                                                 algorithm, parity unpinned); identity at ratio 1
-  FeatureNormalizer processing/normalization.py:31-111 -- host version, one call per hop like the reference;
-                DataProcessor uses it only for normalization_method "power" (scikit-learn's PowerTransformer).
+  FeatureNormalizer processing/normalization.py:119-122 -- the reference's one-vector call shape over the device
+                normaliser below ("power", scikit-learn's PowerTransformer, is not implemented: no host path).
   DeviceFeatureNormalizer  the same post-processing for every other method (mean, median, zscore (default),
                 zscore-median, robust, minmax, quantile) as a HIP scan over a whole batch of hops
                 (libnmx nmx_norm_*, SURVEY 8f "next" #1).
@@ -145,52 +145,26 @@ class Resampler:
 
 
 class FeatureNormalizer:
-    """processing/normalization.py:31-111 for the NumPy methods and the sklearn ones."""
+    """processing/normalization.py:119-122, the reference's call shape (one feature vector per call) ON THE DEVICE:
+    a ``DeviceFeatureNormalizer`` created at the first call, when the vector length is known.  There is no host
+    implementation: "power" (scikit-learn's PowerTransformer: Yeo-Johnson with a likelihood fit inside scipy.stats)
+    raises ``NotImplementedError``."""
 
     def __init__(self, settings) -> None:
-        s = settings.feature_normalization_settings
-        self.method = s.normalization_method
-        self.clip = s.clip
-        self.num_samples_normalize = int(s.normalization_time_s * settings.sampling_rate_features_hz)
-        self.previous = np.empty((0, 0))
-        self._sk = None
-        if self.method in ("quantile", "power", "robust", "minmax"):
-            import sklearn.preprocessing as skpp
-
-            self._sk = {"quantile": lambda: skpp.QuantileTransformer(n_quantiles=300),
-                        "robust": skpp.RobustScaler, "minmax": skpp.MinMaxScaler,
-                        "power": skpp.PowerTransformer}[self.method]()
+        method = settings.feature_normalization_settings.normalization_method
+        if method not in DeviceFeatureNormalizer.METHODS:
+            raise NotImplementedError(
+                f"feature normalization_method {method!r} has no device implementation (available: "
+                f"{', '.join(DeviceFeatureNormalizer.METHODS)}); 'power' is scikit-learn's PowerTransformer, whose "
+                "Yeo-Johnson likelihood fit is not restated")
+        self._settings = settings
+        self._dev = None
 
     def process(self, data: np.ndarray) -> np.ndarray:
-        if self.previous.size == 0:
-            self.previous = data
-            return data
-        self.previous = np.vstack((self.previous, data))
-        prev = self.previous
-        with np.errstate(divide="ignore", invalid="ignore"):
-            if self._sk is not None:
-                out = self._sk.fit(np.nan_to_num(prev)).transform(data[None]).squeeze()
-            else:
-                has_nan = bool(np.any(np.isnan(prev.sum(axis=0))))
-                mean = (np.nanmean if has_nan else np.mean)(prev, axis=0)
-                if self.method == "mean":
-                    out = (data - mean) / mean
-                elif self.method == "median":
-                    med = (np.nanmedian if has_nan else np.median)(prev, axis=0)
-                    out = (data - med) / med
-                else:
-                    std = (np.nanstd if has_nan else np.std)(prev, axis=0)
-                    std[std == 0] = 1
-                    if self.method == "zscore":
-                        out = (data - mean) / std
-                    elif self.method == "zscore-median":
-                        out = (data - (np.nanmedian if has_nan else np.median)(prev, axis=0)) / std
-                    else:
-                        raise ValueError(f"unknown normalization_method {self.method}")
-        if self.clip:
-            out = out.clip(min=-self.clip, max=self.clip)
-        self.previous = self.previous[-self.num_samples_normalize + 1:]
-        return np.nan_to_num(out)
+        data = np.asarray(data)
+        if self._dev is None:
+            self._dev = DeviceFeatureNormalizer(self._settings, int(data.shape[-1]))
+        return self._dev.process(data)
 
 
 class DeviceFeatureNormalizer:
@@ -199,7 +173,7 @@ class DeviceFeatureNormalizer:
     QuantileTransformer(n_quantiles=300) fitted on nan_to_num(history) every hop: restated in nmx_k_norm.h; histories
     are at most N = normalization_time_s * sampling_rate_features_hz rows, far below QuantileTransformer's random
     subsampling threshold of 10 000).  Only "power" (Yeo-Johnson, lambda by maximum likelihood inside
-    scipy.stats) has no device implementation: ``FeatureNormalizer`` calls scikit-learn for it like the reference.
+    scipy.stats) has no device implementation and raises ``NotImplementedError``.
 
     ``process(row)`` keeps the reference's call shape (one feature vector per hop);
     ``process_batch(rows)`` normalises ``rows[n_hops, n_features]`` with the same hop-by-hop

@@ -75,6 +75,26 @@ def test_product_loader_has_no_cpu_fallback(tmp_path):
         NmxLibrary(tmp_path / "missing_libnmx.so")
 
 
+def test_product_package_has_no_host_compute_path():
+    """The package neither imports the oracle nor scikit-learn / scipy.signal for a compute fall-back: every
+    normalisation method is either a device kernel or a NotImplementedError that names the setting."""
+    import re
+    from pathlib import Path
+
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.processing import DeviceFeatureNormalizer, FeatureNormalizer
+
+    pkg = Path(__file__).resolve().parents[1] / "py_neuromodulation_amd"
+    for f in pkg.glob("*.py"):
+        src = f.read_text()
+        assert not re.search(r"^\s*(import|from)\s+(sklearn|oracle)", src, re.M), f.name
+    assert set(DeviceFeatureNormalizer.METHODS) == {"mean", "median", "zscore", "zscore-median", "robust", "minmax", "quantile"}
+    s = NMSettings.get_default()
+    s.feature_normalization_settings.normalization_method = "power"
+    with pytest.raises(NotImplementedError, match="power"):
+        FeatureNormalizer(s)
+
+
 def test_abi_from_plain_c(tmp_path):
     """include/nmx.h is valid C and the library links and runs from a C program."""
     import subprocess
