@@ -127,8 +127,8 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
         const float2 X = k == 0 ? make_float2(R.sum, 0.f) : xbin(k);
-        float v = sqrtf(X.x * X.x + X.y * X.y);
-        if (O.log_transform) v = log10f(v);
+        const float pw = X.x * X.x + X.y * X.y;
+        const float v = O.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
       }
       acc.emit(O, nb, 1, out_row, c, lane);
@@ -141,7 +141,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
         const float yr = 0.5f * X0.x - 0.25f * (Xm.x + Xp.x), yi = 0.5f * X0.y - 0.25f * (Xm.y + Xp.y);
         float p = (yr * yr + yi * yi) * O.scale;
         if (!(k == 0 || k == 500)) p *= 2.f;
-        if (O.log_transform) p = log10f(p);
+        if (O.log_transform) p = nmx_log10_fast(p);
         acc.add(O, nb, k, p);
       }
       acc.emit(O, nb, 1, out_row, c, lane);
@@ -156,6 +156,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
 #pragma unroll
     for (int q = 0; q < 8; ++q) hw[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, 4 * lane + 256 * q, 0, 0));
     acc.clear();
+    const float lscale = O.log_transform ? log10f(O.scale) : 0.f;   // log10(|X| scale) = log10(|X|^2) / 2 + log10(scale)
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
@@ -177,12 +178,12 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
         // A = (zk + conj zn) / 2,  B = -i (zk - conj zn) / 2
         const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
         const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
-        float va = sqrtf(ax * ax + ay * ay) * O.scale;
-        if (O.log_transform) va = log10f(va);
+        const float pa = ax * ax + ay * ay;
+        const float va = O.log_transform ? 0.5f * nmx_log10_fast(pa) + lscale : sqrtf(pa) * O.scale;
         acc.add(O, nb, k, va);
         if (pr < 2) {
-          float vb = sqrtf(bx * bx + by * by) * O.scale;
-          if (O.log_transform) vb = log10f(vb);
+          const float pb = bx * bx + by * by;
+          const float vb = O.log_transform ? 0.5f * nmx_log10_fast(pb) + lscale : sqrtf(pb) * O.scale;
           acc.add(O, nb, k, vb);
         }
       }

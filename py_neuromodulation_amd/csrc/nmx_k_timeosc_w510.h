@@ -140,6 +140,7 @@ template <int NB, int NBK>
 NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2* rootsL, const float* winL, int W, int nb,
                                  int b0, int lane, NmxBandAcc<NB>& acc_s) {
   const int N = OS.n, h = OS.half;
+  const float lscale = OS.log_transform ? log10f(OS.scale) : 0.f;
   for (int sgi = lane; sgi < OS.nseg; sgi += 64) {
     const int s0 = sgi * OS.step;
     float re[NBK], im[NBK];
@@ -165,8 +166,8 @@ NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2
     }
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
-      float v = sqrtf(re[b] * re[b] + im[b] * im[b]) * OS.scale;
-      if (OS.log_transform) v = log10f(v);
+      const float pw = re[b] * re[b] + im[b] * im[b];
+      const float v = OS.log_transform ? 0.5f * nmx_log10_fast(pw) + lscale : sqrtf(pw) * OS.scale;
       acc_s.add(OS, nb, OS.k_lo + b0 + b, v);
     }
   }
@@ -224,16 +225,12 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
         const int q = s ? qb : qa;
         if (q < 0) continue;
         const float re = s ? bx : ax, im = s ? by : ay;
-        float v = sqrtf(re * re + im * im);
+        const float pw = re * re + im * im;
         if (q < n_fft) {
-          if (k >= A.fft.k_lo && k < A.fft.k_hi) {
-            if (A.fft.log_transform) v = log10f(v);
-            acc_f.add(A.fft, nb, k, v);
-          }
+          if (k >= A.fft.k_lo && k < A.fft.k_hi)
+            acc_f.add(A.fft, nb, k, A.fft.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw));
         } else if (k >= OS.k_lo && k < OS.k_hi) {
-          v *= OS.scale;
-          if (OS.log_transform) v = log10f(v);
-          acc_s.add(OS, nb, k, v);
+          acc_s.add(OS, nb, k, OS.log_transform ? 0.5f * nmx_log10_fast(pw) + log10f(OS.scale) : sqrtf(pw) * OS.scale);
         }
       }
     }
