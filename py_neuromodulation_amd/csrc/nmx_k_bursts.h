@@ -364,7 +364,7 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
 #define NMX_THRW_I 256
 // + K / 64 + 2 block counters (launcher)
 // NR = registers per lane holding a hop's new samples: 2 (overlap <= 128) or 4 (overlap <= 256: 2 kHz at 10 Hz)
-#define NMX_THRW_LDS_FLOATS_NR(NR) (2 * 256 * (NR) + 3 * NMX_THR_P + NMX_THRW_I + NMX_THRW_PF * 64 * (NR))
+#define NMX_THRW_LDS_FLOATS_NR(NR) (2 * 256 * (NR) + 3 * ((NR) == 2 ? NMX_THR_P : 512) + NMX_THRW_I + ((NR) == 2 ? NMX_THRW_PF : 4) * 64 * (NR))
 #define NMX_THRW_LDS_FLOATS NMX_THRW_LDS_FLOATS_NR(2)
 
 // number of entries of the DESCENDING list l[0..n) that are > v
@@ -400,18 +400,21 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
   // fringe capacity scales with the samples a hop brings: a stationary signal accepts ~(1 - q) of them, each
   // evicts one fringe entry, and a flush (sort + stream of the whole top-K list) is due when the fringe runs low
   constexpr int TF = 256 * NR, TREFILL = 192 * NR;
+  // NR = 4 (2 kHz hops, thousands of series): a shorter pending list and a shorter prefetch group bring the wave to
+  // 20 KB of LDS -- eight walks per CU, one round for 2048 series instead of two
+  constexpr int TP = NR == 2 ? NMX_THR_P : 512, PF = NR == 2 ? NMX_THRW_PF : 4;
 #ifdef NMX_THRW_PROFILE
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
   int n_ins = 0, n_flush = 0;
 #endif
   float* F = smem;                          // [TF] ascending fringe: entries F[fh .. fh + nF)
   float* F2 = F + TF;
-  float* Pp = F2 + TF;               // [NMX_THR_P] pending, unsorted
-  float* ps = Pp + NMX_THR_P;               // [NMX_THR_P] pending, sorted descending (flush)
-  int* ins = (int*)(ps + NMX_THR_P);        // [NMX_THR_P] insertion indices (flush)
-  float* I = (float*)(ins + NMX_THR_P);     // [NMX_THRW_I] this hop's fringe inserts
-  float* stage = I + NMX_THRW_I;            // [NMX_THRW_PF][64 NR] new samples of the current group of hops
-  int* cb = (int*)(stage + NMX_THRW_PF * 64 * NR);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
+  float* Pp = F2 + TF;               // [TP] pending, unsorted
+  float* ps = Pp + TP;               // [TP] pending, sorted descending (flush)
+  int* ins = (int*)(ps + TP);        // [TP] insertion indices (flush)
+  float* I = (float*)(ins + TP);     // [NMX_THRW_I] this hop's fringe inserts
+  float* stage = I + NMX_THRW_I;            // [PF][64 NR] new samples of the current group of hops
+  int* cb = (int*)(stage + PF * 64 * NR);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
   const int K = A.K, W = A.W, ov = A.overlap;
   const long long sidx = (long long)c * A.n_bands + bi;
   float* L = A.top + sidx * K;              // descending top-K list (global, L2 resident)
@@ -432,25 +435,25 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
 
   const long long hop_stride = (long long)A.n_channels * A.n_bands * W;
   const float* e0 = A.env + ((long long)c * A.n_bands + bi) * W + (W - ov);
-  float nx[NR][NMX_THRW_PF];   // samples of the next NMX_THRW_PF hops, register q of a lane = sample lane + 64 q
+  float nx[NR][PF];   // samples of the next PF hops, register q of a lane = sample lane + 64 q
 #pragma unroll
-  for (int u = 0; u < NMX_THRW_PF; ++u) {
+  for (int u = 0; u < PF; ++u) {
     const float* e = e0 + (long long)u * hop_stride;
     const bool in = u < A.n_windows;
 #pragma unroll
     for (int q = 0; q < NR; ++q) nx[q][u] = (in && lane + 64 * q < ov) ? e[lane + 64 * q] : -INFINITY;
   }
-  for (int w0 = 0; w0 < A.n_windows; w0 += NMX_THRW_PF) {
+  for (int w0 = 0; w0 < A.n_windows; w0 += PF) {
     // the group's samples go to LDS so that the hop loop below stays ROLLED (one copy of the insert and
     // flush code)
 #pragma unroll
-    for (int u = 0; u < NMX_THRW_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
 #pragma unroll
       for (int q = 0; q < NR; ++q) stage[64 * NR * u + 64 * q + lane] = nx[q][u];
     }
 #pragma unroll
-    for (int u = 0; u < NMX_THRW_PF; ++u) {   // in flight while this group of hops is processed
-      const int w = w0 + NMX_THRW_PF + u;
+    for (int u = 0; u < PF; ++u) {   // in flight while this group of hops is processed
+      const int w = w0 + PF + u;
       const float* e = e0 + (long long)w * hop_stride;
       const bool in = w < A.n_windows;
 #pragma unroll
@@ -458,7 +461,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
     }
     NMX_WAVE_FENCE();
     NMX_TP(0)   // group top: wait for the prefetched samples, stage them, issue the next loads
-    const int ng = (A.n_windows - w0) < NMX_THRW_PF ? (A.n_windows - w0) : NMX_THRW_PF;
+    const int ng = (A.n_windows - w0) < PF ? (A.n_windows - w0) : PF;
 #pragma nounroll
     for (int u = 0; u < ng; ++u) {
       const int w = w0 + u;
@@ -578,7 +581,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
       nwin += 1;
       if (lane == 0) A.thr[((long long)w * A.n_channels + c) * A.n_bands + bi] = thr_cur;
       // flush when the fringe could run dry or the pending list could overflow on the next hop
-      if (nF < ov + 8 || nP + ov > NMX_THR_P || w + 1 == A.n_windows) {
+      if (nF < ov + 8 || nP + ov > TP || w + 1 == A.n_windows) {
         NMX_TP(3)   // threshold store + bookkeeping
         // (1) pending -> ps, sorted descending (rank by counting; equal values: lower index first)
         const int n4 = (nP + 3) & ~3;
