@@ -619,6 +619,45 @@ def test_persistent_bank_equals_one_window_kernel_other_lengths(gpu_lib, W):
     eng.close()
 
 
+@pytest.mark.parametrize("sfreq,kernel", [(500.0, "w64d_rd64<1>"), (600.0, "w64d_rd64<0>"), (750.0, "w64c")])
+def test_channel_pair_bank_other_rates(gpu_lib, sfreq, kernel):
+    """One-second windows at 500 / 600 / 750 Hz: the band-pass taps (sfreq - 1 long) need M >= 1.5 W -- 749 and 899
+    fit the 1024-point channel-pair kernel (windows <= 512: only half of the inverse outputs are formed; > 512: all
+    of them), 1124 the 1536-point one.  An odd channel count, batch == window by window bit for bit, two hops against
+    the float64 oracle."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.bandpass_filter = True
+    s = s.validate()
+    W, hop = int(sfreq), int(sfreq / 10)
+    C, n_hops = 33, 40
+    T = W + (n_hops - 1) * hop
+    rng = np.random.default_rng(int(sfreq))
+    t = np.arange(T) / sfreq
+    x = (rng.standard_normal((C, T)) * 40 + 12 * np.sin(2 * np.pi * 18 * t) + rng.uniform(-200, 200, (C, 1))).astype(np.float32)
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * hop
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    got = eng.process_batch(x, starts)
+    assert kernel in eng.kernels(3), eng.kernels(3)
+    for i in (0, 17, 39):
+        one = eng.process_window(x[:, starts[i]:starts[i] + W].astype(np.float64))
+        np.testing.assert_array_equal(one, got[i])
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in eng.enabled]
+    for i in (5, 30):
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(x[:, starts[i]:starts[i] + W].astype(np.float64)))
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], [want[k] for k in eng.keys], s, sfreq, 200.0, W,
+                                       verifier=parity.Verifier(s, ch, sfreq, x[:, starts[i]:starts[i] + W].astype(np.float64)))
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
+
+
 def test_stream_output_files(gpu_lib, tmp_path):
     pc.case_stream_output_files(gpu_lib, tmp_path)
 
