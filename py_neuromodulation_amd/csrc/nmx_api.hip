@@ -213,6 +213,7 @@ static void be_init_once() {
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
+extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   static int scan_ok = -1;
@@ -224,6 +225,7 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
   }
   // default shape (W = 1000, band means): one wave per item, wave-level 500-point transforms
   if (A.w500_tab && nmx_wave_launch_timeosc_w1000(&A, n_items, s)) return;
+  if (A.w500_tab && nmx_wave_launch_timeosc_stft500(&A, n_items, s)) return;
   // 510-sample FFT / STFT segments (17 ms at 30 kHz): one wave per item, in-place prime-factor transforms
   if (A.w510_tab && nmx_wave_launch_timeosc_w510(&A, n_items, s)) return;
   static int fixed_ok = -1;

@@ -192,4 +192,80 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
     acc.emit(O, nb, 5, out_row, c, lane);
   }
 }
+
+// ---- STFT with 500-sample segments on windows of OTHER lengths (BASELINE config 3: 2000-sample windows at 2 kHz, nine
+// segments -- the reference takes windowlength_ms as a sample count, features/oscillatory.py:199-213), one wave per
+// (window, channel): the window in LDS, two real segments per wave-level 500-point transform as above.  Only when the
+// STFT is the one time / oscillatory feature (the 256-thread generic kernel: 1.4-1.7 ms per 256 hops x 256 channels).
+#define NMX_TOS_LDS_FLOATS (2048 + 1008 + 1008)
+static inline bool nmx_timeosc_stft500_ok(const NmxTimeOscArgs& A) {
+  const NmxOsc& O = A.stft;
+  if (!A.w500_tab || A.fft.enabled || A.welch.enabled || !O.enabled || A.n_bands > 8 || A.W > 2048 || A.W < 500 || (A.W & 3)) return false;
+  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) return false;
+  return !O.complex_full && O.estimators == NMXD_EST_MEAN && !O.return_spectrum && O.n == 500 && O.step == 250 && O.half == 250 &&
+         O.nseg >= 1 && O.nseg <= 16;
+}
+template <int NB>
+NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, float* smem) {
+  w = nmx_uniform_i(w);
+  c = nmx_uniform_i(c);
+  const int lane = (int)(threadIdx.x & 63);
+  const int W = A.W;
+  float* xs = smem;                              // [W <= 2048]
+  nmx_c2* fa = (nmx_c2*)(smem + 2048);           // [500]
+  nmx_c2* fb = (nmx_c2*)(smem + 2048 + 1008);    // [501]
+  float* out_row = A.out + (long long)w * A.n_outputs;
+  const NmxOsc& O = A.stft;
+  const int nb = A.n_bands;
+  const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? nmx_uniform_ll(A.starts[w]) : 0ll);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4 * W, 0x00020000);
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (256 * k >= W) break;
+    const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane + 1024 * k, 0, 0);
+    nmx_f4 v = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    if (A.clean_on_load) { v.x = nmx_clean_bl(v.x); v.y = nmx_clean_bl(v.y); v.z = nmx_clean_bl(v.z); v.w = nmx_clean_bl(v.w); }
+    if (4 * (lane + 64 * k) < W) ((nmx_f4*)xs)[lane + 64 * k] = v;
+  }
+  NmxW500TwReg T;
+  T.load(A.w500_tab, lane);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 2000, 0x00020000);
+  float hw[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) hw[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, 4 * lane + 256 * q, 0, 0));
+  NMX_WAVE_FENCE();
+  auto xe = [&](int e) -> float {   // even extension by 250, zero padding beyond
+    if (e < 250) return xs[250 - e];
+    if (e < 250 + W) return xs[e - 250];
+    if (e < 500 + W) return xs[W - 2 - (e - 250 - W)];
+    return 0.f;
+  };
+  NmxBandAcc<NB> acc;
+  acc.clear();
+  const float lscale = O.log_transform ? log10f(O.scale) : 0.f;
+  for (int sa = 0; sa < O.nseg; sa += 2) {
+    const bool two = sa + 1 < O.nseg;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = lane + 64 * q;
+      if (i < 500) fb[i] = nmx_mk2(xe(250 * sa + i) * hw[q], two ? xe(250 * (sa + 1) + i) * hw[q] : 0.f);
+    }
+    NMX_WAVE_FENCE();
+    const nmx_c2* Z = O.k_hi <= 100 ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, O.k_hi) : nmx_w500_fft<-1>(fb, fa, fb, T, lane);
+    for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
+      const nmx_c2 zk = Z[k == 500 ? 0 : k], zn = Z[k == 0 ? 0 : 500 - k];
+      const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
+      const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+      const float pa = ax * ax + ay * ay;
+      acc.add(O, nb, k, O.log_transform ? 0.5f * nmx_log10_fast(pa) + lscale : sqrtf(pa) * O.scale);
+      if (two) {
+        const float pb = bx * bx + by * by;
+        acc.add(O, nb, k, O.log_transform ? 0.5f * nmx_log10_fast(pb) + lscale : sqrtf(pb) * O.scale);
+      }
+    }
+    NMX_WAVE_FENCE();
+  }
+  acc.emit(O, nb, O.nseg, out_row, c, lane);
+}
 #endif

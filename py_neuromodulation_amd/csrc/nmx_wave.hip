@@ -90,6 +90,24 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
   return 1;
 }
 
+// STFT with 500-sample segments on windows of other lengths (<= 2048), the only time / oscillatory feature
+template <int NB>
+__global__ void __launch_bounds__(64) nmx_kern_timeosc_stft500(const NmxTimeOscArgs A) {
+  const int item = blockIdx.x;
+  nmx_timeosc_stft500_item<NB>(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+}
+extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
+  if (!nmx_timeosc_stft500_ok(*A)) return 0;
+  if (A->n_bands <= 4) {
+    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<4>, dim3(n_items), dim3(64), (size_t)NMX_TOS_LDS_FLOATS * 4, s, *A);
+    nmxi_note_kernel("nmx_kern_timeosc_stft500<4>");
+  } else {
+    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<8>, dim3(n_items), dim3(64), (size_t)NMX_TOS_LDS_FLOATS * 4, s, *A);
+    nmxi_note_kernel("nmx_kern_timeosc_stft500<8>");
+  }
+  return 1;
+}
+
 // 510-sample transforms (17 ms at 30 kHz): prime-factor transform per wave (nmx_k_timeosc_w510.h)
 template <int NB>
 __global__ void __launch_bounds__(64) nmx_kern_timeosc_w510(const NmxTimeOscArgs A) {
