@@ -17,7 +17,7 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 
-def run(eng, C, W, hop, n, dev, torch, steps=4):
+def run(eng, C, W, hop, n, dev, torch, steps=12):
     T = W + (n - 1) * hop
     x = torch.randn((C, T), dtype=torch.float32, device=dev) * 50
     out = torch.empty((n, eng.n_outputs), dtype=torch.float32, device=dev)
