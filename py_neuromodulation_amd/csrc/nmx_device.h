@@ -289,7 +289,9 @@ NMX_DEV void nmx_lds_wait5(nmx_c2& a, nmx_c2& b, nmx_c2& c, nmx_c2& d, nmx_c2& e
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory");
 }
 #else
-NMX_DEV void nmx_lds_wait8(nmx_c2*) {}
+// (volatile reads: the compiler counts the waits itself, but its scheduler would sink every read to its first use --
+// one exposed LDS latency per point; a scheduling barrier behind the batch keeps the reads together)
+NMX_DEV void nmx_lds_wait8(nmx_c2*) { __builtin_amdgcn_sched_barrier(0); }
 NMX_DEV void nmx_lds_tie8(nmx_c2*) {}
 NMX_DEV void nmx_lds_tie2(nmx_c2&, nmx_c2&) {}
 NMX_DEV void nmx_lds_wait5(nmx_c2&, nmx_c2&, nmx_c2&, nmx_c2&, nmx_c2&) {}
