@@ -369,8 +369,8 @@ NMX_DEV void nmx_bank_w64c_item(const NmxBankW64Args& AA, int w, int c, const Nm
       const nmx_rsrc s2 = nmx_make_rsrc(d + next, two ? 4 * W : 0);
       NMX_UNROLL
       for (int j = 0; j < 16; ++j) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].x), s1, 4 * l + 256 * j, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].y), s2, 4 * l + 256 * j, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].x), s1, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].y), s2, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
       }
     }
     NMX_PROF(5)

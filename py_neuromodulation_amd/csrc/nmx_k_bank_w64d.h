@@ -138,8 +138,8 @@ NMX_DEV void nmx_bank_w64d_item(const NmxBankW64Args& AA, int w, int c, float* s
       for (int i = 0; i < 16; ++i) {
         if (HALF && (i & 3) >= 2) continue;
         const int off = 4 * l + 256 * (i >> 2) + 1024 * (i & 3);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i].x), s1, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i].y), s2, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i].x), s1, off, 0, NMX_SERIES_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i].y), s2, off, 0, NMX_SERIES_STORE_AUX);
       }
     }
   }
