@@ -347,7 +347,9 @@ class STFT(_Oscillatory):
         ]
 
     def spectrum(self, data):
-        Z = stft_mag(data, self.nperseg)
+        # scipy.signal.stft shrinks nperseg to the input length (with a warning); the band indices keep the
+        # nominal grid (oscillatory.py:201-210), so they select other frequencies or raise IndexError
+        Z = stft_mag(data, min(self.nperseg, np.shape(data)[-1]))
         if self.s.log_transform:
             with np.errstate(divide="ignore"):
                 Z = np.log10(Z)
@@ -1184,3 +1186,19 @@ def burst_decision_margin(env: np.ndarray, thr: float) -> float:
     """min_n |env[n] - thr|: the perturbation that flips one `env >= thr` sample
     (features/bursts.py:175); a flipped sample moves run lengths / counts by whole samples."""
     return float(np.min(np.abs(np.asarray(env, np.float64) - float(thr))))
+
+
+def hjorth_noise_bound(y: np.ndarray, sigma: float):
+    """Relative change of Hjorth mobility / complexity (features/hjorth_raw.py:24-34, bandpower.py:185-207) that white
+    noise of standard deviation `sigma` on the samples of `y` explains.  The three variances are v_k = var(diff^k y);
+    noise adds c_k sigma^2 (c = 1, 2, 6: the squared binomial weights) to v_k plus a cross term whose 3-sigma size is
+    6 sqrt(c_k sigma^2 v_k / N).  A series sampled far above its band (theta at 2 kHz) has v_2 << v_0, so its
+    complexity = sqrt(v_2 v_0) / v_1 amplifies sample noise by (fs / f)^2.  Returns (mobility, complexity) bounds."""
+    y = np.asarray(y, np.float64)
+    n = max(y.shape[-1] - 2, 1)
+    d1 = np.diff(y)
+    v = [float(np.var(y)), float(np.var(d1)), float(np.var(np.diff(d1)))]
+    rel = []
+    for c, vk in zip((1.0, 2.0, 6.0), v):
+        rel.append((c * sigma * sigma + 6.0 * math.sqrt(c * sigma * sigma * vk / n)) / vk if vk > 0 else np.inf)
+    return 0.5 * (rel[0] + rel[1]), 0.5 * (rel[0] + rel[2]) + rel[1]

@@ -365,17 +365,20 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
     float* xs = (float*)X;
     NMX_LANE_LOOP {
-      // all 16 loads in flight before the first LDS store (W < 1024 on this path)
-      float t[16];
-      NMX_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int i = l + 64 * r;
-        t[r] = i < W ? src[i] : 0.f;
-      }
-      NMX_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int i = l + 64 * r;
-        if (i < W) xs[i] = A.clean_on_load ? nmx_clean(t[r]) : t[r];
+      // 16 loads in flight before the first LDS store; a second batch for windows beyond 1024 samples
+      // (W + 2 * pad_half <= 2048 on this path, and the exchange buffer holds 2176 floats)
+      for (int base = 0; base < W; base += 1024) {
+        float t[16];
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int i = base + l + 64 * r;
+          t[r] = i < W ? src[i] : 0.f;
+        }
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int i = base + l + 64 * r;
+          if (i < W) xs[i] = A.clean_on_load ? nmx_clean(t[r]) : t[r];
+        }
       }
     }
     NMX_WSYNC();

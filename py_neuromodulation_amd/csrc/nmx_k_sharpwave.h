@@ -700,8 +700,8 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     n_pairs = 0;
     for (int i = NMX_TID; i < nTr; i += NMX_NT) {
       const int t = tr[i];
-      int lo = 0;   // number of peaks before t: branch-free bisection (nPk <= 1024)
-      for (int step = 512; step > 0; step >>= 1) {
+      int lo = 0;   // number of peaks before t: branch-free bisection (nPk < 2048)
+      for (int step = 1024; step > 0; step >>= 1) {
         const int idx = lo + step;
         lo = (idx <= nPk && (int)pk[idx - 1] < t) ? idx : lo;
       }
@@ -730,12 +730,18 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
       for (int p = 0; p < n_pairs; ++p) lf[p] = tmp[p];
 #else
       // in place: read my entries, barrier, write (lane-strided -> at most pm / 64 registers)
-      nmx_u16 keep[16];
-      int kk = 0;
-      for (int p = NMX_TID; p < n_pairs && kk < 16; p += NMX_NT) keep[kk++] = pk[lf[first_valid + p] - 1];
-      NMX_SYNC();
-      kk = 0;
-      for (int p = NMX_TID; p < n_pairs && kk < 16; p += NMX_NT) lf[p] = keep[kk++];
+      // (blocks of 1024 pairs: a block reads lf[first_valid + p] at or beyond its own range and writes lf[p] inside it,
+      // so an earlier block never overwrites what a later one still has to read)
+      for (int base = 0; base < n_pairs; base += 1024) {
+        const int end = (base + 1024) < n_pairs ? (base + 1024) : n_pairs;
+        nmx_u16 keep[16];
+        int kk = 0;
+        for (int p = base + NMX_TID; p < end && kk < 16; p += NMX_NT) keep[kk++] = pk[lf[first_valid + p] - 1];
+        NMX_SYNC();
+        kk = 0;
+        for (int p = base + NMX_TID; p < end && kk < 16; p += NMX_NT) lf[p] = keep[kk++];
+        if (end < n_pairs) NMX_SYNC();
+      }
 #endif
     }
     NMX_SYNC();

@@ -188,9 +188,9 @@ class HotPathEngine:
                 f"than settings['segment_length_features_ms'] = "
                 f"{self.settings.segment_length_features_ms}")
         o = _lib.OscDesc()
-        # a segment longer than the window shrinks to it: x[:, -N:] (oscillatory.py:95) and
-        # scipy.signal.welch's nperseg clamp; the band bins keep the grid of the NOMINAL length
-        n_eff = min(int(n), self.W) if name in ("fft", "welch") else int(n)
+        # a segment longer than the window shrinks to it: x[:, -N:] (oscillatory.py:95) and the nperseg
+        # clamp of scipy.signal.welch / stft; the band bins keep the grid of the NOMINAL length
+        n_eff = min(int(n), self.W)
         o.n = n_eff
         o.log_transform = int(bool(s.log_transform))
         ests = _enabled(s.features)
@@ -200,6 +200,9 @@ class HotPathEngine:
             idx = np.where((freqs >= lo) & ((freqs <= hi) if inclusive else (freqs < hi)))[0]
             if idx.size and not np.array_equal(idx, np.arange(idx[0], idx[-1] + 1)):
                 raise ValueError("non-contiguous band bins")
+            if not idx.size and "max" in ests:   # np.max over an empty band (oscillatory.py:170)
+                raise ValueError("zero-size array to reduction operation maximum which has no identity "
+                                 f"({name}: band {bands[b][0]} holds no bin of the {len(freqs)}-bin grid)")
             o.bin_lo[b] = int(idx[0]) if idx.size else 0
             o.bin_hi[b] = int(idx[-1]) + 1 if idx.size else 0
             if o.bin_hi[b] > n_eff // 2 + 1:

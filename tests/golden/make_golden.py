@@ -436,6 +436,42 @@ def case_norm_methods():
     print("norm_methods", sorted(k for k in out if k.startswith(("feature_", "raw_"))))
 
 
+def case_short_windows():
+    """Windows SHORTER than the nominal spectral segment: scipy.signal.welch / stft shrink nperseg to the window
+    (with a warning) while the reference keeps the band indices of the nominal frequency grid
+    (features/oscillatory.py:136-144, 201-210): it then returns features of the wrong bins, or raises IndexError
+    when a band index lies beyond the shorter spectrum.  Both behaviours are recorded here."""
+    out = {}
+    cases = {"a": (750, 187, 250, {"theta": [4, 8], "alpha": [8, 12], "high_beta": [20, 35]}),
+             "b": (1000, 500, 500, None),
+             "c": (512, 128, 250, {"alpha": [8, 12], "low_beta": [13, 20], "high_gamma": [90, 200]}),
+             "d": (2000, 600, 1000, None)}
+    for tag, (sfreq, W, wl_ms, bands) in cases.items():
+        s = nm.NMSettings.get_default()
+        if bands is not None:
+            s.frequency_ranges_hz = bands
+        s.segment_length_features_ms = int(1000 * W / sfreq) + 1
+        for name in ("fft_settings", "welch_settings", "stft_settings"):
+            s[name].windowlength_ms = min(wl_ms, s.segment_length_features_ms)
+        all_estimators(s)
+        x = synth(3, W, sfreq, 70 + ord(tag), dc=False)
+        out[f"{tag}_settings_json"] = dump(s)
+        out[f"{tag}_sfreq"] = sfreq
+        out[f"{tag}_data"] = x
+        ch = ["c0", "c1", "c2"]
+        for fam, cls in (("fft", nm.features.FFT), ("welch", nm.features.Welch), ("stft", nm.features.STFT)):
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    d = cls(s, ch, sfreq).calc_feature(x)
+                pack(d, f"{tag}_{fam}", out)
+                out[f"{tag}_{fam}_error"] = ""
+            except Exception as e:   # noqa: BLE001 -- the error class is the recorded behaviour
+                out[f"{tag}_{fam}_error"] = type(e).__name__
+            print("short_windows", tag, fam, out[f"{tag}_{fam}_error"] or len(out[f"{tag}_{fam}_keys"]))
+    np.savez_compressed(HERE / "short_windows.npz", **out)
+
+
 def case_resample_quirk():
     """Recordings that are NOT sampled at raw_resampling_settings.resample_freq_hz (1000 Hz) under the default
     pre-processing: the reference resamples every window (processing/resample.py:42-60) but keeps building
@@ -521,6 +557,7 @@ if __name__ == "__main__":
     case_preprocessing_filter()
     case_raw_normalizer()
     case_norm_methods()
+    case_short_windows()
     case_schedule()
     case_feat_1k()
     case_feat_2k()

@@ -32,6 +32,11 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
     convolution.  All entries of that (channel, filter) then share the verdict.
   * bursts: `env >= thr`.  Accepted iff min_n |env[n] - thr| of that (channel, band) in the float64
     oracle is < DECISION_RTOL x max |input row|.
+  * Hjorth mobility / complexity (RawHjorth and the band-pass `mobility` / `complexity`): ratios of variances of
+    finite differences.  For a series sampled far above its band the second difference cancels (theta at 2 kHz:
+    var(diff^2 y) = 1e-7 var(y)), so white sample noise is amplified by (fs / f)^2.  Accepted iff the miss is no
+    larger than what white noise of HJORTH_EPS (1e-7, two fp32 ulp) x the rms of the input row on the samples of
+    the float64 series explains (oracle.hjorth_noise_bound, per entry).
   Without a verifier nothing is forgiven.  Every accepted entry is counted in `STATS` and the test
   session prints the counts per test (tests/conftest.py).
   * degenerate rows (all-zero / constant input): spectral bins that are exactly 0 in exact
@@ -92,6 +97,7 @@ def tolerances(key: str, settings, sfreq: float, amp_scale: float, W: int):
 
 NULL_RATIO = 1e-2       # contributing bin below this fraction of the spectrum's rms: ill-conditioned log10
 FP32_BIN_EPS = 1e-6     # absolute fp32 error of a spectral bin (pre-processing + transform) relative to the window's white-noise level: ~16 ulp
+HJORTH_EPS = 1e-7       # white noise on a (filtered) series relative to the rms of the input row: two fp32 ulp
 DECISION_RTOL = 1e-6    # decision margin relative to max |input row| below which fp32 can flip it
 
 STATS = {"compared": 0, "forgiven": {}, "notes": []}
@@ -134,6 +140,7 @@ class Verifier:
         self._sw_taps = sw_taps
         self._bursts = bursts
         self._spec, self._sw_y, self._margin = {}, None, {}
+        self._bp_y = None
 
     @property
     def x(self):
@@ -179,6 +186,25 @@ class Verifier:
         bound = orc.spectral_log_error_bound(mag, idx, floor, FP32_BIN_EPS, fam == "welch", est)
         return (r < NULL_RATIO and err <= bound,
                 f"min bin / white-noise level of the window = {r:.2e}, miss {err:.1e} <= explained {bound:.1e}")
+
+    def hjorth(self, key, fam, err, want):
+        from oracle import nm_oracle as orc
+
+        ci, rest = _split_key(key, self.ch)
+        if fam == "hjorth":
+            y, which = self.x[ci], rest.rsplit("_", 1)[1].lower()
+        else:
+            bp = orc.BandPower(self.s, self.ch, self.sfreq)
+            which, band = rest[len("bandpass_"):].split("_", 1)
+            bi = bp.band_names.index(band)
+            if self._bp_y is None:
+                self._bp_y = orc.fir_bank_apply(self.x, bp.taps)
+            y = self._bp_y[ci, bi, -bp.seglens[bi]:]
+        if which not in ("mobility", "complexity"):
+            return False, "not a ratio of difference variances"
+        mob, comp = orc.hjorth_noise_bound(y, HJORTH_EPS * self._rms(ci))
+        bound = (mob if which == "mobility" else comp) * abs(want)
+        return err <= bound, f"miss {err:.1e} <= {bound:.1e} explained by sample noise of {HJORTH_EPS:.0e} x rms"
 
     def sharpwave(self, key):
         from oracle import nm_oracle as orc
@@ -239,6 +265,8 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, verifier=
             accepted = False
             if fam in ("fft", "welch", "stft") and getattr(settings, f"{fam}_settings").log_transform:
                 accepted, why = verifier.spectral(k, fam, err)
+            elif fam in ("hjorth", "bandpass"):
+                accepted, why = verifier.hjorth(k, fam, err, w)
             elif fam == "sharpwave":
                 accepted, why = verifier.sharpwave(k)
             elif fam == "bursts":

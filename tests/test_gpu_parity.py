@@ -448,7 +448,7 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
 
     check("default", default)
     m2048 = {"NMX_BANK_W64C": "0"}   # every filter on the M = 2048 one-channel kernels (and their fused variants)
-    for knobs in ({"NMX_SW_DENSE": "0"}, {"NMX_SW_DENSE_FIRST": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
+    for knobs in ({"NMX_SW_DENSE": "0"}, {"NMX_SW_DENSE_FIRST": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"}, {"NMX_OVERLAP": "3"},
                   m2048, {**m2048, "NMX_FUSE_SHARP": "1"}, {**m2048, "NMX_FUSE_HILBERT": "1"}, {**m2048, "NMX_W64_PIPE": "0"},
                   {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_STFT_PER_WAVE": "0"}, {"NMX_TIMEOSC_W1000": "0"},
                   {"NMX_SHARP_FIRST": "1"}, {"NMX_CHUNK_WINDOWS": "9"}):
@@ -656,6 +656,15 @@ def test_channel_pair_bank_other_rates(gpu_lib, sfreq, kernel):
                                        verifier=parity.Verifier(s, ch, sfreq, x[:, starts[i]:starts[i] + W].astype(np.float64)))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def test_windows_shorter_than_the_spectral_segment(gpu_lib):
+    pc.case_short_windows(gpu_lib)
+
+
+@pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS)
+def test_random_settings_stream_equals_oracle(gpu_lib, seed):
+    pc.case_random_settings(gpu_lib, seed)
 
 
 def test_stream_output_files(gpu_lib, tmp_path):

@@ -120,3 +120,12 @@ def test_reref_structured_matrices(emu_lib):
 
 def test_raw_resampling_reference_quirk(emu_lib):
     pc.case_raw_resampling_reference_quirk(emu_lib)
+
+
+def test_windows_shorter_than_the_spectral_segment(emu_lib):
+    pc.case_short_windows(emu_lib)
+
+
+@pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS[:12])
+def test_random_settings_stream_equals_oracle(emu_lib, seed):
+    pc.case_random_settings(emu_lib, seed)
