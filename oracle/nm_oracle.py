@@ -1022,6 +1022,10 @@ class DataProcessor:
             elif name == "re_referencing":
                 R = reref_matrix(ch["name"], ch["rereference"], ch["used"], ch["type"], ch["status"])
                 self.pre.append(_Reref(R))
+            elif name == "preprocessing_filter":
+                self.pre.append(PreprocessingFilter(settings, self.sfreq))
+            elif name == "raw_normalization":
+                self.pre.append(RawNormalizer(self.sfreq, settings))
             else:
                 raise NotImplementedError(f"{name} is out of scope (SURVEY.md section 2)")
         self.features = []
@@ -1147,11 +1151,14 @@ def spectral_log_error_bound(mag: np.ndarray, idx: np.ndarray, floor_rms: float,
     spectrum); their MEAN for the "mean" estimator, their MAX for median / std / max and single-bin
     ("psd") entries (one bin can move those by at most its own error)."""
     m = np.asarray(mag, np.float64)
-    sel = np.abs(m[np.asarray(idx, dtype=int)]).ravel()
+    sel = np.abs(m[np.asarray(idx, dtype=int)])
     if sel.size == 0:
         return 0.0
+    e = np.asarray(eps, np.float64)          # scalar, or one value per contributing bin
+    if e.ndim == 1 and sel.ndim == 2:
+        e = e[:, None]
     with np.errstate(divide="ignore"):
-        per = np.log10(1.0 + eps * floor_rms / sel) * (2.0 if power else 1.0)
+        per = np.log10(1.0 + e * floor_rms / sel) * (2.0 if power else 1.0)
     return float(per.mean() if estimator == "mean" else per.max())
 
 

@@ -21,6 +21,9 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
   * log10-valued spectral features (FFT / Welch / STFT with log_transform, "psd" keys): fp32 puts an
     absolute error on every bin (the rounding of each sample is relative to its size, DC offset
     included, and spreads over all bins like white noise), log10 makes it relative.  Accepted iff some
+    (x (1 + number of fp32 pre-processing stages in front of the features): each adds its own rounding, and the null test scales with it; without
+    log_transform the same absolute bin error is the whole tolerance (a bin in a filter's stop band is not known
+    to 1e-5 of ITSELF in fp32).  Log-valued entries are accepted iff some
     bin that contributes to the entry has |X_k| < NULL_RATIO (1e-2) x the magnitude white noise with
     the window's rms (DC included) has in that family AND the miss is no larger than what an absolute
     error of FP32_BIN_EPS (1e-6, ~16 fp32 ulp) x that level on each contributing bin explains (computed per entry from
@@ -133,8 +136,9 @@ class Verifier:
     average removes still costs its fp32 ulps); the noise level of a channel is taken from the larger
     of the two rms values."""
 
-    def __init__(self, settings, ch_names, sfreq, x, *, sw_taps=None, bursts=None, raw=None):
+    def __init__(self, settings, ch_names, sfreq, x, *, sw_taps=None, bursts=None, raw=None, n_stages=0):
         self.s, self.ch, self.sfreq = settings, list(ch_names), sfreq
+        self.n_stages = int(n_stages)   # fp32 pre-processing stages in front of the features (each adds its rounding)
         self._x = x
         self._raw = raw
         self._sw_taps = sw_taps
@@ -182,8 +186,25 @@ class Verifier:
             band, est = rest.rsplit("_", 1)
             idx = dict(idx_range)[band]
         floor = gain * self._rms(ci)
-        r = orc.spectral_null_ratio(mag, idx, floor)
-        bound = orc.spectral_log_error_bound(mag, idx, floor, FP32_BIN_EPS, fam == "welch", est)
+        eps = FP32_BIN_EPS * (1 + self.n_stages)
+        # DC and Nyquist bins sum the samples coherently (all +, or + - + -): a rounding BIAS of half an fp32 ulp of
+        # the sample amplitude, far below the per-sample noise, adds up N-fold there instead of sqrt(N)-fold
+        # (measured on the resampler: median bin error 1e-7 of the white level, 3e-6 at DC / Nyquist)
+        n_fft = 2 * (len(freqs) - 1)
+        coh = 2.0 ** -24 * np.sqrt(n_fft) * self._amp(ci) / max(self._rms(ci), 1e-300) * (1 + self.n_stages)
+        idx = np.asarray(idx, dtype=int)
+        eps = eps + coh * ((idx == 0) | (idx == len(freqs) - 1))
+        if not getattr(self.s, f"{fam}_settings").log_transform:
+            # linear magnitudes: every bin carries the absolute error eps x the white-noise level, whatever its own size
+            # (Welch: a power, d(m^2) = 2 m dm)
+            d = float(np.max(eps)) * floor if idx.size else 0.0
+            bound = d if fam != "welch" else 2.0 * float(np.max(mag[idx])) * d + d * d
+            return err <= bound, f"linear bin: miss {err:.1e} <= {bound:.1e} = fp32 bin error at the window's noise level"
+        # ill-conditioned = some contributing bin within 1 / NULL_RATIO of ITS OWN error level
+        m_sel = np.abs(np.asarray(mag, np.float64)[idx])
+        scale = eps / FP32_BIN_EPS
+        r = float((m_sel / (scale[:, None] if m_sel.ndim == 2 else scale)).min() / floor) if m_sel.size and floor else float("inf")
+        bound = orc.spectral_log_error_bound(mag, idx, floor, eps, fam == "welch", est)
         return (r < NULL_RATIO and err <= bound,
                 f"min bin / white-noise level of the window = {r:.2e}, miss {err:.1e} <= explained {bound:.1e}")
 
@@ -263,7 +284,7 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, verifier=
         why = "no verifier"
         if verifier is not None:
             accepted = False
-            if fam in ("fft", "welch", "stft") and getattr(settings, f"{fam}_settings").log_transform:
+            if fam in ("fft", "welch", "stft"):
                 accepted, why = verifier.spectral(k, fam, err)
             elif fam in ("hjorth", "bandpass"):
                 accepted, why = verifier.hjorth(k, fam, err, w)
@@ -333,7 +354,8 @@ class PipelineVerifiers:
 
     def row(self, i) -> Verifier:
         has_b = "bursts" in list(self.s.features.get_enabled())
-        return Verifier(self.s, self.names, self.dp.sfreq, lambda: self.window(i),
+        n_stages = sum(len(p.taps) if hasattr(p, "taps") and isinstance(p.taps, list) else 1 for p in self.dp.pre)
+        return Verifier(self.s, self.names, self.dp.sfreq, lambda: self.window(i), n_stages=n_stages,
                         bursts=(lambda: self._burst_trace(i)) if has_b else None,
                         raw=(lambda: self.data[:, self.starts[i]:self.ends[i]]) if self.dp.pre else None)
 

@@ -1130,3 +1130,171 @@ def case_short_windows(lib):
                                            verifier=parity.Verifier(s, ch, sfreq, x))
             assert n_bad == 0, f"{tag} {fam}\n{rep}"
             eng.close()
+
+
+WIDE_SETTINGS_SEEDS = [i for i in range(201, 242) if i != 216]   # (216: four 3999-tap stages x 34 channels, minutes in the oracle)
+
+
+def random_settings_wide(seed):
+    """Second generator: everything `random_settings` draws plus estimator sets, return_spectrum, sharp-wave feature /
+    estimator tables, Kalman smoothing, raw_resampling / preprocessing_filter, channel counts up to 70, a flat channel,
+    and a feature-normalisation method.  Returns (settings, sfreq, data, line_noise, norm_method or None)."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.settings import _SW_FEATURES
+
+    rng = np.random.default_rng(seed)
+    for _ in range(200):
+        sfreq = float(rng.choice([250, 500, 600, 1000, 1000, 2000, 2048, 4000]))
+        seg_ms = int(rng.choice([500, 1000, 1000, 2000]))
+        feat_hz = int(rng.choice([4, 10, 10, 20]))
+        n_ch = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 64, 70]))
+        pre = []
+        fs_feat = sfreq
+        if rng.random() < 0.3 and sfreq * seg_ms / 1000 <= 7992:   # (the resample kernel pads to <= 8192 samples)
+            rs = float(rng.choice([250, 500, 1000]))
+            if rs < sfreq:
+                pre.append("raw_resampling")
+                fs_feat = rs
+        nyq = fs_feat / 2
+        pool = [("theta", [4, 8]), ("alpha", [8, 12]), ("low_beta", [13, 20]), ("high_beta", [20, 35]),
+                ("low_gamma", [60, 80]), ("high_gamma", [90, 200]), ("HFA", [200, 400])]
+        fit = [(n, r) for n, r in pool if r[1] + 10 < nyq]
+        keep = [b for b in fit if rng.random() < 0.6]
+        if len(keep) < 2:
+            keep = fit[:2]
+        base = NMSettings.get_default().to_dict()
+        base["frequency_ranges_hz"] = {n: r for n, r in keep}
+        s = NMSettings(**base)
+        s.sampling_rate_features_hz = feat_hz
+        s.segment_length_features_ms = seg_ms
+        if "raw_resampling" in pre:
+            s.raw_resampling_settings.resample_freq_hz = fs_feat
+        s.features.disable_all()
+        fams = ["fft", "welch", "stft", "bandpass_filter", "raw_hjorth", "linelength", "return_raw",
+                "sharpwave_analysis", "bursts"]
+        on = [f for f in fams if rng.random() < 0.5] or ["fft"]
+        W = int(sfreq * seg_ms / 1000)
+        if W > 4092 or seg_ms < 1000 and "welch" in on:
+            on = [f for f in on if f not in ("sharpwave_analysis", "welch")] or ["fft"]
+        if (sfreq / feat_hz) % 1 or "raw_resampling" in pre or W > 6000:   # (W > 6000: the Hilbert stage of the generic
+            on = [f for f in on if f != "bursts"] or ["fft"]                 # bank kernel needs 2 x 8 W bytes of LDS)
+        for f in on:
+            setattr(s.features, f, True)
+        for name in ("fft_settings", "welch_settings", "stft_settings"):
+            o = s[name]
+            o.windowlength_ms = int(min(rng.choice([250, 500, 1000]), seg_ms))
+            ests = [e for e in ("mean", "median", "std", "max") if rng.random() < 0.4] or ["mean"]
+            for e in ("mean", "median", "std", "max"):
+                setattr(o.features, e, e in ests)
+            o.log_transform = bool(rng.random() < 0.8)
+            o.return_spectrum = bool(rng.random() < 0.15) and o.windowlength_ms <= 1000 and name != "welch_settings"
+        s.bandpass_filter_settings.segment_lengths_ms = {
+            n: int(min(rng.choice([100, 333, 500, 1000]), seg_ms)) for n, _ in keep}
+        s.bandpass_filter_settings.log_transform = bool(rng.random() < 0.7)
+        for f in ("activity", "mobility", "complexity"):
+            setattr(s.bandpass_filter_settings.bandpower_features, f, bool(rng.random() < 0.5))
+        if not s.bandpass_filter_settings.bandpower_features.get_enabled():
+            s.bandpass_filter_settings.bandpower_features.activity = True
+        if rng.random() < 0.25 and s.bandpass_filter_settings.bandpower_features.activity:
+            s.bandpass_filter_settings.kalman_filter = True
+            s.kalman_filter_settings.frequency_bands = [n for n, _ in keep if rng.random() < 0.6] or [keep[0][0]]
+        s.bursts_settings.frequency_bands = [n for n, _ in keep if rng.random() < 0.5] or [keep[0][0]]
+        s.bursts_settings.time_duration_s = float(rng.choice([1, 3, 30]))
+        s.bursts_settings.threshold = float(rng.choice([50, 75, 90]))
+        for f in ("duration", "amplitude", "burst_rate_per_s", "in_burst"):
+            setattr(s.bursts_settings.burst_features, f, bool(rng.random() < 0.7))
+        if not s.bursts_settings.burst_features.get_enabled():
+            s.bursts_settings.burst_features.duration = True
+        sw = s.sharpwave_analysis_settings
+        feats = [f for f in _SW_FEATURES if rng.random() < 0.3] or ["prominence"]
+        for f in _SW_FEATURES:
+            setattr(sw.sharpwave_features, f, f in feats)
+        est = {e: [] for e in ("mean", "median", "max", "min", "var")}
+        for f in feats:
+            for e in rng.choice(list(est), size=int(rng.integers(1, 3)), replace=False):
+                est[str(e)].append(f)
+        for e, fl in est.items():
+            sw.estimator[e] = fl
+        sw.apply_estimator_between_peaks_and_troughs = bool(rng.random() < 0.5)
+        sw.detect_troughs.estimate = True
+        sw.detect_peaks.estimate = bool(sw.apply_estimator_between_peaks_and_troughs or rng.random() < 0.5)
+        for node in (sw.detect_troughs, sw.detect_peaks):
+            node.distance_troughs_ms = float(rng.choice([3, 5, 10, 15]))
+            node.distance_peaks_ms = float(rng.choice([3, 5, 10, 15]))
+        hi = 80 if nyq > 100 else 40
+        sw.filter_ranges_hz = [[[5, hi], [5, 30]], [[5, 30]], [[10, hi]]][int(rng.integers(0, 3))]
+        if rng.random() < 0.4:
+            pre.append("notch_filter")
+        if rng.random() < 0.5 and n_ch >= 2:
+            pre.append("re_referencing")
+        if rng.random() < 0.2 and fs_feat >= 1000 and "raw_resampling" not in pre:
+            pre.append("preprocessing_filter")
+            for f in ("bandstop_filter", "bandpass_filter", "lowpass_filter", "highpass_filter"):
+                setattr(s.preprocessing_filter, f, bool(rng.random() < 0.5))
+        s.preprocessing = pre
+        s.postprocessing.feature_normalization = False
+        norm = None
+        if rng.random() < 0.5:
+            norm = str(rng.choice(["zscore", "mean", "median", "zscore-median", "robust", "minmax", "quantile"]))
+            s.feature_normalization_settings.normalization_method = norm
+            s.feature_normalization_settings.normalization_time_s = float(rng.choice([1, 3, 30]))
+            s.feature_normalization_settings.clip = float(rng.choice([0, 3]))
+        try:
+            s = NMSettings(**s.to_dict()).validate()
+        except Exception:
+            continue
+        n_hops = int(min(rng.integers(6, 60), max(400 // n_ch, 4)))
+        T = W + int(n_hops * sfreq / feat_hz) + int(rng.integers(0, 7))
+        t = np.arange(T) / sfreq
+        data = rng.standard_normal((n_ch, T)) * 10 + rng.uniform(-50, 50, (n_ch, 1))
+        data += 8 * np.sin(2 * np.pi * rng.uniform(5, min(40, nyq / 3)) * t)[None]
+        if n_ch >= 3 and rng.random() < 0.25:
+            data[int(rng.integers(0, n_ch))] = 0.0   # a flat channel: -inf logs, empty extrema lists
+        return s, sfreq, data, 50, norm
+    raise RuntimeError("no valid settings drawn")
+
+
+def case_random_settings_wide(lib, seed):
+    """`case_random_settings` over the wider generator; a drawn feature-normalisation method is checked as in
+    case_pipeline_readme_default_zscore: the engine's normalised rows against the float64 oracle normaliser applied to
+    the engine's OWN un-normalised rows."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.stream import Stream
+
+    s, sfreq, data, line, norm = random_settings_wide(seed)
+    ch = chmod.get_default_channels_from_data(data).to_dict("list")
+    what = f"seed {seed} ({sfreq} Hz, {data.shape[0]} ch, {s.features.get_enabled()}, {s.preprocessing}, norm {norm})"
+    try:
+        df = Stream(sfreq, data=data, settings=s, line_noise=line, lib=lib).run(save_csv=False)
+    except (ValueError, IndexError) as e:
+        with pytest.raises(Exception):
+            orc.run_stream(data, sfreq, s, ch, line_noise=line)
+        return f"both raise: {e}"
+    rows = orc.run_stream(data, sfreq, s, ch, line_noise=line)
+    assert list(df.columns) == list(rows[0].keys()), f"{what}: columns differ"
+    assert len(df) == len(rows)
+    got = df.to_numpy(float)
+    fs_win = sfreq
+    starts, ends, _ = orc.window_schedule(data.shape[1], fs_win, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    W = int(ends[0] - starts[0])
+    pv = parity.PipelineVerifiers(s, ch, sfreq, data, starts, W, line_noise=line, ends=ends)
+    cols = list(df.columns)
+    for i, r in enumerate(rows):
+        want = np.array(list(r.values()))
+        n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[:-1], s, sfreq, 40.0, W, verifier=pv.row(i))
+        assert n_bad == 0, f"{what} hop {i}\n{rep}"
+        assert got[i, -1] == want[-1]
+    if norm is not None:
+        s_n = type(s)(**s.to_dict())
+        s_n.postprocessing.feature_normalization = True
+        got_n = Stream(sfreq, data=data, settings=s_n, line_noise=line, lib=lib).run(save_csv=False).to_numpy(float)
+        fn = orc.FeatureNormalizer(s_n)
+        sel = [i for i, k in enumerate(cols[:-1]) if "psd" not in k]   # normalize_psd = False (data_processor.py:283-290)
+        want_n = got[:, :-1].copy()
+        want_n[:, sel] = np.stack([fn.process(r.copy()) for r in got[:, sel]])
+
+        def huge(a):   # nan_to_num'ed infinities: float64 max in the oracle, float32 max in the engine (tests/parity.py)
+            return np.where(np.abs(a) >= parity.HUGE, np.sign(a) * np.inf, a)
+
+        np.testing.assert_allclose(huge(got_n[:, :-1]), huge(want_n), rtol=1e-5, atol=2e-6, err_msg=what)

@@ -129,3 +129,8 @@ def test_windows_shorter_than_the_spectral_segment(emu_lib):
 @pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS[:12])
 def test_random_settings_stream_equals_oracle(emu_lib, seed):
     pc.case_random_settings(emu_lib, seed)
+
+
+@pytest.mark.parametrize("seed", pc.WIDE_SETTINGS_SEEDS[:12])
+def test_random_settings_wide_stream_equals_oracle(emu_lib, seed):
+    pc.case_random_settings_wide(emu_lib, seed)
