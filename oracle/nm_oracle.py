@@ -1121,8 +1121,9 @@ def spectral_magnitudes(family: str, settings, sfreq: float, x_row: np.ndarray):
         gain = math.sqrt(2.0 / o.sfreq)
     elif family == "stft":
         o = STFT(settings, ["c"], sfreq)
-        mag = stft_mag(x, o.nperseg)[0]
-        w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(o.nperseg) / o.nperseg)
+        n = min(o.nperseg, x.shape[-1])   # scipy's nperseg clamp (STFT.spectrum)
+        mag = stft_mag(x, n)[0]
+        w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(n) / n)
         gain = math.sqrt(np.sum(w * w)) / np.sum(w)
     else:
         raise ValueError(family)
@@ -1200,7 +1201,8 @@ def hjorth_noise_bound(y: np.ndarray, sigma: float):
     noise of standard deviation `sigma` on the samples of `y` explains.  The three variances are v_k = var(diff^k y);
     noise adds c_k sigma^2 (c = 1, 2, 6: the squared binomial weights) to v_k plus a cross term whose 3-sigma size is
     6 sqrt(c_k sigma^2 v_k / N).  A series sampled far above its band (theta at 2 kHz) has v_2 << v_0, so its
-    complexity = sqrt(v_2 v_0) / v_1 amplifies sample noise by (fs / f)^2.  Returns (mobility, complexity) bounds."""
+    complexity = sqrt(v_2 v_0) / v_1 amplifies sample noise by (fs / f)^2; a band in the stop band of a pre-processing
+    filter has v_0 itself far below the input power.  Returns (activity, mobility, complexity) bounds."""
     y = np.asarray(y, np.float64)
     n = max(y.shape[-1] - 2, 1)
     d1 = np.diff(y)
@@ -1208,4 +1210,4 @@ def hjorth_noise_bound(y: np.ndarray, sigma: float):
     rel = []
     for c, vk in zip((1.0, 2.0, 6.0), v):
         rel.append((c * sigma * sigma + 6.0 * math.sqrt(c * sigma * sigma * vk / n)) / vk if vk > 0 else np.inf)
-    return 0.5 * (rel[0] + rel[1]), 0.5 * (rel[0] + rel[2]) + rel[1]
+    return rel[0], 0.5 * (rel[0] + rel[1]), 0.5 * (rel[0] + rel[2]) + rel[1]

@@ -39,6 +39,11 @@ __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs 
   const int item = blockIdx.x;
   nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
 }
+// long histories (4 kHz x 30 s at the 60th percentile: 48 001 list entries): 1024 threads x 64 entries each
+__global__ void __launch_bounds__(1024) nmx_kern_burst_thr_wide(const NmxBurstThrArgs A) {
+  const int item = blockIdx.x;
+  nmx_burst_thr_item<64>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
+}
 // kernels compiled with a compile-time workgroup size live in nmx_timeosc.hip / nmx_wave.hip
 extern "C" void nmx_timeosc_fixed_launch128(const NmxTimeOscArgs* A, int n_items, size_t lds, hipStream_t s);
 extern "C" void nmx_hilbert_fixed_launch128(const NmxHilbertArgs* A, long long n_items, size_t lds, hipStream_t s);
@@ -208,6 +213,7 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<32>);
   be_allow_lds(nmx_kern_burst_thr<64>);
   be_allow_lds(nmx_kern_burst_thr<128>);
+  be_allow_lds(nmx_kern_burst_thr_wide);
 }
 
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
@@ -324,7 +330,8 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, s
   // ring already full at the first hop: the barrier-free one-wave walk over the list in L2
   if (windows_seen > 0 && nmx_burst_thr_wave_ok(A, windows_seen)) { nmx_wave_launch_burst_thr(&A, n_items, s); return; }
   const int chunk = (A.K + nt - 1) / nt;
-  if (chunk <= 32) { hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<32>"); }
+  if (nt > 256) { hipLaunchKernelGGL(nmx_kern_burst_thr_wide, dim3(n_items), dim3(1024), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr_wide"); }
+  else if (chunk <= 32) { hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<32>"); }
   else if (chunk <= 64) { hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<64>"); }
   else { hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<128>"); }
 }

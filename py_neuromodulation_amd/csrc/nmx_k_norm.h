@@ -246,7 +246,9 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     if (q > 0) {  // the first row ever is returned as it came
       double out;
       if (sk) {
-        out = nmx_norm_sklearn(A, j, ns, (double)x);
+        // (the current value is widened like the history: a nan_to_num'ed -inf feature is -DBL_MAX on both sides of
+        // the reference's subtraction, not -FLT_MAX against -DBL_MAX)
+        out = nmx_norm_sklearn(A, j, ns, nmx_norm_finite(x) ? nmx_norm_wide(x) : (double)x);
       } else if (cnt + ninf == 0 || (ninf > 0 && A.method != NMX_NORM_MEDIAN)) {
         out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
       } else if (A.method == NMX_NORM_MEDIAN) {

@@ -38,8 +38,9 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
   * Hjorth mobility / complexity (RawHjorth and the band-pass `mobility` / `complexity`): ratios of variances of
     finite differences.  For a series sampled far above its band the second difference cancels (theta at 2 kHz:
     var(diff^2 y) = 1e-7 var(y)), so white sample noise is amplified by (fs / f)^2.  Accepted iff the miss is no
-    larger than what white noise of HJORTH_EPS (1e-7, two fp32 ulp) x the rms of the input row on the samples of
-    the float64 series explains (oracle.hjorth_noise_bound, per entry).
+    larger than what white noise of HJORTH_EPS (1e-7, two fp32 ulp) x the rms of the input row (per fp32 stage) on
+    the samples of the float64 series explains (oracle.hjorth_noise_bound, per entry).  The same bound covers the
+    `activity` (variance) of a band that a pre-processing filter has pushed far below the input power.
   Without a verifier nothing is forgiven.  Every accepted entry is counted in `STATS` and the test
   session prints the counts per test (tests/conftest.py).
   * degenerate rows (all-zero / constant input): spectral bins that are exactly 0 in exact
@@ -53,6 +54,17 @@ from __future__ import annotations
 import numpy as np
 
 HUGE = 1e37
+
+
+def widen_huge(row) -> np.ndarray:
+    """float64 copy of an fp32 feature row with +-FLT_MAX (the engine's nan_to_num'ed +-inf) mapped to the reference's
+    +-DBL_MAX, for feeding engine rows to a float64 oracle stage."""
+    r = np.array(row, dtype=np.float64)
+    fmax = float(np.finfo(np.float32).max)
+    fin = np.isfinite(r)
+    r[fin & (r >= fmax)] = np.finfo(np.float64).max
+    r[fin & (r <= -fmax)] = np.finfo(np.float64).min
+    return r
 
 
 def _same_huge(a: float, b: float) -> bool:
@@ -170,7 +182,7 @@ class Verifier:
             r = max(r, float(np.sqrt(np.mean(self.raw ** 2))))
         return r
 
-    def spectral(self, key, fam, err):
+    def spectral(self, key, fam, err, got=None):
         from oracle import nm_oracle as orc
 
         ci, rest = _split_key(key, self.ch)
@@ -190,10 +202,11 @@ class Verifier:
         # DC and Nyquist bins sum the samples coherently (all +, or + - + -): a rounding BIAS of half an fp32 ulp of
         # the sample amplitude, far below the per-sample noise, adds up N-fold there instead of sqrt(N)-fold
         # (measured on the resampler: median bin error 1e-7 of the white level, 3e-6 at DC / Nyquist)
-        n_fft = 2 * (len(freqs) - 1)
+        n_bins = np.shape(mag)[0]          # of the transform actually taken (shorter than `freqs` on a short window)
+        n_fft = 2 * (n_bins - 1)
         coh = 2.0 ** -24 * np.sqrt(n_fft) * self._amp(ci) / max(self._rms(ci), 1e-300) * (1 + self.n_stages)
         idx = np.asarray(idx, dtype=int)
-        eps = eps + coh * ((idx == 0) | (idx == len(freqs) - 1))
+        eps = eps + coh * ((idx == 0) | (idx == n_bins - 1))
         if not getattr(self.s, f"{fam}_settings").log_transform:
             # linear magnitudes: every bin carries the absolute error eps x the white-noise level, whatever its own size
             # (Welch: a power, d(m^2) = 2 m dm)
@@ -203,6 +216,13 @@ class Verifier:
         # ill-conditioned = some contributing bin within 1 / NULL_RATIO of ITS OWN error level
         m_sel = np.abs(np.asarray(mag, np.float64)[idx])
         scale = eps / FP32_BIN_EPS
+        if got is not None and np.isneginf(got) and m_sel.size and floor:
+            # a bin BELOW its own fp32 error level is rounding noise on the grid of the last additions' ulps; that grid
+            # contains 0, and log10(0) = -inf takes the band's mean / median / max with it
+            e_col = eps[:, None] if m_sel.ndim == 2 else eps
+            rr = float((m_sel / (e_col * floor)).min())
+            if rr < 1.0:
+                return True, f"-inf: a contributing bin lies at {rr:.1e} of its fp32 error level (can round to exactly 0)"
         r = float((m_sel / (scale[:, None] if m_sel.ndim == 2 else scale)).min() / floor) if m_sel.size and floor else float("inf")
         bound = orc.spectral_log_error_bound(mag, idx, floor, eps, fam == "welch", est)
         return (r < NULL_RATIO and err <= bound,
@@ -221,11 +241,15 @@ class Verifier:
             if self._bp_y is None:
                 self._bp_y = orc.fir_bank_apply(self.x, bp.taps)
             y = self._bp_y[ci, bi, -bp.seglens[bi]:]
-        if which not in ("mobility", "complexity"):
-            return False, "not a ratio of difference variances"
-        mob, comp = orc.hjorth_noise_bound(y, HJORTH_EPS * self._rms(ci))
-        bound = (mob if which == "mobility" else comp) * abs(want)
-        return err <= bound, f"miss {err:.1e} <= {bound:.1e} explained by sample noise of {HJORTH_EPS:.0e} x rms"
+        if which not in ("activity", "mobility", "complexity"):
+            return False, "not a Hjorth parameter"
+        act, mob, comp = orc.hjorth_noise_bound(y, HJORTH_EPS * (1 + self.n_stages) * self._rms(ci))
+        if which == "activity":   # a variance; log10-valued with log_transform (band-pass) -- small when the band lies in
+            log = fam == "bandpass" and self.s.bandpass_filter_settings.log_transform   # a pre-processing stop band
+            bound = float(np.log10(1.0 + act)) if log else act * abs(want)
+        else:
+            bound = (mob if which == "mobility" else comp) * abs(want)
+        return err <= bound, f"miss {err:.1e} <= {bound:.1e} explained by sample noise of {HJORTH_EPS:.0e} x rms per fp32 stage"
 
     def sharpwave(self, key):
         from oracle import nm_oracle as orc
@@ -285,7 +309,7 @@ def compare(keys, got, want, settings, sfreq, amp_scale, W, skip=None, verifier=
         if verifier is not None:
             accepted = False
             if fam in ("fft", "welch", "stft"):
-                accepted, why = verifier.spectral(k, fam, err)
+                accepted, why = verifier.spectral(k, fam, err, g)
             elif fam in ("hjorth", "bandpass"):
                 accepted, why = verifier.hjorth(k, fam, err, w)
             elif fam == "sharpwave":

@@ -458,15 +458,22 @@ def case_feature_normalizer_batches(lib):
     mask = np.ones(F, dtype=np.uint8)
     mask[20:24] = 0
     rows[:, 15] = np.round(rows[:, 15])                # ties: repeated quantiles
+    col16 = rows[:, 16].copy()
     for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0), ("median", 3), ("zscore-median", 3), ("median", 0),
                          ("robust", 3), ("robust", 0), ("minmax", 3), ("quantile", 3), ("quantile", 0)):
+        # a nan_to_num'ed -inf feature (band power of a flat channel).  Not for the scikit-learn methods: np.nanmedian
+        # of a 2-D history with fewer than 600 cells averages (low + high) also for odd counts, which overflows to -inf
+        # for +-DBL_MAX; the kernel follows the large-array branch (np.median per column)
+        rows[:, 16] = col16 if method in ("robust", "minmax", "quantile") else np.finfo(np.float32).min
         s = NMSettings.get_default()
         s.sampling_rate_features_hz = 10
         s.feature_normalization_settings.normalization_time_s = 5
         s.feature_normalization_settings.normalization_method = method
         s.feature_normalization_settings.clip = clip
         ref = orc.FeatureNormalizer(s)
-        want = np.stack([ref.process(r.astype(np.float64)) for r in rows[:, mask == 1]])
+        # (+-FLT_MAX is the fp32 image of the reference's nan_to_num'ed +-inf = +-DBL_MAX: the oracle sees the latter, where
+        # e.g. the median of an even number of them overflows to -inf exactly as numpy's does in the reference)
+        want = np.stack([ref.process(parity.widen_huge(r)) for r in rows[:, mask == 1]])
         dn = DeviceFeatureNormalizer(s, F, colmask=mask, lib=lib)
         got = [dn.process_batch(rows[:1]), dn.process_batch(rows[1:130])]
         state = dn.export_state()
@@ -1187,7 +1194,9 @@ def random_settings_wide(seed):
             for e in ("mean", "median", "std", "max"):
                 setattr(o.features, e, e in ests)
             o.log_transform = bool(rng.random() < 0.8)
-            o.return_spectrum = bool(rng.random() < 0.15) and o.windowlength_ms <= 1000 and name != "welch_settings"
+            # (a bin spacing below 1 Hz makes the reference's 'psd_<int(f)>' keys collide: not supported, raises)
+            spacing = sfreq / min(o.windowlength_ms, W) if name == "stft_settings" else 1000.0 / o.windowlength_ms
+            o.return_spectrum = bool(rng.random() < 0.15) and spacing >= 1.0 and name != "welch_settings"
         s.bandpass_filter_settings.segment_lengths_ms = {
             n: int(min(rng.choice([100, 333, 500, 1000]), seg_ms)) for n, _ in keep}
         s.bandpass_filter_settings.log_transform = bool(rng.random() < 0.7)
@@ -1248,8 +1257,10 @@ def random_settings_wide(seed):
         t = np.arange(T) / sfreq
         data = rng.standard_normal((n_ch, T)) * 10 + rng.uniform(-50, 50, (n_ch, 1))
         data += 8 * np.sin(2 * np.pi * rng.uniform(5, min(40, nyq / 3)) * t)[None]
-        if n_ch >= 3 and rng.random() < 0.25:
-            data[int(rng.integers(0, n_ch))] = 0.0   # a flat channel: -inf logs, empty extrema lists
+        # a flat channel: -inf logs, empty extrema lists (not with the scikit-learn normalisers: their transform raises
+        # ValueError on an infinite feature in the reference)
+        if n_ch >= 3 and rng.random() < 0.25 and norm not in ("robust", "minmax", "quantile"):
+            data[int(rng.integers(0, n_ch))] = 0.0
         return s, sfreq, data, 50, norm
     raise RuntimeError("no valid settings drawn")
 
@@ -1292,7 +1303,7 @@ def case_random_settings_wide(lib, seed):
         fn = orc.FeatureNormalizer(s_n)
         sel = [i for i, k in enumerate(cols[:-1]) if "psd" not in k]   # normalize_psd = False (data_processor.py:283-290)
         want_n = got[:, :-1].copy()
-        want_n[:, sel] = np.stack([fn.process(r.copy()) for r in got[:, sel]])
+        want_n[:, sel] = np.stack([fn.process(parity.widen_huge(r)) for r in got[:, sel]])
 
         def huge(a):   # nan_to_num'ed infinities: float64 max in the oracle, float32 max in the engine (tests/parity.py)
             return np.where(np.abs(a) >= parity.HUGE, np.sign(a) * np.inf, a)
