@@ -1282,7 +1282,12 @@ def case_random_settings_wide(lib, seed):
         with pytest.raises(Exception):
             orc.run_stream(data, sfreq, s, ch, line_noise=line)
         return f"both raise: {e}"
-    rows = orc.run_stream(data, sfreq, s, ch, line_noise=line)
+    try:
+        rows = orc.run_stream(data, sfreq, s, ch, line_noise=line)
+    except IndexError as e:
+        # data-dependent crash of the reference itself (sharpwaves.py:419-430: a window whose only trough has no peak
+        # on one side still enters the steepness loop); a device kernel cannot raise, nothing to compare
+        return f"reference raises on this recording: {e}"
     assert list(df.columns) == list(rows[0].keys()), f"{what}: columns differ"
     assert len(df) == len(rows)
     got = df.to_numpy(float)
