@@ -1315,3 +1315,80 @@ def case_random_settings_wide(lib, seed):
             return np.where(np.abs(a) >= parity.HUGE, np.sign(a) * np.inf, a)
 
         np.testing.assert_allclose(huge(got_n[:, :-1]), huge(want_n), rtol=1e-5, atol=2e-6, err_msg=what)
+
+
+CHANNEL_TABLE_SEEDS = list(range(301, 321))
+
+
+def random_channel_table(rng, n_ch):
+    """A random channel table in the reference's layout: mixed types, bad / unused channels, a target channel, and every
+    re-reference form of processing/rereference.py:33-86 ("average" inside the type, one named channel, "a&b", "None")."""
+    import pandas as pd
+
+    types = [str(rng.choice(["ecog", "ecog", "seeg", "lfp"])) for _ in range(n_ch)]
+    names = [f"{t.upper()}_{'LR'[int(rng.integers(0, 2))]}_{i}" for i, t in enumerate(types)]
+    status = ["bad" if rng.random() < 0.12 else "good" for _ in range(n_ch)]
+    used = [0 if rng.random() < 0.12 else 1 for _ in range(n_ch)]
+    target = [0] * n_ch
+    if n_ch >= 4 and rng.random() < 0.5:
+        t = int(rng.integers(0, n_ch))
+        target[t], used[t], names[t], types[t] = 1, 0, "MOV_RIGHT", "misc"
+    if not any(u == 1 and s == "good" and not tg for u, s, tg in zip(used, status, target)):
+        used[0], status[0], target[0] = 1, "good", 0
+    refs = []
+    for i in range(n_ch):
+        others = [names[j] for j in range(n_ch) if j != i and used[j] == 1 and not target[j]]
+        mates = [j for j in range(n_ch) if j != i and used[j] == 1 and status[j] == "good" and types[j] == types[i]]
+        u = rng.random()
+        if target[i] or u < 0.2 or not others:
+            refs.append("None")
+        elif u < 0.6 and mates:
+            refs.append("average")
+        elif u < 0.85 or len(others) < 2:
+            refs.append(str(rng.choice(others)))
+        else:
+            a, b = rng.choice(len(others), size=2, replace=False)
+            refs.append(f"{others[a]}&{others[b]}")
+    new = [n if r == "None" else (f"{n}-avgref" if r == "average" else f"{n}-{r}") for n, r in zip(names, refs)]
+    return pd.DataFrame({"name": names, "rereference": refs, "used": used, "target": target, "type": types,
+                         "status": status, "new_name": new})
+
+
+def case_random_channel_tables(lib, seed):
+    """Random channel tables (types, bad / unused channels, a target column, all re-reference forms) under random
+    settings with re-referencing on: `Stream.run` against the oracle, columns (target column included) in order."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.stream import Stream
+
+    s, sfreq, data, line = random_settings(seed)
+    rng = np.random.default_rng(seed + 7)
+    n_ch = int(rng.integers(3, 24))
+    T = data.shape[1]
+    data = rng.standard_normal((n_ch, T)) * 10 + rng.uniform(-50, 50, (n_ch, 1)) + data[:1]
+    if "re_referencing" not in s.preprocessing:
+        s.preprocessing = list(s.preprocessing) + ["re_referencing"]
+        s = type(s)(**s.to_dict()).validate()
+    tab = random_channel_table(rng, n_ch)
+    ch = tab.to_dict("list")
+    try:
+        df = Stream(sfreq, channels=tab, data=data, settings=s, line_noise=line, lib=lib).run(data, save_csv=False)
+    except (ValueError, IndexError) as e:
+        with pytest.raises(Exception):
+            orc.run_stream(data, sfreq, s, ch, line_noise=line)
+        return f"both raise: {e}"
+    rows = orc.run_stream(data, sfreq, s, ch, line_noise=line)
+    assert list(df.columns) == list(rows[0].keys()), f"seed {seed}: columns differ\n{list(df.columns)[:6]}\n{list(rows[0])[:6]}"
+    assert len(df) == len(rows)
+    got = df.to_numpy(float)
+    starts, ends, _ = orc.window_schedule(T, sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    W = int(ends[0] - starts[0])
+    pv = parity.PipelineVerifiers(s, ch, sfreq, data, starts, W, line_noise=line, ends=ends)
+    cols = list(df.columns)
+    n_t = sum(tab["target"])
+    feat_cols = len(cols) - 1 - n_t
+    for i, r in enumerate(rows):
+        want = np.array(list(r.values()))
+        n_bad, rep, _ = parity.compare(cols[:feat_cols], got[i, :feat_cols], want[:feat_cols], s, sfreq, 40.0, W,
+                                       verifier=pv.row(i))
+        assert n_bad == 0, f"seed {seed} ({sfreq} Hz, {n_ch} ch)\n{tab}\nhop {i}\n{rep}"
+        np.testing.assert_array_equal(got[i, feat_cols:], want[feat_cols:])   # time and target columns: exact

@@ -134,3 +134,8 @@ def test_random_settings_stream_equals_oracle(emu_lib, seed):
 @pytest.mark.parametrize("seed", pc.WIDE_SETTINGS_SEEDS[:12])
 def test_random_settings_wide_stream_equals_oracle(emu_lib, seed):
     pc.case_random_settings_wide(emu_lib, seed)
+
+
+@pytest.mark.parametrize("seed", pc.CHANNEL_TABLE_SEEDS[:8])
+def test_random_channel_tables_stream_equals_oracle(emu_lib, seed):
+    pc.case_random_channel_tables(emu_lib, seed)
