@@ -1392,3 +1392,66 @@ def case_random_channel_tables(lib, seed):
                                        verifier=pv.row(i))
         assert n_bad == 0, f"seed {seed} ({sfreq} Hz, {n_ch} ch)\n{tab}\nhop {i}\n{rep}"
         np.testing.assert_array_equal(got[i, feat_cols:], want[feat_cols:])   # time and target columns: exact
+
+
+BURST_STREAM_SEEDS = list(range(401, 417))
+
+
+def case_random_burst_streams(lib, seed):
+    """Long streams through the burst detector only: the history fills, the walk switches from the workgroup kernel to
+    the one-wave kernel in the middle of a batch (nmx_engine.inc, k_fill), and runs many hops in steady state -- over
+    random sampling rates, feature rates, history lengths, percentiles and window lengths, fed in random batch sizes
+    (state carried across `process_batch` calls) against the oracle's hop-by-hop `Bursts`."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    rng = np.random.default_rng(seed)
+    sfreq = float(rng.choice([250, 500, 1000, 1000, 2000, 4000]))
+    feat_hz = int(rng.choice([5, 10, 10, 20, 50]))
+    seg_ms = int(rng.choice([250, 500, 1000]))
+    hop = int(sfreq / feat_hz)
+    W = int(sfreq * seg_ms / 1000)
+    dur = float(rng.choice([0.5, 1, 2, 5]))
+    base = NMSettings.get_default().to_dict()
+    pool = [("alpha", [8, 12]), ("low_beta", [13, 20]), ("high_beta", [20, 35]), ("low_gamma", [60, 80])]
+    keep = [b for b in pool if b[1][1] + 10 < sfreq / 2]
+    keep = [keep[i] for i in sorted(rng.choice(len(keep), size=int(rng.integers(1, len(keep) + 1)), replace=False))]
+    base["frequency_ranges_hz"] = {n: r for n, r in keep}
+    s = NMSettings(**base)
+    s.sampling_rate_features_hz = feat_hz
+    s.segment_length_features_ms = seg_ms
+    s.features.disable_all()
+    s.features.bursts = True
+    s.bursts_settings.frequency_bands = [n for n, _ in keep]
+    s.bursts_settings.time_duration_s = dur
+    s.bursts_settings.threshold = float(rng.choice([50, 75, 75, 90, 97]))
+    s.bandpass_filter_settings.segment_lengths_ms = {n: seg_ms for n, _ in keep}
+    s.preprocessing = []
+    s.postprocessing.feature_normalization = False
+    s = NMSettings(**s.to_dict()).validate()
+    C = int(rng.integers(1, 6))
+    n_fill = int(np.ceil(max(dur * sfreq - W, 0) / hop)) + 1      # hops until the history is full
+    n_hops = int(min(n_fill + rng.integers(20, 120), 600))
+    T = W + (n_hops - 1) * hop
+    t = np.arange(T) / sfreq
+    x = rng.standard_normal((C, T)) * 10 + 6 * np.sin(2 * np.pi * 17 * t) * (1 + np.sin(2 * np.pi * 0.7 * t))
+    ch = [f"c{i}" for i in range(C)]
+    eng = HotPathEngine(s, ch, sfreq, lib=lib)
+    ob = orc.Bursts(s, ch, sfreq)
+    starts = np.arange(n_hops, dtype=np.int64) * hop
+    got, a = [], 0
+    while a < n_hops:                     # random batch sizes; the first one often ends inside the fill phase
+        b = min(n_hops, a + int(rng.integers(1, max(n_fill, 2) * 2)))
+        got.append(eng.process_batch(x, starts[a:b]))
+        a = b
+    got = np.concatenate(got)
+    what = f"seed {seed}: {sfreq} Hz, hop {hop}, W {W}, history {dur} s, q {s.bursts_settings.threshold}, {C} ch, {n_hops} hops"
+    for i, st in enumerate(starts):
+        w = x[:, st:st + W]
+        want = ob.calc_feature(w)
+        assert list(want) == eng.keys
+        ver = parity.Verifier(s, ch, sfreq, w, bursts=ob)
+        n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 40.0, W, verifier=ver)
+        assert n_bad == 0, f"{what}; hop {i} (history full from hop {n_fill})\n{rep}"
+    eng.close()

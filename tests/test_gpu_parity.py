@@ -677,6 +677,11 @@ def test_random_channel_tables_stream_equals_oracle(gpu_lib, seed):
     pc.case_random_channel_tables(gpu_lib, seed)
 
 
+@pytest.mark.parametrize("seed", pc.BURST_STREAM_SEEDS)
+def test_random_burst_streams_equal_oracle(gpu_lib, seed):
+    pc.case_random_burst_streams(gpu_lib, seed)
+
+
 def test_stream_output_files(gpu_lib, tmp_path):
     pc.case_stream_output_files(gpu_lib, tmp_path)
 

@@ -139,3 +139,8 @@ def test_random_settings_wide_stream_equals_oracle(emu_lib, seed):
 @pytest.mark.parametrize("seed", pc.CHANNEL_TABLE_SEEDS[:8])
 def test_random_channel_tables_stream_equals_oracle(emu_lib, seed):
     pc.case_random_channel_tables(emu_lib, seed)
+
+
+@pytest.mark.parametrize("seed", pc.BURST_STREAM_SEEDS[:6])
+def test_random_burst_streams_equal_oracle(emu_lib, seed):
+    pc.case_random_burst_streams(emu_lib, seed)
