@@ -28,7 +28,8 @@ def window_schedule(n_samples: int, sfreq: float, sampling_rate_features_hz: flo
         k += 1
         if int(end) > n_samples:
             break
-        ts_last = np.arange(start, end)[-1] / sfreq
+        # np.arange(start, end)[-1] without building the array: ceil((end - start) / 1) elements, the i-th is start + i
+        ts_last = (start + (math.ceil(end - start) - 1)) / sfreq
         starts.append(int(start))
         lens.append(int(end) - int(start))
         times.append(math.ceil(ts_last * 1000 + 1))
