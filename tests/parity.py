@@ -379,7 +379,10 @@ class PipelineVerifiers:
 
     def row(self, i) -> Verifier:
         has_b = "bursts" in list(self.s.features.get_enabled())
-        n_stages = sum(len(p.taps) if hasattr(p, "taps") and isinstance(p.taps, list) else 1 for p in self.dp.pre)
+        # fp32 stages in front of the features: one per FIR of a pre-processing filter chain, two for the resampler (a
+        # forward and an inverse transform of the padded window, 4 - 16 k points), one for everything else
+        n_stages = sum(len(p.taps) if hasattr(p, "taps") and isinstance(p.taps, list)
+                       else (2 if type(p).__name__ == "Resampler" else 1) for p in self.dp.pre)
         return Verifier(self.s, self.names, self.dp.sfreq, lambda: self.window(i), n_stages=n_stages,
                         bursts=(lambda: self._burst_trace(i)) if has_b else None,
                         raw=(lambda: self.data[:, self.starts[i]:self.ends[i]]) if self.dp.pre else None)

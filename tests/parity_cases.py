@@ -1036,7 +1036,8 @@ def random_settings(seed):
             on = ["fft"]
         if seg_ms < 500 or sfreq * seg_ms / 1000 > 4092:   # (the sharp-wave kernel takes windows up to 4092 samples)
             on = [f for f in on if f != "sharpwave_analysis"] or ["fft"]
-        if (sfreq / feat_hz) % 1:   # ragged windows: one plan per length, the burst history is per plan (not supported)
+        if (sfreq * seg_ms / 1000) % 1:   # ragged window LENGTHS (non-integer segment): one plan per length, the burst
+            # history is per plan (not supported; a non-integer HOP alone is fine)
             on = [f for f in on if f != "bursts"] or ["fft"]
         for f in on:
             setattr(s.features, f, True)
@@ -1183,7 +1184,7 @@ def random_settings_wide(seed):
         W = int(sfreq * seg_ms / 1000)
         if W > 4092 or seg_ms < 1000 and "welch" in on:
             on = [f for f in on if f not in ("sharpwave_analysis", "welch")] or ["fft"]
-        if (sfreq / feat_hz) % 1 or "raw_resampling" in pre or W > 6000:   # (W > 6000: the Hilbert stage of the generic
+        if (sfreq * seg_ms / 1000) % 1 or "raw_resampling" in pre or W > 6000:   # (W > 6000: the Hilbert stage of the generic
             on = [f for f in on if f != "bursts"] or ["fft"]                 # bank kernel needs 2 x 8 W bytes of LDS)
         for f in on:
             setattr(s.features, f, True)
