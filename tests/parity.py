@@ -365,6 +365,9 @@ class PipelineVerifiers:
         self.names = list(key_names) if key_names is not None else list(self.dp.ch_names_used)
         self._cache = {}
         self._tracer = None
+        if any(type(p).__name__ == "RawNormalizer" for p in self.dp.pre):
+            for i in range(len(self.starts)):   # a stateful pre-processor: every hop once, in order
+                self.window(i)
 
     def window(self, i):
         if i not in self._cache:

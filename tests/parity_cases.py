@@ -1241,6 +1241,15 @@ def random_settings_wide(seed):
             pre.append("preprocessing_filter")
             for f in ("bandstop_filter", "bandpass_filter", "lowpass_filter", "highpass_filter"):
                 setattr(s.preprocessing_filter, f, bool(rng.random() < 0.5))
+        raw_norm = bool(rng.random() < 0.15) and "raw_resampling" not in pre
+        if raw_norm:
+            pre.append("raw_normalization")
+            # ("mean" / "median" divide by the centre: ill-conditioned on re-referenced, near-zero-mean rows; they are
+            # pinned by the reference goldens of case_raw_normalizer* on data with an offset)
+            s.raw_normalization_settings.normalization_method = str(
+                rng.choice(["zscore", "zscore-median", "robust", "minmax"]))
+            s.raw_normalization_settings.normalization_time_s = float(rng.choice([1, 3, 30]))
+            s.raw_normalization_settings.clip = float(rng.choice([0, 3]))
         s.preprocessing = pre
         s.postprocessing.feature_normalization = False
         norm = None
@@ -1261,7 +1270,7 @@ def random_settings_wide(seed):
         # a flat channel: -inf logs, empty extrema lists.  Not together with a normaliser: the reference's statistics of a
         # history that holds nan_to_num'ed infinities (+-DBL_MAX) are overflow artefacts of numpy's summation order
         # (mean -> -inf, std -> inf or NaN), and the scikit-learn transforms raise ValueError on an infinite feature
-        if n_ch >= 3 and rng.random() < 0.25 and norm is None:
+        if n_ch >= 3 and rng.random() < 0.25 and norm is None and not raw_norm:
             data[int(rng.integers(0, n_ch))] = 0.0
         return s, sfreq, data, 50, norm
     raise RuntimeError("no valid settings drawn")
