@@ -288,6 +288,16 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       }
       if (med && (sk || o == o)) { pend = true; pend_val = sk ? nmx_clean(o) : o; }
       --len;
+      // a value far larger than what stays behind leaves the sliding sums with ITS rounding (4e1 leaving a window of
+      // 1e-5's: s2 is 1e-13 off against 7e-9): rebuild the sums from the rows that remain (rare)
+      if (nmx_norm_finite(o) && !((double)o * (double)o <= 1e4 * s2)) {
+        s1 = 0.0; s2 = 0.0; cnt = 0; ninf = 0;
+        for (long long t = q - len + 1; t <= q; ++t) {
+          const float h = A.ring[(t % cap) * A.n_cols + j];
+          if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+          else if (h == h) ++ninf;
+        }
+      }
     }
   }
 }

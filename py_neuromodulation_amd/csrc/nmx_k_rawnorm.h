@@ -119,8 +119,17 @@ NMX_DEV void nmx_rawnorm_stats_item(const NmxRawNormArgs& A, int c) {
         const double v = (double)ring[(cnt - len + i) % A.cap];
         d1 += v; d2 += v * v;
       }
-      s1 -= nmx_wave_sum_d(d1); s2 -= nmx_wave_sum_d(d2);
+      const double dd2 = nmx_wave_sum_d(d2);
+      s1 -= nmx_wave_sum_d(d1); s2 -= dd2;
       len -= drop;
+      if (!(dd2 <= 1e4 * s2)) {   // what left dwarfs what stays (an artefact leaving the history): rebuild the sums
+        double r1 = 0.0, r2 = 0.0;
+        for (int i = NMX_TID; i < len; i += NMX_NT) {
+          const double v = (double)ring[(cnt - len + i) % A.cap];
+          r1 += v; r2 += v * v;
+        }
+        s1 = nmx_wave_sum_d(r1); s2 = nmx_wave_sum_d(r2);
+      }
     }
   }
   if (NMX_TID == 0) { A.count[c] = cnt; A.len[c] = len; }
@@ -340,9 +349,20 @@ NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem)
         dr_raw[i] = v;
         d1 += (double)v; d2 += (double)v * (double)v;
       }
-      if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) { s1 -= nmx_rawnorm_block_sum_d(d1, red); s2 -= nmx_rawnorm_block_sum_d(d2, red); }
       len -= drop;
       n_drop = drop;
+      if (A.method == NMX_RAWNORM_ZSCORE_MEDIAN) {
+        const double dd2 = nmx_rawnorm_block_sum_d(d2, red);
+        s1 -= nmx_rawnorm_block_sum_d(d1, red); s2 -= dd2;
+        if (!(dd2 <= 1e4 * s2)) {   // (as in nmx_rawnorm_stats_item: rebuild when what left dwarfs what stays)
+          double r1 = 0.0, r2 = 0.0;
+          for (int i = NMX_TID; i < len; i += NMX_NT) {
+            const double v = (double)ring[(cnt - len + i) % A.cap];
+            r1 += v; r2 += v * v;
+          }
+          s1 = nmx_rawnorm_block_sum_d(r1, red); s2 = nmx_rawnorm_block_sum_d(r2, red);
+        }
+      }
     }
     NMX_SYNC();
   }

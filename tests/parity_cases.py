@@ -459,6 +459,8 @@ def case_feature_normalizer_batches(lib):
     mask[20:24] = 0
     rows[:, 15] = np.round(rows[:, 15])                # ties: repeated quantiles
     col16 = rows[:, 16].copy()
+    rows[:, 17] = np.abs(rows[:, 17]) * 1e-6           # tiny values ...
+    rows[::97, 17] = 40.0                              # ... and a huge one passing through the history every 97 hops
     for method, clip in (("zscore", 3), ("mean", 3), ("zscore", 0), ("median", 3), ("zscore-median", 3), ("median", 0),
                          ("robust", 3), ("robust", 0), ("minmax", 3), ("quantile", 3), ("quantile", 0)):
         # a nan_to_num'ed -inf feature (band power of a flat channel).  Not for the scikit-learn methods: np.nanmedian
@@ -875,6 +877,22 @@ def case_raw_normalizer(lib):
     np.testing.assert_allclose(e2.process_batch(data, starts[:2]), got[:2], rtol=1e-6, atol=1e-7)
     e1.close()
     e2.close()
+    # an artefact 1e6 x the signal passes through the 0.5 s history: the sliding sums are rebuilt once it has left
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 1000 + 20 * 100)) * 1e-3 + 0.01
+    x[0, 1100:1110] = 5e3
+    st2 = np.arange(21) * 100
+    for method in ("zscore", "zscore-median"):
+        s2 = settings_from_json(g["zscore_settings_json"])
+        s2.raw_normalization_settings.normalization_method = method
+        s2.raw_normalization_settings.clip = 0
+        ref = orc.RawNormalizer(sfreq, s2)
+        want = np.stack([ref.process(x[:, a:a + 1000])[:, -1] for a in st2])
+        eng = HotPathEngine(NMSettings.get_default(), ["a", "b"], sfreq, features=["return_raw"],
+                            raw_norm=(method, 0, int(0.5 * sfreq), 100), window=1000, lib=lib)
+        got = eng.process_batch(x, st2)
+        np.testing.assert_allclose(got[1:], want[1:], rtol=2e-5, atol=5e-6, err_msg=f"artefact, {method}")
+        eng.close()
 
 
 def case_psd_keys_skip_normalisation(lib):
@@ -1241,7 +1259,8 @@ def random_settings_wide(seed):
             pre.append("preprocessing_filter")
             for f in ("bandstop_filter", "bandpass_filter", "lowpass_filter", "highpass_filter"):
                 setattr(s.preprocessing_filter, f, bool(rng.random() < 0.5))
-        raw_norm = bool(rng.random() < 0.15) and "raw_resampling" not in pre
+        # (the order-statistic raw normalisers keep window + hop samples in LDS lists: <= 6484)
+        raw_norm = bool(rng.random() < 0.15) and "raw_resampling" not in pre and W + sfreq / feat_hz <= 6400
         if raw_norm:
             pre.append("raw_normalization")
             # ("mean" / "median" divide by the centre: ill-conditioned on re-referenced, near-zero-mean rows; they are
