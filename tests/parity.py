@@ -247,7 +247,13 @@ class Verifier:
         act, mob, comp = orc.hjorth_noise_bound(y, HJORTH_EPS * (1 + self.n_stages) * self._rms(ci))
         if which == "activity":   # a variance; log10-valued with log_transform (band-pass) -- small when the band lies in
             log = fam == "bandpass" and self.s.bandpass_filter_settings.log_transform   # a pre-processing stop band
-            bound = float(np.log10(1.0 + act)) if log else act * abs(want)
+            # linear: also 1e-5 of the variance SCALE per fp32 stage -- a Kalman-smoothed activity can sit near zero while
+            # its inputs do not, and every pre-processing stage adds its relative error to all samples alike
+            v0 = float(np.var(y))
+            bound = float(np.log10(1.0 + act)) if log else max(act * abs(want), 1e-5 * (1 + self.n_stages) * max(v0, abs(want)))
+            if fam == "bandpass" and getattr(self.s.bandpass_filter_settings, "kalman_filter", False) and \
+                    band in self.s.kalman_filter_settings.frequency_bands:
+                bound *= 4.0   # the recursive smoother carries the rounding of every earlier hop (random walk over the stream)
         else:
             bound = (mob if which == "mobility" else comp) * abs(want)
         return err <= bound, f"miss {err:.1e} <= {bound:.1e} explained by sample noise of {HJORTH_EPS:.0e} x rms per fp32 stage"
