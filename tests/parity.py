@@ -23,7 +23,7 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
     (the rounding of each sample is relative to its size, DC offset included, and spreads over all bins like white
     noise): FP32_BIN_EPS (2e-6, ~32 fp32 ulp) x the magnitude white noise with the window's rms (DC included) has in
     that family, x (1 + number of fp32 pre-processing stages in front of the features: each adds its own rounding).
-    The DC and Nyquist bins add the samples coherently and get 2^-24 sqrt(N) amp / rms on top (a rounding bias of half
+    The DC, Nyquist and N/4 bins add the samples coherently and get 2^-24 sqrt(N) amp / rms on top (a rounding bias of half
     an ulp adds up N-fold there).  With log_transform that absolute error becomes relative: a miss is accepted iff it
     is no larger than what this error on each contributing bin explains, computed per entry from the oracle's own bins
     (mean of log10(1 + eps * level / |X_k|) for "mean" entries, the max otherwise; a healthy bin cannot be forgiven: at
@@ -208,7 +208,8 @@ class Verifier:
         n_fft = 2 * (n_bins - 1)
         coh = 2.0 ** -24 * np.sqrt(n_fft) * self._amp(ci) / max(self._rms(ci), 1e-300) * (1 + self.n_stages)
         idx = np.asarray(idx, dtype=int)
-        eps = eps + coh * ((idx == 0) | (idx == n_bins - 1))
+        quarter = (idx == n_fft // 4) if n_fft % 4 == 0 else np.zeros(idx.shape, bool)   # twiddles 1, -i, -1, i: period-4 bias
+        eps = eps + coh * ((idx == 0) | (idx == n_bins - 1) | quarter)
         if not getattr(self.s, f"{fam}_settings").log_transform:
             # linear magnitudes: every bin carries the absolute error eps x the white-noise level, whatever its own size
             # (Welch: a power, d(m^2) = 2 m dm)
