@@ -6,6 +6,7 @@
 #include "nmx_k_bank.h"
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_bursts.h"
+#include "nmx_k_burst_fill.h"
 #include "nmx_k_kalman.h"
 #include "nmx_k_norm.h"
 #include "nmx_k_prep.h"
@@ -38,6 +39,11 @@ __global__ void __launch_bounds__(256) nmx_kern_burst_thr(const NmxBurstThrArgs 
   __builtin_amdgcn_s_setprio(3);
   const int item = blockIdx.x;
   nmx_burst_thr_item<CH>(A, item / A.n_bands, item % A.n_bands, nmx_smem);
+}
+// fresh stream: the fill phase of the history as one sort + a barrier-free walk (nmx_k_burst_fill.h)
+__global__ void __launch_bounds__(NMX_FILL_NT) nmx_kern_burst_fill(const NmxBurstThrArgs A, int n2, unsigned short* slots) {
+  const int item = blockIdx.x;
+  nmx_burst_fill_item(A, item / A.n_bands, item % A.n_bands, n2, slots, nmx_smem);
 }
 // long histories (4 kHz x 30 s at the 60th percentile: 48 001 list entries): 1024 threads x 64 entries each
 __global__ void __launch_bounds__(1024) nmx_kern_burst_thr_wide(const NmxBurstThrArgs A) {
@@ -214,6 +220,7 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<64>);
   be_allow_lds(nmx_kern_burst_thr<128>);
   be_allow_lds(nmx_kern_burst_thr_wide);
+  be_allow_lds(nmx_kern_burst_fill);
 }
 
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
@@ -334,6 +341,13 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, s
   else if (chunk <= 32) { hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<32>"); }
   else if (chunk <= 64) { hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<64>"); }
   else { hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<128>"); }
+}
+static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short* slots, be_stream_t s) {
+  be_init_once();
+  int n2 = 2048;
+  while (n2 < A.W + (A.n_windows - 1) * A.overlap) n2 <<= 1;
+  hipLaunchKernelGGL(nmx_kern_burst_fill, dim3(n_items), dim3(NMX_FILL_NT), nmx_burst_fill_lds(n2), s, A, n2, slots);
+  nmxi_note_kernel("nmx_kern_burst_fill");
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t s) {
   be_init_once();

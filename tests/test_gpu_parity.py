@@ -450,7 +450,7 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     m2048 = {"NMX_BANK_W64C": "0"}   # every filter on the M = 2048 one-channel kernels (and their fused variants)
     for knobs in ({"NMX_SW_DENSE": "0"}, {"NMX_SW_DENSE_FIRST": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"}, {"NMX_OVERLAP": "3"},
                   m2048, {**m2048, "NMX_FUSE_SHARP": "1"}, {**m2048, "NMX_FUSE_HILBERT": "1"}, {**m2048, "NMX_W64_PIPE": "0"},
-                  {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_STFT_PER_WAVE": "0"}, {"NMX_TIMEOSC_W1000": "0"},
+                  {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_STFT_PER_WAVE": "0"}, {"NMX_TIMEOSC_W1000": "0"},
                   {"NMX_SHARP_FIRST": "1"}, {"NMX_CHUNK_WINDOWS": "9"}):
         for knob, val in knobs.items():
             monkeypatch.setenv(knob, val)
@@ -555,8 +555,9 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch, s
     starts = np.arange(n_hops) * hop
     monkeypatch.setenv("NMX_CHUNK_WINDOWS", "128")
 
-    def run(wave, plan, export_at=None):
+    def run(wave, plan, export_at=None, fill=True):
         monkeypatch.setenv("NMX_THR_WAVE", "1" if wave else "0")
+        monkeypatch.setenv("NMX_THR_FILL", "1" if fill else "0")   # fresh stream: the sort-once fill walk (nmx_k_burst_fill.h)
         eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib, features=["bursts"], bank_taps=None)
         rows, i = [], 0
         for n in plan:
@@ -570,9 +571,15 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch, s
         eng.close()
         return np.concatenate(rows)
 
-    want = run(False, [n_hops])
+    want = run(False, [n_hops], fill=False)          # the workgroup kernel alone
     assert not np.isnan(want).any()
-    np.testing.assert_array_equal(run(True, [n_hops]), want)
+    np.testing.assert_array_equal(run(False, [n_hops]), want)            # fill walk + workgroup kernel
+    np.testing.assert_array_equal(run(True, [n_hops], fill=False), want)
+    np.testing.assert_array_equal(run(True, [n_hops]), want)             # the default: fill walk, then the one-wave walk
+    np.testing.assert_array_equal(run(True, [5, 1, n_hops - 6]), want)   # a fill walk of 5 hops, continued by the others
+    monkeypatch.setenv("NMX_CHUNK_WINDOWS", "1024")
+    np.testing.assert_array_equal(run(True, [n_hops]), want)             # one chunk: the fill walk ends where the ring is full
+    monkeypatch.setenv("NMX_CHUNK_WINDOWS", "128")
     a, b = n_hops // 3, n_hops // 2
     np.testing.assert_array_equal(run(True, [a, 1, 7, n_hops - 2 * a - 8, a]), want)
     np.testing.assert_array_equal(run(True, [b, n_hops - b], export_at=b), want)
