@@ -9,9 +9,9 @@
 //   2. looks every sample up in the sorted array, all threads in parallel (binary search; equal values claim the next
 //      free slot of their run with an atomic OR on a bit mask) and notes its slot, in arrival order, in a 16-bit
 //      scratch list (global memory, L2-resident);
-//   3. walks the hops in order on ONE wave, barrier-free: a hop's slots (prefetched one hop ahead) are marked
-//      "arrived" in a second bit mask, per 64 slots a counter holds the arrived ones; the two order statistics are
-//      two rank selections (wave scan over the block counters, then inside one 64-bit mask);
+//   3. walks the hops in order on ONE wave, barrier-free: a hop's slots (staged in LDS 81 hops at a time) are marked
+//      "arrived" in a second bit mask; the slot of the threshold's rank is a POINTER that moves by the few arrived
+//      slots the rank changed by (one 4096-slot window of the mask per move: see "the rank pointer" below);
 //   4. leaves the state the other walk kernels continue from: the descending top-K list and the counters.
 // Same float64 interpolation on the same two floats as nmx_burst_thr_item: bit-identical thresholds.
 #pragma once
@@ -20,10 +20,10 @@
 
 #define NMX_FILL_NT 1024
 #define NMX_FILL_CHUNK 8192  // slots staged in LDS at a time
-#define NMX_FILL_MAX 32768   // samples (LDS: 4 bytes each + 2 bits + 1/16 counter byte + the slot chunk = 154 KB)
+#define NMX_FILL_MAX 32768   // samples (LDS: 4 bytes each + 2 bits + the slot chunk = 152 KB)
 
 // LDS bytes for a sort size of n2 samples
-static inline size_t nmx_burst_fill_lds(int n2) { return (size_t)n2 * 4 + 2 * ((size_t)n2 / 8) + (size_t)n2 / 16 + 2 * NMX_FILL_CHUNK + 64; }
+static inline size_t nmx_burst_fill_lds(int n2) { return (size_t)n2 * 4 + 2 * ((size_t)n2 / 8) + 2 * NMX_FILL_CHUNK + 64; }
 
 // hops a fresh stream can hand to this kernel: all samples of the batch must fit the LDS sort
 static inline int nmx_burst_fill_hops(const NmxBurstThrArgs& A, int n_windows) {
@@ -33,46 +33,88 @@ static inline int nmx_burst_fill_hops(const NmxBurstThrArgs& A, int n_windows) {
 }
 
 #ifndef NMX_HOST_EMU
-// slots of the (r + 1)-th and, if r > 0, the r-th arrived sample in descending order (r < number arrived); wave-uniform.
-// pre[8]: this lane's inclusive running counts over its `per` blocks, base: arrived before this lane's blocks.
-// The r-th is the previous set bit of the same 64-slot mask when there is one (else *prev = -1: select it separately).
-NMX_DEV int nmx_fill_select(const unsigned* act, const int* pre, int base, int lane_total, int per, int r, int lane, int* prev) {
-  const bool mine = r >= base && r < base + lane_total;
-  const int src = (int)__ffsll((long long)__ballot(mine)) - 1;
-  int p = 0, q = -1;
-  if (mine) {
-    int rr = r - base, b = 0, skip = 0;
+// ---- the rank pointer -----------------------------------------------------------------------------------------
+// The threshold of a hop is the arrived slot of rank r (r grows by ~(1 - q) x overlap per hop).  Instead of
+// re-selecting it from counters, the walk keeps the slot p of the previous rank and MOVES it: the new arrivals below p
+// raise p's own rank by their number (a ballot), the rest of the difference is a walk over the arrival mask -- ONE
+// window of 64 x 64 slots read by the 64 lanes, a DPP scan of the popcounts and one popcount bisection.
+NMX_DEV int nmx_fill_scan64(int v) {   // inclusive wave scan on the DPP path (no LDS round trips)
+  int incl = v;
+#define NMX_FILL_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, incl, ctrl, rmask, 0xf, false)
+  incl += NMX_FILL_DPP(0x111, 0xf);   // row_shr:1
+  incl += NMX_FILL_DPP(0x112, 0xf);   // row_shr:2
+  incl += NMX_FILL_DPP(0x114, 0xf);   // row_shr:4
+  incl += NMX_FILL_DPP(0x118, 0xf);   // row_shr:8
+  incl += NMX_FILL_DPP(0x142, 0xa);   // row_bcast:15
+  incl += NMX_FILL_DPP(0x143, 0xc);   // row_bcast:31
+#undef NMX_FILL_DPP
+  return incl;
+}
+// position of the (j + 1)-th lowest set bit of m (j < popcount(m))
+NMX_DEV int nmx_fill_bit(unsigned long long m, int j) {
+  unsigned x = (unsigned)m;
+  int off = 0, cnt = __popc(x);
+  if (j >= cnt) { j -= cnt; off = 32; x = (unsigned)(m >> 32); }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {   // (compile-time indices only: a runtime index would put pre[] into scratch memory)
-      const int before = i ? pre[i - 1] : 0;
-      if (rr >= before && rr < pre[i]) { b = i; skip = before; }
-    }
-    rr -= skip;
-    const int blk = per * lane + b;
-    // the (rr + 1)-th set bit of the block's 64-bit mask (slots ascend = values descend): popcount bisection
-    const unsigned long long m64 = (unsigned long long)act[2 * blk] | ((unsigned long long)act[2 * blk + 1] << 32);
-    unsigned x = (unsigned)m64;
-    int off = 0, cnt = __popc(x);
-    if (rr >= cnt) { rr -= cnt; off = 32; x = (unsigned)(m64 >> 32); }
-#pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) {
-      cnt = __popc(x & ((1u << w) - 1u));
-      if (rr >= cnt) { rr -= cnt; x >>= w; off += w; }
-    }
-    p = 64 * blk + off;
-    const unsigned long long below = off ? (m64 & ((1ull << off) - 1ull)) : 0ull;
-    if (below) q = 64 * blk + 63 - __clzll((long long)below);
+  for (int w = 16; w >= 1; w >>= 1) {
+    cnt = __popc(x & ((1u << w) - 1u));
+    if (j >= cnt) { j -= cnt; x >>= w; off += w; }
   }
-  *prev = __builtin_amdgcn_readlane(q, src);
-  return __builtin_amdgcn_readlane(p, src);
+  return off;
+}
+NMX_DEV unsigned long long nmx_fill_word(const unsigned* act, int w, int nw64) {
+  return (w >= 0 && w < nw64) ? ((unsigned long long)act[2 * w] | ((unsigned long long)act[2 * w + 1] << 32)) : 0ull;
+}
+// the k-th arrived slot strictly AFTER p (k >= 1; p = -1: from the start); wave-uniform
+NMX_DEV int nmx_fill_forward(const unsigned* act, int p, int k, int lane, int nw64) {
+  int w0 = p < 0 ? 0 : (p >> 6);
+  bool first = p >= 0;
+  for (;;) {
+    const int w = w0 + lane;
+    unsigned long long m = nmx_fill_word(act, w, nw64);
+    if (first && lane == 0) m &= ((p & 63) == 63) ? 0ull : ~((2ull << (p & 63)) - 1ull);   // bits <= p off
+    const int c = __popcll(m), incl = nmx_fill_scan64(c);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total >= k) {
+      const int src = (int)__ffsll((long long)__ballot(incl >= k)) - 1;
+      int r = 0;
+      if (lane == src) r = 64 * w + nmx_fill_bit(m, k - (incl - c) - 1);
+      return __builtin_amdgcn_readlane(r, src);
+    }
+    k -= total;
+    w0 += 64;
+    first = false;
+    if (w0 >= nw64) return 64 * nw64 - 1;   // (cannot happen: k never exceeds the arrived slots after p)
+  }
+}
+// the k-th arrived slot strictly BEFORE p (k >= 1); wave-uniform
+NMX_DEV int nmx_fill_backward(const unsigned* act, int p, int k, int lane, int nw64) {
+  int w0 = p >> 6;
+  bool first = true;
+  for (;;) {
+    const int w = w0 - lane;
+    unsigned long long m = nmx_fill_word(act, w, nw64);
+    if (first && lane == 0) m &= (1ull << (p & 63)) - 1ull;   // bits >= p off
+    const int c = __popcll(m), incl = nmx_fill_scan64(c);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total >= k) {
+      const int src = (int)__ffsll((long long)__ballot(incl >= k)) - 1;
+      int r = 0;
+      if (lane == src) r = 64 * w + 63 - nmx_fill_bit(__brevll(m), k - (incl - c) - 1);   // counted from the top
+      return __builtin_amdgcn_readlane(r, src);
+    }
+    k -= total;
+    w0 -= 64;
+    first = false;
+    if (w0 < 0) return 0;   // (cannot happen)
+  }
 }
 
 NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2, unsigned short* slots, float* smem) {
   float* S = smem;                               // [n2] all samples, descending after the sort
   unsigned* act = (unsigned*)(S + n2);           // [n2 / 32] arrived bits
   unsigned* claim = act + n2 / 32;               // [n2 / 32] slots taken by the look-up
-  int* cblk = (int*)(claim + n2 / 32);           // [n2 / 64] arrived per 64 slots
-  unsigned short* sq = (unsigned short*)(cblk + n2 / 64);   // [NMX_FILL_CHUNK] slots of the next hops
+  unsigned short* sq = (unsigned short*)(claim + n2 / 32);   // [NMX_FILL_CHUNK] slots of the next hops
   const int tid = (int)threadIdx.x, nt = NMX_FILL_NT;
   const int W = A.W, ov = A.overlap, n = A.n_windows;
   const int M = W + (n - 1) * ov;
@@ -88,7 +130,6 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
     S[i] = v;
   }
   for (int i = tid; i < n2 / 16; i += nt) act[i] = 0u;   // (act and claim)
-  for (int i = tid; i < n2 / 64; i += nt) cblk[i] = 0;
   __syncthreads();
 #ifdef NMX_FILL_PROFILE
   tp1 = clock64();
@@ -128,8 +169,9 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
   if (tid < 64) {   // ---- the walk: one wave, no barriers (LDS operations of one wave complete in order) ----
     const int lane = tid;
     const long long sidx = (long long)c * A.n_bands + bi;
-    const int nblk = n2 / 64, per = (nblk + 63) / 64;   // blocks per lane (<= 8)
+    const int nw64 = n2 / 64;
     long long total = 0;
+    int pa = 0x7fffffff, ra_prev = 0;   // the rank pointer (hop 0: nothing is 'below' it)
     // the slots of the hops travel from the scratch list to LDS in chunks of `nh` hops (one burst of pipelined loads
     // every nh hops instead of one global-memory round trip per hop)
     const int nh = ov <= NMX_FILL_CHUNK ? NMX_FILL_CHUNK / ov : 0;
@@ -141,12 +183,13 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
       wl = clock64();
 #endif
       const int n_new = h ? ov : W;
+      int below = 0;   // this hop's arrivals below the rank pointer
       if (h == 0 || nh == 0) {
         const int off = h ? W + (h - 1) * ov : 0;
         for (int t = lane; t < n_new; t += 64) {
           const int p = (int)sl[off + t];
           atomicOr(&act[p >> 5], 1u << (p & 31));
-          atomicAdd(&cblk[p >> 6], 1);
+          below += __popcll(__ballot(p < pa));
         }
       } else {
         const int hc = (h - 1) % nh;
@@ -158,32 +201,15 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
         for (int t = lane; t < ov; t += 64) {
           const int p = (int)sq[hc * ov + t];
           atomicOr(&act[p >> 5], 1u << (p & 31));
-          atomicAdd(&cblk[p >> 6], 1);
+          below += __popcll(__ballot(p < pa));
         }
       }
       total += n_new;
+      below = __builtin_amdgcn_readfirstlane(below);   // (lane 0 took part in every iteration above)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #ifdef NMX_FILL_PROFILE
       { const long long t_ = clock64(); wa += t_ - wl; wl = t_; }
 #endif
-      // running counts over this lane's blocks, exclusive scan of the lane totals
-      int pre[8], tot = 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int b = per * lane + i;
-        tot += (i < per && b < nblk) ? cblk[b] : 0;
-        pre[i] = tot;
-      }
-      int incl = tot;   // inclusive scan of the lane totals on the DPP path (no LDS round trips)
-#define NMX_FILL_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, incl, ctrl, rmask, 0xf, false)
-      incl += NMX_FILL_DPP(0x111, 0xf);   // row_shr:1
-      incl += NMX_FILL_DPP(0x112, 0xf);   // row_shr:2
-      incl += NMX_FILL_DPP(0x114, 0xf);   // row_shr:4
-      incl += NMX_FILL_DPP(0x118, 0xf);   // row_shr:8
-      incl += NMX_FILL_DPP(0x142, 0xa);   // row_bcast:15
-      incl += NMX_FILL_DPP(0x143, 0xc);   // row_bcast:31
-#undef NMX_FILL_DPP
-      const int base = incl - tot;
       const long long m = total < (long long)A.n_ring ? total : (long long)A.n_ring;
       const double pos = A.q * (double)(m - 1);
       const long long lo_q = (long long)floor(pos);
@@ -192,9 +218,12 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
       { const long long t_ = clock64(); wb += t_ - wl; wl = t_; }
 #endif
       const int ra = (int)(m - 1 - lo_q);
-      int pb, dummy;
-      const int pa = nmx_fill_select(act, pre, base, tot, per, ra, lane, &pb);
-      if (have_hi && pb < 0) pb = nmx_fill_select(act, pre, base, tot, per, ra - 1, lane, &dummy);
+      // p held rank ra_prev; the arrivals below it moved it to rank ra_prev + below
+      const int k = h ? ra - (ra_prev + below) : ra + 1;
+      if (k > 0) pa = nmx_fill_forward(act, h ? pa : -1, k, lane, nw64);
+      else if (k < 0) pa = nmx_fill_backward(act, pa, -k, lane, nw64);
+      ra_prev = ra;
+      const int pb = have_hi ? nmx_fill_backward(act, pa, 1, lane, nw64) : 0;
       if (lane == 0)
         A.thr[((long long)h * A.n_channels + c) * A.n_bands + bi] =
             nmx_lerp_thr((double)S[pa], have_hi ? (double)S[pb] : 0.0, pos - (double)lo_q, have_hi);
