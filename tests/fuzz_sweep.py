@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Sweep of the two randomised-settings generators (tests/parity_cases.py) over many seeds on the GPU library; prints
 one line per failing seed.  Not collected by pytest (test infrastructure, imports the oracle):
-    python tests/fuzz_sweep.py 1000 1300          # seeds [1000, 1300) of the four generators"""
+    python tests/fuzz_sweep.py 1000 1300          # seeds [1000, 1300) of the five generators"""
 import os
 import sys
 import time
@@ -21,12 +21,14 @@ def main(lo, hi, budget_s=1500.0):
         lib = _lib.NmxLibrary(ge.build_emu())
     else:
         lib = _lib.get_library()
-    only = os.environ.get("NMX_FUZZ_ONLY")   # "narrow" / "wide" / "channels" / "bursts"
+    only = os.environ.get("NMX_FUZZ_ONLY")   # "narrow" / "wide" / "channels" / "bursts" / "windows"
     t0 = time.time()
     n = bad = 0
     for seed in range(lo, hi):
         for name, fn in (("narrow", pc.case_random_settings), ("wide", pc.case_random_settings_wide),
-                         ("channels", pc.case_random_channel_tables), ("bursts", pc.case_random_burst_streams)):
+                         ("channels", pc.case_random_channel_tables), ("bursts", pc.case_random_burst_streams),
+                         ("windows", pc.case_random_window_by_window),
+                         ("windows_wide", lambda lib, seed: pc.case_random_window_by_window(lib, seed, wide=True))):
             if only and name != only:
                 continue
             if time.time() - t0 > budget_s:

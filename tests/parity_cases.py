@@ -1484,3 +1484,41 @@ def case_random_burst_streams(lib, seed):
         n_bad, rep, _ = parity.compare(eng.keys, got[i], list(want.values()), s, sfreq, 40.0, W, verifier=ver)
         assert n_bad == 0, f"{what}; hop {i} (history full from hop {n_fill})\n{rep}"
     eng.close()
+
+
+def case_random_window_by_window(lib, seed, wide=False):
+    """The reference's real-time loop hands ONE window per call to `DataProcessor.process`; the batch driver hands all
+    hops of a recording to the library at once.  Both are the same kernels and the same carried state (burst history,
+    Kalman filters, normalisers), so for a random settings point the rows must agree BIT FOR BIT -- with the feature
+    normaliser switched on (its history is part of the state)."""
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.data_processor import DataProcessor
+    from py_neuromodulation_amd.stream import Stream
+
+    if wide:   # (+ resampling, pre-processing filters, raw normalisation, Kalman, every normaliser method)
+        s, sfreq, data, line, _ = random_settings_wide(seed)
+    else:
+        s, sfreq, data, line = random_settings(seed)
+    s = type(s)(**s.to_dict())
+    s.postprocessing.feature_normalization = True
+    if not wide:
+        s.feature_normalization_settings.normalization_time_s = 1.0
+    data = data.astype(np.float32).astype(np.float64)
+    try:
+        st = Stream(sfreq, data=data, settings=s, line_noise=line, lib=lib)
+        df = st.run(save_csv=False)
+    except (ValueError, IndexError, NotImplementedError) as e:
+        return f"not runnable: {e}"
+    from oracle import nm_oracle as orc   # (the schedule only)
+
+    starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    if len({int(b - a) for a, b in zip(starts, ends)}) != 1:
+        return "ragged window lengths: one processor per length in the batch driver"
+    dp = DataProcessor(sfreq=sfreq, settings=s, channels=chmod.get_default_channels_from_data(data), line_noise=line,
+                       lib=lib)
+    cols = [c for c in df.columns if c != "time"]
+    got = df[cols].to_numpy(float)
+    for i, (a, b) in enumerate(zip(starts, ends)):
+        row = dp.process(data[:, a:b])
+        assert list(row) == cols
+        np.testing.assert_array_equal(np.array(list(row.values())), got[i], err_msg=f"seed {seed} hop {i}")

@@ -689,6 +689,11 @@ def test_random_burst_streams_equal_oracle(gpu_lib, seed):
     pc.case_random_burst_streams(gpu_lib, seed)
 
 
+@pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS[:20])
+def test_random_settings_window_by_window_equals_batch(gpu_lib, seed):
+    pc.case_random_window_by_window(gpu_lib, seed)
+
+
 def test_stream_output_files(gpu_lib, tmp_path):
     pc.case_stream_output_files(gpu_lib, tmp_path)
 

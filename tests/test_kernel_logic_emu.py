@@ -144,3 +144,8 @@ def test_random_channel_tables_stream_equals_oracle(emu_lib, seed):
 @pytest.mark.parametrize("seed", pc.BURST_STREAM_SEEDS[:6])
 def test_random_burst_streams_equal_oracle(emu_lib, seed):
     pc.case_random_burst_streams(emu_lib, seed)
+
+
+@pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS[:8])
+def test_random_settings_window_by_window_equals_batch(emu_lib, seed):
+    pc.case_random_window_by_window(emu_lib, seed)
