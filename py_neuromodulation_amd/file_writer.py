@@ -116,12 +116,17 @@ def save_features(df, out_dir="", prefix: str = "") -> Path:
     return path
 
 
-def save_channels(channels, out_dir="", prefix: str = "") -> Path:
-    out_dir = Path.cwd() if not out_dir else Path(out_dir)
-    path = out_dir / prefix / ("channels.csv" if not prefix else prefix + "_channels.csv")
-    path.parent.mkdir(parents=True, exist_ok=True)
+def channels_csv_text(channels) -> str:
     # utils/io.py:234-253 writes through pyarrow.csv: strings (and the header) quoted, numbers bare
     import csv
 
-    channels.to_csv(path, index=False, quoting=csv.QUOTE_NONNUMERIC, lineterminator="\n")
+    return channels.to_csv(None, index=False, quoting=csv.QUOTE_NONNUMERIC, lineterminator="\n")
+
+
+def save_channels(channels, out_dir="", prefix: str = "", text: str | None = None) -> Path:
+    out_dir = Path.cwd() if not out_dir else Path(out_dir)
+    path = out_dir / prefix / ("channels.csv" if not prefix else prefix + "_channels.csv")
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with open(path, "w", newline="") as f:
+        f.write(text if text is not None else channels_csv_text(channels))
     return path

@@ -358,7 +358,16 @@ class NMSettings(_Node):
             raise ValueError("File format not supported.")
         return NMSettings(**d)
 
-    def save(self, out_dir=".", prefix: str = "", format: str = "yaml") -> None:
+    def to_yaml_text(self) -> str:
+        import yaml
+
+        # libyaml's emitter when PyYAML was built with it (same text, a few ms less per Stream.run)
+        dumper = getattr(yaml, "CSafeDumper", None) or yaml.SafeDumper
+        return yaml.dump(self.to_dict(), default_flow_style=None, Dumper=dumper)
+
+    def save(self, out_dir=".", prefix: str = "", format: str = "yaml", text: str | None = None) -> None:
+        """``text``: the serialised settings if the caller already has them (Stream.run re-uses the text of its
+        previous run while the settings are unchanged)."""
         filename = f"{prefix}_SETTINGS.{format}" if prefix else f"SETTINGS.{format}"
         out = Path(out_dir) / prefix / filename
         out.parent.mkdir(parents=True, exist_ok=True)
@@ -366,8 +375,4 @@ class NMSettings(_Node):
             if format == "json":
                 json.dump(self.to_dict(), f, indent=4)
             else:
-                import yaml
-
-                # libyaml's emitter when PyYAML was built with it (same text, a few ms less per Stream.run)
-                dumper = getattr(yaml, "CSafeDumper", None) or yaml.SafeDumper
-                yaml.dump(self.to_dict(), f, default_flow_style=None, Dumper=dumper)
+                f.write(text if text is not None else self.to_yaml_text())

@@ -176,5 +176,11 @@ class Stream:
         sidecar = {"original_fs": self.sfreq, "final_fs": self.data_processor.sfreq_raw,
                    "sfreq": float(self.settings.sampling_rate_features_hz), "sess_right": self.sess_right}
         fw.save_sidecar(sidecar, out_dir, experiment_name)
-        self.settings.save(out_dir or Path.cwd(), experiment_name)
-        fw.save_channels(self.channels, out_dir, experiment_name)
+        # the serialised settings / channel table of the previous run are re-used while both are unchanged
+        token = self._settings_token()
+        cache = getattr(self, "_after_text", None)
+        if cache is None or cache[0] != token:
+            cache = (token, self.settings.to_yaml_text(), fw.channels_csv_text(self.channels))
+            self._after_text = cache
+        self.settings.save(out_dir or Path.cwd(), experiment_name, text=cache[1])
+        fw.save_channels(self.channels, out_dir, experiment_name, text=cache[2])
