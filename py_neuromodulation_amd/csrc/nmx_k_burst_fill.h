@@ -134,15 +134,28 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
 #ifdef NMX_FILL_PROFILE
   tp1 = clock64();
 #endif
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < n2 / 2; t += nt) {   // one compare-exchange per thread and step: pair (i, i + j)
+  // Bitonic sort, one compare-exchange per thread and step: pair (i, i + j).  A wave's 64 consecutive pairs of a step
+  // with j <= 64 lie inside ONE 128-element group, the same group for every such step: those steps need no workgroup
+  // barrier (the LDS operations of one wave complete in order), only the steps with j >= 128 exchange between waves.
+  for (int k = 2; k <= n2; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= 128; j >>= 1) {
+      for (int t = tid; t < n2 / 2; t += nt) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
         const float a = S[i], b = S[l];
         if (((i & k) == 0) ? (a < b) : (a > b)) { S[i] = b; S[l] = a; }
       }
       __syncthreads();
     }
+    for (int t = tid; t < n2 / 2; t += nt)        // this wave's group for pair block t: steps j = min(k / 2, 64) .. 1
+      for (int jj = j; jj > 0; jj >>= 1) {
+        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l = i + jj;
+        const float a = S[i], b = S[l];
+        if (((i & k) == 0) ? (a < b) : (a > b)) { S[i] = b; S[l] = a; }
+      }
+    if (k >= 128) __syncthreads();
+  }
+  __syncthreads();
 #ifdef NMX_FILL_PROFILE
   tp2 = clock64();
 #endif
