@@ -260,3 +260,60 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
   for (int i = tid; i < keep; i += nt) gtop[i] = S[i];
 }
 #endif
+
+#ifdef NMX_HOST_EMU
+// Single-thread form of the same walk for the CPU logic tests (tests/emu): sort once, slot look-up with the claim
+// mask, arrival mask and the MOVING rank pointer -- the steps of nmx_burst_fill_item without the wave mechanics.
+#include <algorithm>
+#include <functional>
+inline void nmx_burst_fill_item_emu(const NmxBurstThrArgs& A, int c, int bi) {
+  const int W = A.W, ov = A.overlap, n = A.n_windows;
+  const int M = W + (n - 1) * ov;
+  const long long row = (long long)A.n_channels * A.n_bands * W;
+  const float* e0 = A.env + ((long long)c * A.n_bands + bi) * W;
+  std::vector<float> arr(M);
+  for (int i = 0; i < M; ++i) {
+    if (i < W) arr[i] = e0[i];
+    else { const int h = 1 + (i - W) / ov, o = (i - W) - (h - 1) * ov; arr[i] = e0[(long long)h * row + (W - ov) + o]; }
+  }
+  std::vector<float> S(arr);
+  std::sort(S.begin(), S.end(), std::greater<float>());
+  std::vector<char> claim(M, 0), act(M, 0);
+  std::vector<int> slot(M);
+  for (int i = 0; i < M; ++i) {
+    int lo = 0, hi = M;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] > arr[i]) lo = mid + 1; else hi = mid; }
+    while (claim[lo]) ++lo;
+    claim[lo] = 1;
+    slot[i] = lo;
+  }
+  auto forward = [&](int p, int k) { while (k > 0) { ++p; if (act[p]) --k; } return p; };
+  auto backward = [&](int p, int k) { while (k > 0) { --p; if (act[p]) --k; } return p; };
+  long long total = 0;
+  int pa = 0x7fffffff, ra_prev = 0;
+  for (int h = 0; h < n; ++h) {
+    const int n_new = h ? ov : W, off = h ? W + (h - 1) * ov : 0;
+    int below = 0;
+    for (int t = 0; t < n_new; ++t) { const int p = slot[off + t]; act[p] = 1; below += p < pa; }
+    total += n_new;
+    const long long m = total < (long long)A.n_ring ? total : (long long)A.n_ring;
+    const double pos = A.q * (double)(m - 1);
+    const long long lo_q = (long long)floor(pos);
+    const bool have_hi = lo_q + 1 <= m - 1;
+    const int ra = (int)(m - 1 - lo_q);
+    const int k = h ? ra - (ra_prev + below) : ra + 1;
+    if (k > 0) pa = forward(h ? pa : -1, k);
+    else if (k < 0) pa = backward(pa, -k);
+    ra_prev = ra;
+    const int pb = have_hi ? backward(pa, 1) : 0;
+    A.thr[((long long)h * A.n_channels + c) * A.n_bands + bi] =
+        nmx_lerp_thr((double)S[pa], have_hi ? (double)S[pb] : 0.0, pos - (double)lo_q, have_hi);
+  }
+  const long long sidx = (long long)c * A.n_bands + bi;
+  A.counts[2 * sidx] = total;
+  A.counts[2 * sidx + 1] = (long long)n;
+  float* gtop = A.top + sidx * A.K;
+  const int keep = M < A.K ? M : A.K;
+  for (int i = 0; i < keep; ++i) gtop[i] = S[i];
+}
+#endif

@@ -16,6 +16,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bank_w64.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_bursts.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_burst_fill.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_kalman.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_norm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
@@ -91,6 +92,9 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int, s
 static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size_t lds, be_stream_t, long long = -1) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_burst_thr_item<1>(A, it / A.n_bands, it % A.n_bands, sm.data());
+}
+static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short*, be_stream_t) {
+  for (int it = 0; it < n_items; ++it) nmx_burst_fill_item_emu(A, it / A.n_bands, it % A.n_bands);
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);

@@ -149,3 +149,37 @@ def test_random_burst_streams_equal_oracle(emu_lib, seed):
 @pytest.mark.parametrize("seed", pc.RANDOM_SETTINGS_SEEDS[:8])
 def test_random_settings_window_by_window_equals_batch(emu_lib, seed):
     pc.case_random_window_by_window(emu_lib, seed)
+
+
+def test_burst_fill_walk_equals_workgroup_walk(emu_lib, monkeypatch):
+    """The sort-once walk of a fresh stream's fill phase (nmx_k_burst_fill.h: slot look-up with the claim mask, arrival
+    mask, moving rank pointer -- here its single-thread form) against the per-hop merge walk: identical burst features
+    over a stream that crosses the point where the 3 s history is full, in one batch and in uneven batches, with a
+    quantised channel (runs of equal values)."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.bursts_settings.time_duration_s = 3
+    s = s.validate()
+    C, W, hop, n = 3, 1000, 100, 80
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((C, W + (n - 1) * hop)) * 20).astype(np.float32)
+    x[2] = np.round(x[2])
+    ch = [f"c{i}" for i in range(C)]
+    starts = np.arange(n) * hop
+
+    def run(fill, plan):
+        monkeypatch.setenv("NMX_THR_FILL", "1" if fill else "0")
+        eng = HotPathEngine(s, ch, 1000.0, lib=emu_lib, features=["bursts"], bank_taps=None)
+        out, i = [], 0
+        for k in plan:
+            out.append(eng.process_batch(x, starts[i:i + k]))
+            i += k
+        eng.close()
+        return np.concatenate(out)
+
+    want = run(False, [n])
+    assert not np.isnan(want).any()
+    for plan in ([n], [5, 1, n - 6], [30, 50]):
+        np.testing.assert_array_equal(run(True, plan), want)
