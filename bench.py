@@ -276,9 +276,33 @@ def main() -> None:
 
     import torch
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    forced = "NMX_BENCH_FORCE_DEVICE" in os.environ   # (tests: several ranks on one GPU, gloo only)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over
+        # RCCL) -- never report a 1-GPU number under an N-GPU label
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and not forced:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} HIP device(s) visible on this node")
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if world > 1 and not forced and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} HIP device(s) visible")
     # one process per GPU; NMX_BENCH_FORCE_DEVICE lets a 1-GPU box exercise the N > 1 code path
     dev_index = int(os.environ.get("NMX_BENCH_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
@@ -287,8 +311,6 @@ def main() -> None:
         import torch.distributed as dist
 
         dist.init_process_group(args.backend)
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if args.config != "headline":
         run_config(args, torch, dist if world > 1 else None, world, rank, dev, dev_index)
         if world > 1:
@@ -366,8 +388,9 @@ def main() -> None:
         achieved = bank_bytes / (bank_ms * 1e-3) / 1e9 if bank_ms > 0 else 0.0
         kernel = eng.kernels(3)   # what the plan launched in the FIR-bank stage of the last step
         traffic = traffic_at = None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():
+        tfiles = sorted((ROOT / "profiles").glob("r[0-9][0-9]_hbm_traffic.json"))   # newest round's PMC passes
+        tfile = tfiles[-1] if tfiles else None
+        if tfile is not None:
             try:
                 doc = json.loads(tfile.read_text())
                 hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == kernel]

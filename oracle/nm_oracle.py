@@ -726,15 +726,25 @@ class SharpwaveAnalyzer:
 # --------------------------------------------------------------------------------------
 
 
-def notch_design(sfreq: float, line_noise: float, notch_width: float = 3.0,
-                 trans_bandwidth: float = 6.8):
-    """filter/notch_filter.py:25-76: band-stop bank at k * line_noise, L = int(sfreq - 1)."""
-    freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
+def notch_design(sfreq: float, line_noise, notch_width=3.0, trans_bandwidth: float = 6.8, freqs=None):
+    """filter/notch_filter.py:25-76: band-stop bank at `freqs` (default k * line_noise), L = int(sfreq - 1);
+    notch_width None -> freqs / 200, one width, or one per notch (:44-56)."""
+    if freqs is None:
+        freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
     if freqs.size > 0 and freqs[-1] >= sfreq / 2:
         freqs = freqs[:-1]
     if freqs.size == 0:
         return None
-    widths = notch_width * np.ones_like(freqs)
+    if notch_width is None:
+        widths = freqs / 200.0
+    elif np.any(np.asarray(notch_width) < 0):
+        raise ValueError("notch_widths must be >= 0")
+    else:
+        widths = np.atleast_1d(notch_width)
+        if len(widths) == 1:
+            widths = widths[0] * np.ones_like(freqs)
+        elif len(widths) != len(freqs):
+            raise ValueError("notch_widths must be None, scalar, or the same length as freqs")
     tb_half = trans_bandwidth / 2.0
     lows = [f - w / 2.0 - tb_half for f, w in zip(freqs, widths)]
     highs = [f + w / 2.0 + tb_half for f, w in zip(freqs, widths)]
@@ -746,10 +756,10 @@ def notch_design(sfreq: float, line_noise: float, notch_width: float = 3.0,
 class NotchFilter:
     """filter/notch_filter.py:9-93."""
 
-    def __init__(self, sfreq, line_noise=None, taps=None) -> None:
-        if line_noise is None and taps is None:
+    def __init__(self, sfreq, line_noise=None, taps=None, freqs=None, notch_widths=3, trans_bandwidth=6.8) -> None:
+        if line_noise is None and taps is None and freqs is None:
             raise ValueError("Either line_noise or freqs must be defined")
-        self.taps = notch_design(sfreq, line_noise) if taps is None else taps
+        self.taps = notch_design(sfreq, line_noise, notch_widths, trans_bandwidth, freqs) if taps is None else taps
 
     def process(self, data):
         if self.taps is None:

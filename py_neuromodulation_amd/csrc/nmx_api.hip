@@ -136,7 +136,7 @@ static void* be_alloc(size_t n) {
 static void be_free(void* p) { (void)hipFree(p); }
 static void* be_host_alloc(size_t n) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, n, hipHostMallocPortable)   /* every device of a multi-device stream copies from it */ != hipSuccess) return nullptr;
   return p;
 }
 static void be_host_free(void* p) { (void)hipHostFree(p); }
@@ -221,6 +221,7 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<128>);
   be_allow_lds(nmx_kern_burst_thr_wide);
   be_allow_lds(nmx_kern_burst_fill);
+  be_allow_lds(nmx_kern_rawnorm_order);   // 24 * (window + hop) + 8 KiB: above 64 KiB from ~2390 samples
 }
 
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
@@ -368,6 +369,7 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, si
   nmxi_note_kernel("nmx_kern_resample");
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
+  be_init_once();
   if (A.method >= NMX_RAWNORM_MEDIAN) {
     const size_t lds = (size_t)24 * A.max_list + 8 * NMX_RAWNORM_ORDER_NT;
     hipLaunchKernelGGL(nmx_kern_rawnorm_order, dim3(A.n_channels), dim3(NMX_RAWNORM_ORDER_NT), lds, s, A);

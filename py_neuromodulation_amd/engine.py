@@ -75,21 +75,31 @@ def parallel_cast(dst: np.ndarray, src: np.ndarray) -> None:
 _STAGING: dict = {}
 
 
-def _staging(lib) -> "_Pinned":
+def _staging(lib, device: int = 0) -> "_Pinned":
     """ONE staging pool per loaded library, shared by every engine (page-locking ~170 MB costs tens of
     milliseconds -- Stream.run builds a fresh engine per run, like the reference builds a fresh
-    DataProcessor).  Engines are not re-entrant (include/nmx.h), neither is the pool."""
-    key = str(lib.path)
+    DataProcessor).  Engines are not re-entrant (include/nmx.h), neither is the pool -- one pool PER DEVICE, so
+    that the engines of a multi-device stream (one host thread each) never share a staging array.  The pool is
+    reference counted: the last open engine of (library, device) frees the page-locked memory."""
+    key = (str(lib.path), int(device))
     if key not in _STAGING:
-        _STAGING[key] = _Pinned(lib)
+        _STAGING[key] = _Pinned(lib, key)
+    _STAGING[key].users += 1
     return _STAGING[key]
+
+
+def _release_staging(pool: "_Pinned") -> None:
+    pool.users -= 1
+    if pool.users <= 0:
+        pool.close()
+        _STAGING.pop(pool.key, None)
 
 
 class _Pinned:
     """Page-locked staging arrays (nmx_host_alloc), grown on demand and reused across calls."""
 
-    def __init__(self, lib) -> None:
-        self.lib, self._bufs = lib, {}
+    def __init__(self, lib, key=None) -> None:
+        self.lib, self._bufs, self.users, self.key = lib, {}, 0, key
 
     def array(self, name: str, shape, dtype) -> np.ndarray:
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
@@ -171,7 +181,7 @@ class HotPathEngine:
         self._pinned = None
         if not dry_run:
             self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
-            self._pinned = _staging(self.lib)
+            self._pinned = _staging(self.lib, device)
 
     # ------------------------------------------------------------------------------------
     def _dptr(self, arr: np.ndarray):
@@ -458,6 +468,8 @@ class HotPathEngine:
         if getattr(self, "_plan", None) is not None and self._plan.value:
             self.lib.lib.nmx_plan_destroy(self._plan)
             self._plan = C.c_void_p()
+        if getattr(self, "_pinned", None) is not None:
+            _release_staging(self._pinned)
         self._pinned = None
 
     def __del__(self):  # pragma: no cover
@@ -500,10 +512,20 @@ class HotPathEngine:
         self._norm = norm   # keep it alive
 
     def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
-        """A page-locked array of the caller's own (lives as long as the library's staging pool): inputs /
-        ``out=`` buffers allocated here move at the full PCIe rate, asynchronously."""
-        self._n_user = getattr(self, "_n_user", 0) + 1
-        return self._pinned.array(f"user{id(self)}_{self._n_user}", tuple(shape), dtype)
+        """A page-locked array of the caller's own: inputs / ``out=`` buffers allocated here move at the full PCIe
+        rate, asynchronously.  The allocation belongs to the returned array (and its views): it is released
+        (nmx_host_free) when the last of them is garbage-collected, never handed to anybody else."""
+        import weakref
+
+        shape = tuple(int(x) for x in shape)
+        count = int(np.prod(shape))
+        n = max(count * np.dtype(dtype).itemsize, 1)
+        p = C.c_void_p()
+        lib = self.lib
+        lib.check(lib.lib.nmx_host_alloc(n, C.byref(p)))
+        buf = (C.c_char * n).from_address(p.value)
+        weakref.finalize(buf, lib.lib.nmx_host_free, p.value)   # numpy keeps `buf` alive as the base of every view
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
     def process_batch(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False,
                       staged_output: bool = False, out: np.ndarray | None = None):

@@ -113,14 +113,32 @@ def band_pass_bank(f_ranges, sfreq: float, filter_length: float | None = None,
     return np.vstack(rows)
 
 
-def notch_bank(sfreq: float, line_noise: float, notch_width: float = 3.0,
-               trans_bandwidth: float = 6.8) -> np.ndarray | None:
-    """NotchFilter.__init__: multi band-stop at k * line_noise, length int(sfreq - 1)."""
-    freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
+def notch_bank(sfreq: float, line_noise: float | None, notch_width=3.0,
+               trans_bandwidth: float = 6.8, freqs=None) -> np.ndarray | None:
+    """NotchFilter.__init__ (filter/notch_filter.py:9-76): multi band-stop, length int(sfreq - 1), at the explicit
+    ``freqs`` or at k * line_noise; ``notch_width``: None (= freqs / 200), one width, or one per notch."""
+    if freqs is None:
+        if line_noise is None:
+            raise ValueError("Either line_noise or freqs must be defined if notch_filter is activated.")
+        freqs = np.arange(line_noise, sfreq / 2, line_noise, dtype=int)
+    else:
+        freqs = np.atleast_1d(np.asarray(freqs))
     if freqs.size > 0 and freqs[-1] >= sfreq / 2:
         freqs = freqs[:-1]
     if freqs.size == 0:
         return None
+    if notch_width is None:
+        notch_width = freqs / 200.0
+    elif np.any(np.asarray(notch_width) < 0):
+        raise ValueError("notch_widths must be >= 0")
+    else:
+        notch_width = np.atleast_1d(notch_width)
+        if len(notch_width) == 1:
+            notch_width = notch_width[0] * np.ones_like(freqs)   # (integer freqs x integer width stay integers, :50)
+        elif len(notch_width) != len(freqs):
+            raise ValueError("notch_widths must be None, scalar, or the same length as freqs")
+    freqs = np.asarray(freqs, dtype=np.float64)
+    notch_width = np.asarray(notch_width, dtype=np.float64)
     nyq = float(sfreq) / 2.0
     tb = trans_bandwidth / 2.0
     lows = freqs - notch_width / 2.0 - tb     # pass-band edges below each notch

@@ -47,11 +47,8 @@ class NotchFilter:
                  notch_widths=3, trans_bandwidth: float = 6.8) -> None:
         if line_noise is None and freqs is None:
             raise ValueError("Either line_noise or freqs must be defined if notch_filter is activated.")
-        if freqs is not None:
-            raise NotImplementedError("explicit notch `freqs` are not supported; pass line_noise")
         self.sfreq = sfreq
-        self.filter_bank = fir_design.notch_bank(sfreq, line_noise, float(np.atleast_1d(notch_widths)[0]),
-                                                 trans_bandwidth)
+        self.filter_bank = fir_design.notch_bank(sfreq, line_noise, notch_widths, trans_bandwidth, freqs=freqs)
         self._engines: dict = {}
 
     def process(self, data: np.ndarray) -> np.ndarray:

@@ -22,6 +22,8 @@ import math
 from pathlib import Path
 from typing import Any
 
+import numpy as np
+
 __all__ = ["NMSettings", "FrequencyRange", "BoolSelector", "SettingsError"]
 
 
@@ -102,6 +104,10 @@ class _Node:
                 return {k: conv(x) for k, x in v.items()}
             if isinstance(v, (list, tuple)):
                 return [conv(x) for x in v]
+            if isinstance(v, np.generic):      # numpy scalars assigned by callers: builtins, like pydantic's coercion
+                return v.item()
+            if isinstance(v, np.ndarray):
+                return [conv(x) for x in v.tolist()]
             return v
 
         return {k: conv(v) for k, v in self.__dict__.items()}

@@ -67,6 +67,17 @@ class ShardedStream:
                              device=self.device, window=window, lib=self._lib, channel_subset=self.shard,
                              local_inputs=self.local_input, dry_run=dry_run)
 
+    def _comm_device(self, group=None):
+        """Where the tensors of a collective must live: this rank's GPU under the "nccl" backend (= RCCL, which
+        only moves device memory), the host under gloo."""
+        import torch
+        import torch.distributed as dist
+
+        if str(dist.get_backend(group)).lower() == "nccl":
+            torch.cuda.set_device(self.device)   # the object collectives (NaN mask, feature table) stage here too
+            return torch.device("cuda", self.device)
+        return torch.device("cpu")
+
     def group_sums(self, local_data: np.ndarray, group=None) -> np.ndarray:
         """[n_groups, T] float64: sum over each group's member rows of nan_to_num(x), partial sums of the rows
         this rank OWNS all-reduced over the ranks (the one exchange step of the sharded path)."""
@@ -82,9 +93,9 @@ class ShardedStream:
             if idx:
                 part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float64)).sum(axis=0)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and part.size:
-            t = torch.from_numpy(part)
+            t = torch.from_numpy(part).to(self._comm_device(group))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            part = t.numpy()
+            part = t.cpu().numpy()
         return part
 
     def _gather_mask(self, mask_local: np.ndarray, n_all: int, group=None) -> np.ndarray:
@@ -96,6 +107,7 @@ class ShardedStream:
         mine = (np.asarray(self.owned_rows, np.int64), mask_local[:, [pos[j] for j in self.owned_rows]].astype(np.uint8))
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             parts = [None] * dist.get_world_size(group)
+            self._comm_device(group)
             dist.all_gather_object(parts, mine, group=group)
         else:
             parts = [mine]
@@ -131,6 +143,76 @@ class ShardedStream:
         rows = dp.postprocess_batch(out, mask_all if mask_all.any() else np.zeros((len(out), len(dp.ch_names_used)), bool),
                                     normalised=dp._norm_in_engine)
         return list(dp.keys), rows, times
+
+
+class MultiDeviceProcessor:
+    """Single-process form of the channel shard: one plan per device, one host thread per plan
+    (ctypes drops the GIL for the duration of every libnmx call, so the launch sequences, the host <-> device
+    copies and the waits of all devices overlap).  Every device is handed the whole recording and applies its own
+    rows of the folded (re-reference x channel-pick) matrix -- no exchange step; the feature normaliser is per
+    column, so each device normalises its own columns.  Same surface as ``DataProcessor`` for what ``Stream``
+    uses: ``keys`` (reference order over ALL channels), ``process``, ``process_batch``, ``reset``."""
+
+    def __init__(self, sfreq, settings, channels, line_noise=None, devices=(0,), window=None, lib=None,
+                 verbose: bool = False, resample_features_at_new_rate: bool = False) -> None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.settings = NMSettings.load(settings)
+        self.channels = chmod.load_channels(channels)
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
+        names, _, _ = chmod.channel_info(self.channels)
+        kw = dict(line_noise=line_noise, verbose=False, window=window, lib=lib,
+                  resample_features_at_new_rate=resample_features_at_new_rate)
+        layout = DataProcessor(sfreq, self.settings, self.channels, dry_run=True, **kw)
+        self.keys = list(layout.keys)
+        self.sfreq_raw = layout.sfreq_raw
+        self.ch_names_used = layout.ch_names_used
+        col = {k: i for i, k in enumerate(self.keys)}
+        self.parts, self._cols = [], []
+        for i, dev in enumerate(devices):
+            shard = channel_shard(len(names), len(devices), i)
+            if not len(shard):
+                continue   # more devices than channels
+            dp = DataProcessor(sfreq, self.settings, self.channels, device=dev, channel_subset=shard, **kw)
+            self.parts.append(dp)
+            self._cols.append(np.array([col[k] for k in dp.keys], dtype=np.int64))
+        self.devices = devices[:len(self.parts)]
+        self.verbose = verbose
+        self.settings_token = None
+        self._norm_in_engine = all(p._norm_in_engine for p in self.parts)
+        self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+
+    @property
+    def engine(self):
+        return self.parts[0].engine   # window length / input shape are the same on every device
+
+    def reset(self) -> None:
+        for p in self.parts:
+            p.reset()
+
+    def _merge(self, rows) -> np.ndarray:
+        out = np.full((rows[0].shape[0], len(self.keys)), np.nan)
+        for cols, r in zip(self._cols, rows):
+            out[:, cols] = r
+        return out
+
+    def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
+        rows = list(self._pool.map(lambda p: p.process_batch(data, starts), self.parts))
+        return self._merge(rows)
+
+    def process(self, data: np.ndarray) -> dict:
+        parts = list(self._pool.map(lambda p: p.process(data), self.parts))
+        merged = {}
+        for d in parts:
+            merged.update(d)
+        return {k: merged[k] for k in self.keys}
+
+    def close(self) -> None:
+        for p in self.parts:
+            p.engine.close()
+        self._pool.shutdown(wait=False)
 
 
 def merge_shards(all_keys: list[str], shards) -> np.ndarray:

@@ -25,7 +25,10 @@ class Stream:
     def __init__(self, sfreq: float, channels=None, data=None, settings=None,
                  line_noise: float | None = 50, sampling_rate_features_hz: float | None = None,
                  path_grids=None, coord_names=None, coord_list=None, verbose: bool = False,
-                 device: int = 0, lib=None, resample_features_at_new_rate: bool = False) -> None:
+                 device: int = 0, lib=None, resample_features_at_new_rate: bool = False,
+                 devices=None) -> None:
+        """``devices=[0, 1, ...]``: the channels are sharded in contiguous blocks over these GPUs inside this one
+        process (one plan and one host thread per device, sharding.MultiDeviceProcessor); ``device`` otherwise."""
         self.settings = NMSettings.load(settings)
         if channels is None and data is not None:
             channels = chmod.get_default_channels_from_data(data)
@@ -46,6 +49,7 @@ class Stream:
         self.line_noise = line_noise
         self.verbose = verbose
         self.device = device
+        self.devices = [int(d) for d in devices] if devices is not None else None
         self._resample_new_rate = resample_features_at_new_rate
         self._lib = lib  # None = the product library (libnmx.so); tests may inject a binding
         self.data = data
@@ -60,12 +64,27 @@ class Stream:
 
         return json.dumps(self.settings.to_dict(), sort_keys=True, default=str) + self.channels.to_json()
 
+    def _processor_token(self):
+        """Everything a DataProcessor is built from: the settings / channel table AND the stream attributes the
+        reference reads afresh on every run (stream/stream.py:233-242 builds a new DataProcessor per run)."""
+        return (self._settings_token(), repr(self.line_noise), repr(self.sfreq), bool(self._resample_new_rate),
+                int(self.device), tuple(self.devices or ()), id(self._lib))
+
     def _make_processor(self, window):
+        if self.devices is not None and len(self.devices) > 1:
+            from .sharding import MultiDeviceProcessor
+
+            dp = MultiDeviceProcessor(self.sfreq, self.settings, self.channels, line_noise=self.line_noise,
+                                      devices=self.devices, window=window, lib=self._lib, verbose=self.verbose,
+                                      resample_features_at_new_rate=self._resample_new_rate)
+            dp.settings_token = self._processor_token()
+            return dp
         dp = DataProcessor(sfreq=self.sfreq, settings=self.settings, channels=self.channels,
-                           line_noise=self.line_noise, verbose=self.verbose, device=self.device,
+                           line_noise=self.line_noise, verbose=self.verbose,
+                           device=self.devices[0] if self.devices else self.device,
                            window=window, lib=self._lib,
                            resample_features_at_new_rate=self._resample_new_rate)
-        dp.settings_token = self._settings_token()
+        dp.settings_token = self._processor_token()
         return dp
 
     def _handle_data(self, data) -> np.ndarray:
@@ -117,13 +136,15 @@ class Stream:
             groups = sorted(set(int(x) for x in lens))
             if len(groups) > 1 and "bursts" in st.features.get_enabled():
                 raise NotImplementedError("bursts with a non-integer hop (ragged windows) is not supported")
+            if len(groups) > 1 and self.devices is not None and len(self.devices) > 1:
+                raise NotImplementedError("ragged windows (non-integer hop) are not supported on several devices")
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
             # processor per window length.  The processor built by __init__ (or by the previous run) is
             # reused with its state reset when it fits -- same results, no second plan build.
             procs = {}
             for w in groups:
                 dp = self.data_processor
-                if (len(groups) == 1 and dp is not None and dp.engine.W_in == w and dp.settings_token == self._settings_token()):
+                if (len(groups) == 1 and dp is not None and dp.engine.W_in == w and dp.settings_token == self._processor_token()):
                     dp.reset()
                     procs[w] = dp
                 else:

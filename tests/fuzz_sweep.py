@@ -21,6 +21,9 @@ def main(lo, hi, budget_s=1500.0):
         lib = _lib.NmxLibrary(ge.build_emu())
     else:
         lib = _lib.get_library()
+    import tempfile
+
+    os.chdir(tempfile.mkdtemp(prefix="nmx_fuzz_"))   # Stream.run leaves its side-car files under the working directory
     only = os.environ.get("NMX_FUZZ_ONLY")   # "narrow" / "wide" / "channels" / "bursts" / "windows"
     t0 = time.time()
     n = bad = 0

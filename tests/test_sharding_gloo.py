@@ -9,6 +9,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
 
@@ -22,9 +23,16 @@ from py_neuromodulation_amd import NMSettings, _lib
 from py_neuromodulation_amd import channels as chmod
 from py_neuromodulation_amd.sharding import ShardedStream, gather_dataframe, global_keys, channel_shard
 
-dist.init_process_group("gloo")
+backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
+rank_env = int(os.environ["LOCAL_RANK"])
+if backend == "nccl":          # the real target: RCCL, one GPU per rank, the product library
+    import torch
+    torch.cuda.set_device(rank_env)
+    lib, dev = _lib.get_library(), rank_env
+else:                          # CPU tier: gloo + the kernel-logic emulator
+    lib, dev = _lib.NmxLibrary(ge.build_emu()), 0
+dist.init_process_group(backend)
 rank, world = dist.get_rank(), dist.get_world_size()
-lib = _lib.NmxLibrary(ge.build_emu())
 s = NMSettings.get_default()
 s.features.bandpass_filter = True
 s.preprocessing = ["notch_filter", "re_referencing"]
@@ -32,7 +40,7 @@ s.postprocessing.feature_normalization = False
 rng = np.random.default_rng(7)
 data = rng.standard_normal((5, 2500)) * 20 + rng.uniform(-100, 100, (5, 1))
 ch = chmod.get_default_channels_from_data(data)
-st = ShardedStream(1000.0, ch, s, line_noise=50, rank=rank, world_size=world, device=0, lib=lib)
+st = ShardedStream(1000.0, ch, s, line_noise=50, rank=rank, world_size=world, device=dev, lib=lib)
 keys, rows, times = st.run(data)
 assert len(keys) == len(set(keys))
 allk = global_keys(1000.0, s, ch)
@@ -48,7 +56,7 @@ ch2.loc[3, "type"] = "lfp"; ch2.loc[3, "rereference"] = "ch0"; ch2.loc[3, "new_n
 ch2.loc[4, "type"] = "lfp"; ch2.loc[4, "rereference"] = "ch3&ch1"; ch2.loc[4, "new_name"] = "ch4_ch3ch1"
 data2 = data.copy()
 data2[1, 1200:1210] = np.nan
-st2 = ShardedStream(1000.0, ch2, s, line_noise=50, rank=rank, world_size=world, device=0, lib=lib, local_input=True)
+st2 = ShardedStream(1000.0, ch2, s, line_noise=50, rank=rank, world_size=world, device=dev, lib=lib, local_input=True)
 assert set(st2.owned_rows) <= set(st2.local_rows) and len(st2.local_rows) < 5
 keys2, rows2, times2 = st2.run(data2[st2.local_rows])
 df2 = gather_dataframe(keys2, rows2, times2, global_keys(1000.0, s, ch2))
@@ -59,7 +67,77 @@ dist.destroy_process_group()
 '''
 
 
+def _device_count() -> int:
+    try:
+        from py_neuromodulation_amd import _lib
+
+        return _lib.get_library().device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_device_count() < 2, reason="the RCCL path needs two GPUs (one rank per GPU)")
+def test_two_rank_channel_shards_nccl(tmp_path):
+    """The SAME worker with backend="nccl" (= RCCL) on two GPUs and the product library: the group-sum all-reduce
+    and the mask all-gather run on device tensors."""
+    _run_two_ranks(tmp_path, "nccl", 29519)
+
+
 def test_two_rank_channel_shards_equal_single_process(tmp_path):
+    _run_two_ranks(tmp_path, "gloo", 29517)
+
+
+@pytest.mark.gpu
+def test_single_process_multi_device_stream_on_the_gpu():
+    """The same on the product library: distinct GPUs when the box has them, else two plans on GPU 0 driven by two
+    host threads at once (what a 1-GPU box can show: the plans, staging pools and streams do not interfere)."""
+    from py_neuromodulation_amd import _lib
+
+    lib = _lib.get_library()
+    _multi_device_case(lib, [0, 1] if lib.device_count() >= 2 else [0, 0])
+
+
+def test_single_process_multi_device_stream_equals_single_device():
+    """Stream(devices=[...]): one plan + one host thread per device inside one process.  CPU tier: three
+    plans of the kernel-logic emulator; the merged table must equal the one-plan stream column for column,
+    including a z-score normaliser (per column, so sharding it is exact) and the NaN policy."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+
+    from py_neuromodulation_amd import _lib
+
+    _multi_device_case(_lib.NmxLibrary(ge.build_emu()), [0, 0, 0])
+
+
+def _multi_device_case(lib, devices):
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    s.features.bandpass_filter = True
+    s.preprocessing = ["notch_filter", "re_referencing"]
+    rng = np.random.default_rng(11)
+    data = rng.standard_normal((5, 2300)) * 20 + rng.uniform(-100, 100, (5, 1))
+    data[2, 1500:1504] = np.nan
+    os.environ["NMX_CAR_FAST"] = "0"   # same arithmetic on both sides (see below)
+    try:
+        one = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+        st = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib, devices=devices)
+        many = st.run(save_csv=False)
+        again = st.run(save_csv=False)   # the processors are reused with their state reset
+    finally:
+        del os.environ["NMX_CAR_FAST"]
+    assert list(many.columns) == list(one.columns)
+    a, b = many.to_numpy(float), one.to_numpy(float)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any()
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, equal_nan=True)
+    np.testing.assert_array_equal(again.to_numpy(float), a)
+    row = st.data_processor.process(np.nan_to_num(data[:, :1000]))
+    assert list(row) == list(one.columns)[:-1]
+
+
+def _run_two_ranks(tmp_path, backend, port):
     sys.path.insert(0, str(ROOT))
     import __graft_entry__ as ge
     import pandas as pd
@@ -74,14 +152,14 @@ def test_two_rank_channel_shards_equal_single_process(tmp_path):
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER)
     out = tmp_path / "sharded.pkl"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", str(worker), str(ROOT), str(out)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker), str(ROOT), str(out), backend]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     sharded = pd.read_pickle(out)
 
-    lib = _lib.NmxLibrary(ge.build_emu())
+    lib = _lib.get_library() if backend == "nccl" else _lib.NmxLibrary(ge.build_emu())
     s = NMSettings.get_default()
     s.features.bandpass_filter = True
     s.preprocessing = ["notch_filter", "re_referencing"]
