@@ -20,10 +20,12 @@
 
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_scan.h"
+#include "nmx_k_td.h"
 
 #ifndef NMX_HOST_EMU
 
-#define NMX_TOW_LDS_FLOATS (1000 + 1008 + 1008)
+#define NMX_TOW_LDS_FLOATS (1008 + 1008 + 1000)
+#define NMX_TOW_LDS_FLOATS_NOSTFT (1008 + 1008)
 
 // can this configuration run on the wave kernel?  (host side, called by the launcher)
 static inline bool nmx_timeosc_w1000_ok(const NmxTimeOscArgs& A) {
@@ -37,6 +39,16 @@ static inline bool nmx_timeosc_w1000_ok(const NmxTimeOscArgs& A) {
                           A.stft.half == 250)) return false;
   return A.fft.enabled || A.welch.enabled || A.stft.enabled;
 }
+
+// the persistent, prefetching kernel (nmx_wave.hip: nmx_kern_timeosc_w1000_low) takes the configurations without an STFT
+// whose bands all end below bin 100 -- the default four bands (4 - 35 Hz), BASELINE config[1]
+static inline bool nmx_timeosc_w1000_low_ok(const NmxTimeOscArgs& A) {
+  if (A.stft.enabled || !(A.fft.enabled || A.welch.enabled)) return false;
+  if (A.fft.enabled && A.fft.k_hi > 100) return false;
+  if (A.welch.enabled && A.welch.k_hi + 1 > 100) return false;
+  return true;
+}
+#define NMX_TOW_LOW_LDS_FLOATS (1008 + 1008 + 2 * 102)
 
 // NB = compile-time bound on the number of bands (4 covers the default settings: half the select / add
 // instructions per spectral value of the 8-band build)
@@ -59,39 +71,62 @@ struct NmxBandAcc {
       if (b >= n_bands) continue;
       const float tot = nmx_wave_reduce(s[b], 0.f, [](float a_, float b_) { return a_ + b_; });
       const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
-      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot / (float)cnt : NAN;
+      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot * __builtin_amdgcn_rcpf((float)cnt) : NAN;
     }
   }
 };
 
-template <int NB>
-NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float* smem) {
-  w = nmx_uniform_i(w);
-  c = nmx_uniform_i(c);
+// Rt: the window of (w, c), loads issued by the caller (or in flight: the persistent kernel issues the loads of a wave's NEXT item
+// before it works on the current one); T: the lane's twiddles.  LDS: fa[500] | fb[501] | xs[1000] (xs only with the STFT).
+// LOW: the persistent kernel's form -- no STFT, every band below bin 100 (nmx_timeosc_w1000_low_ok), the first 102
+// entries of the real-transform twiddle table in LDS at smem + 2016: NO vector-memory load inside the item (loads retire
+// in order, so one would wait for the prefetch of the next window to land first).
+template <int NB, bool LOW = false>
+NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& Rt, const NmxW500TwReg& T, float* smem) {
   const int lane = (int)(threadIdx.x & 63);
-  float* xs = smem;                              // [1000] the window, natural order
-  nmx_c2* fa = (nmx_c2*)(smem + 1000);           // [500]
-  nmx_c2* fb = (nmx_c2*)(smem + 2008);           // [501]
+  nmx_c2* fa = (nmx_c2*)smem;                    // [500]
+  nmx_c2* fb = (nmx_c2*)(smem + 1008);           // [501]
+  float* xs = smem + 2016;                       // [1000] the window, natural order
   float* out_row = A.out + (long long)w * A.n_outputs;
   const int nb = A.n_bands;
 
-  NmxScanRegs R;
-  nmx_scan_load(A, w, c, R);
-  NmxW500TwReg T;
-  T.load(A.w500_tab, lane);
-  R.sum = 0.f;
-  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) {
-    nmx_scan_emit(A, w, c, R);
-  } else if (A.welch.enabled || A.fft.enabled) {
-    float p0 = 0.f;
+  const bool spec1000 = A.fft.enabled || A.welch.enabled;
+  float wsum;
+  {
+    // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
+    const bool td = (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
+    // (always: the window sum it forms is also the NaN / infinity test of the window)
+    const bool fast = nmx_td_emit<1000>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
+    wsum = Rt.sum;
+    if (fast) {
+      if (!LOW && A.stft.enabled) {   // park the window in LDS (group 3: lanes 0..57)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p0 += (R.x[k][0] + R.x[k][1]) + (R.x[k][2] + R.x[k][3]);   // out-of-range samples are 0
-    R.sum = nmx_wave_reduce(p0, 0.f, [](float a_, float b_) { return a_ + b_; });
+        for (int k = 0; k < 4; ++k)
+          if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = Rt.x[k];
+      }
+    } else {
+      // a NaN or an infinity in the window: cleaning loads and the scalar formulation (nmx_k_scan.h)
+      NmxScanRegs R;
+      nmx_scan_load(A, w, c, R);
+      R.sum = 0.f;
+      if (td) {
+        nmx_scan_emit(A, w, c, R);
+      } else if (spec1000) {
+        float p0 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p0 += (R.x[k][0] + R.x[k][1]) + (R.x[k][2] + R.x[k][3]);   // out-of-range samples are 0
+        R.sum = nmx_wave_reduce(p0, 0.f, [](float a_, float b_) { return a_ + b_; });
+      }
+      wsum = R.sum;
+      const float mean = R.sum / 1000.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < 3 || lane < 58) {
+          if (!LOW && A.stft.enabled) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
+          if (spec1000) ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
+        }
+    }
   }
-  // park the window in LDS (group 3: lanes 0..57)
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
   NMX_WAVE_FENCE();
 
   NmxBandAcc<NB> acc;
@@ -103,19 +138,13 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
   //     multiplying by w is a three-term convolution of the spectrum,
   //         Y[k] = X'[k] / 2 - (X'[k-1] + X'[k+1]) / 4,   X'[0] = 0,  X'[-k] = conj X'[k],
   //     so no second transform and no windowed copy of the window are needed.
-  if (A.fft.enabled || A.welch.enabled) {
-    const float mean = R.sum / 1000.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < 3 || lane < 58)
-        ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
-    NMX_WAVE_FENCE();
+  if (spec1000) {
     // bins read below: up to max(k_hi) (+1 for Welch's neighbours) and their mirror images 500 - k
     const int kmax = (A.fft.enabled ? A.fft.k_hi : 0) > (A.welch.enabled ? A.welch.k_hi + 1 : 0)
                          ? A.fft.k_hi : (A.welch.enabled ? A.welch.k_hi + 1 : 0);
-    const float2* Z = (const float2*)(kmax <= 100 ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
-                                                  : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
-    const float2* twr = (A.fft.enabled ? A.fft : A.welch).fft.twr;
+    const float2* Z = (const float2*)((LOW || kmax <= 100) ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
+                                                           : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
+    const float2* twr = LOW ? (const float2*)(smem + 2016) : (A.fft.enabled ? A.fft : A.welch).fft.twr;
     auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
       const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
       if (kk == 0) return make_float2(0.f, 0.f);
@@ -126,7 +155,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
       const NmxOsc& O = A.fft;
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
-        const float2 X = k == 0 ? make_float2(R.sum, 0.f) : xbin(k);
+        const float2 X = k == 0 ? make_float2(wsum, 0.f) : xbin(k);
         const float pw = X.x * X.x + X.y * X.y;
         const float v = O.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
@@ -149,7 +178,7 @@ NMX_DEV void nmx_timeosc_w1000_item(const NmxTimeOscArgs& A, int w, int c, float
     NMX_WAVE_FENCE();
   }
   // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
-  if (A.stft.enabled) {
+  if (!LOW && A.stft.enabled) {
     const NmxOsc& O = A.stft;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 2000, 0x00020000);
     float hw[8];

@@ -15,6 +15,7 @@
 #include "nmx_k_bursts.h"
 #include "nmx_k_bank_w64.h"
 #include "nmx_k_scan.h"
+#include "nmx_k_td.h"
 #include "nmx_k_timeosc_w1000.h"
 #include "nmx_k_timeosc_w510.h"
 #include "nmx_k_sharpwave.h"
@@ -74,17 +75,107 @@ extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long 
 template <int NB>
 __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
   const int item = blockIdx.x;
-  nmx_timeosc_w1000_item<NB>(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+  const int w = nmx_uniform_i(item / A.n_channels), c = nmx_uniform_i(item % A.n_channels);
+  NmxW500TwReg T;
+  T.load(A.w500_tab, (int)(threadIdx.x & 63));
+  NmxTdRegs R;
+  nmx_td_load<1000>(A, w, c, R);
+  nmx_timeosc_w1000_body<NB>(A, w, c, R, T, nmx_smem_wave);
+}
+
+// The same without an STFT and with low bands only (nmx_timeosc_w1000_low_ok: the default 4 - 35 Hz bands, BASELINE
+// config[1]): PERSISTENT waves (one-wave workgroups, grid = what the chip holds at once) walk the items with stride
+// gridDim, and the 16-byte loads of a wave's NEXT window are issued before it works on the current one -- the HBM
+// latency of a window (4 KB per wave, distinct per item in SURVEY 8d's Mode A) hides behind the arithmetic of the item
+// instead of idling the wave (one-item-per-workgroup form: SQ_WAIT_ANY 45 % of the wave cycles).  What it takes:
+//   * vmcnt retires IN ORDER, so the item must not wait for ANY vector-memory load issued after the prefetch: the small
+//     loads of the current item (successors, row ends) go out before it, the real-transform twiddles of the bins come
+//     from a 102-entry LDS copy, nothing is spilled (3 waves per SIMD: 168 VGPRs), and the prefetch is UNCONDITIONAL
+//     (a load issued on some paths only forces s_waitcnt vmcnt(0) at the next use of anything loaded earlier);
+//   * the plan (band tables, output columns: ~100 dwords) must NOT be hoisted out of the item loop into scalar
+//     registers -- it does not fit, and spilled scalars come back as v_readlane VALU instructions (500 of them in a
+//     first build): the kernel-argument pointer is laundered once per iteration, so every use re-reads its dwords with
+//     s_load from the constant cache, as the one-item-per-workgroup kernel does.
+template <int NB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
+  typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;
+  nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+  const NmxTimeOscArgs& A = *(const NmxTimeOscArgs*)Ap;
+  const int lane = (int)(threadIdx.x & 63);
+  NmxW500TwReg T;
+  T.load(A.w500_tab, lane);
+  {
+    const float2* twr = (A.fft.enabled ? A.fft : A.welch).fft.twr;
+    float2* twl = (float2*)(nmx_smem_wave + 2016);
+    twl[lane] = twr[lane];
+    if (lane < 38) twl[64 + lane] = twr[64 + lane];
+  }
+  const int C = A.n_channels, step = (int)gridDim.x;
+  int item = (int)blockIdx.x;
+  if (item >= n_items) return;
+  NmxTdRegs R;
+  nmx_f4 Xn[4];
+  int w = nmx_uniform_i(item / C), c = nmx_uniform_i(item - w * C);
+  nmx_td_load_x<1000>(A, w, c, R);
+  NMX_WAVE_FENCE();
+#pragma nounroll
+  for (;;) {
+    const int nxt = item + step;
+    int wn = 0, cn = 0;
+    nmx_td_load_rest<1000>(A, w, c, R);
+    {
+      const int pf = nxt < n_items ? nxt : item;   // (the last iteration re-reads its own item)
+      wn = nmx_uniform_i(pf / C); cn = nmx_uniform_i(pf - wn * C);
+      NmxTdRegs Rn;
+      nmx_td_load_x<1000>(A, wn, cn, Rn);
+      Xn[0] = Rn.x[0]; Xn[1] = Rn.x[1]; Xn[2] = Rn.x[2]; Xn[3] = Rn.x[3];
+    }
+    asm volatile("" : "+s"(Ap));
+    nmx_timeosc_w1000_body<NB, true>(*(const NmxTimeOscArgs*)Ap, w, c, R, T, nmx_smem_wave);
+    NMX_WAVE_FENCE();
+    if (nxt >= n_items) break;
+    item = nxt; w = wn; c = cn;
+    R.x[0] = Xn[0]; R.x[1] = Xn[1]; R.x[2] = Xn[2]; R.x[3] = Xn[3];
+  }
 }
 
 // returns 0 when the configuration needs the generic kernel
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w1000_ok(*A)) return 0;
+  static int n_cu = 0, want = 0, low_ok = 1;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    const char* v = getenv("NMX_TOW_WAVES");
+    want = (v && atoi(v) >= 1 && atoi(v) <= 16) ? atoi(v) : 12;
+    const char* u = getenv("NMX_TOW_PERSISTENT");
+    low_ok = !(u && u[0] == '0');
+  }
+  if (low_ok && nmx_timeosc_w1000_low_ok(*A)) {
+    // resident waves per CU: 3 per SIMD (168 VGPRs).  The channel of a wave's items stays fixed -- and with it the XCD
+    // whose L2 holds the overlapping windows -- when the stride is a multiple of the channel count
+    int grid = n_cu * want;
+    const int C = A->n_channels;
+    if (grid > C && grid % C) grid -= grid % C;
+    if (grid > n_items) grid = n_items;
+    const size_t lds = (size_t)NMX_TOW_LOW_LDS_FLOATS * 4;
+    if (A->n_bands <= 4) {
+      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low<4>, dim3(grid), dim3(64), lds, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low<4>");
+    } else {
+      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low<8>, dim3(grid), dim3(64), lds, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low<8>");
+    }
+    return 1;
+  }
+  const size_t lds = (size_t)(A->stft.enabled ? NMX_TOW_LDS_FLOATS : NMX_TOW_LDS_FLOATS_NOSTFT) * 4;
   if (A->n_bands <= 4) {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), lds, s, *A);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<4>");
   } else {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, dim3(n_items), dim3(64), (size_t)NMX_TOW_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, dim3(n_items), dim3(64), lds, s, *A);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<8>");
   }
   return 1;
@@ -131,8 +222,8 @@ __global__ void __launch_bounds__(256) nmx_kern_scan(const NmxTimeOscArgs A, int
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x * 4 + wave;
   if (item >= n_items) return;
-  if (order) nmx_scan_item(A, item % n_windows, item / n_windows);
-  else nmx_scan_item(A, item / A.n_channels, item % A.n_channels);
+  if (order) nmx_td_item(A, item % n_windows, item / n_windows);
+  else nmx_td_item(A, item / A.n_channels, item % A.n_channels);
 }
 
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {

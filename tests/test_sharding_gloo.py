@@ -95,7 +95,9 @@ def test_single_process_multi_device_stream_on_the_gpu():
     from py_neuromodulation_amd import _lib
 
     lib = _lib.get_library()
-    _multi_device_case(lib, [0, 1] if lib.device_count() >= 2 else [0, 0])
+    # fp32: the channel-pair FIR kernel pairs channel 3 with 2 in the one-plan stream and with 4 in the shard; the
+    # z-score divides the 1e-6 relative difference of a log power by a standard deviation 20x smaller than its mean
+    _multi_device_case(lib, [0, 1] if lib.device_count() >= 2 else [0, 0], tol=2e-4)
 
 
 def test_single_process_multi_device_stream_equals_single_device():
@@ -110,7 +112,7 @@ def test_single_process_multi_device_stream_equals_single_device():
     _multi_device_case(_lib.NmxLibrary(ge.build_emu()), [0, 0, 0])
 
 
-def _multi_device_case(lib, devices):
+def _multi_device_case(lib, devices, tol=1e-6):
     from py_neuromodulation_amd import NMSettings
     from py_neuromodulation_amd.stream import Stream
 
@@ -131,7 +133,7 @@ def _multi_device_case(lib, devices):
     assert list(many.columns) == list(one.columns)
     a, b = many.to_numpy(float), one.to_numpy(float)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any()
-    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol, equal_nan=True)
     np.testing.assert_array_equal(again.to_numpy(float), a)
     row = st.data_processor.process(np.nan_to_num(data[:, :1000]))
     assert list(row) == list(one.columns)[:-1]
