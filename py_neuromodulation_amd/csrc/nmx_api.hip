@@ -253,61 +253,35 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds
   hipLaunchKernelGGL(nmx_kern_bank, dim3(n_items), dim3(nt), lds, s, A);
   nmxi_note_kernel("nmx_kern_bank");
 }
-extern "C" void nmx_w64_launch_slp(const NmxBankW64Args*, int, size_t, hipStream_t);
-extern "C" void nmx_w64_launch_scalar(const NmxBankW64Args*, int, size_t, hipStream_t);
 extern "C" void nmx_w64_launch_rd64(const NmxBankW64Args*, int, size_t, hipStream_t);
-extern "C" int nmx_w64p_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
+extern "C" int nmx_w64p_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64q_launch_notch_rd64(const NmxBankW64Args*, int, hipStream_t);
 extern "C" int nmx_w64x2_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64c_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64d_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
-extern "C" int nmx_w64p_launch_slp(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
-extern "C" int nmx_w64p_launch_scalar(const NmxBankW64Args*, int, int, hipStream_t, const NmxSharpArgs*);
-extern "C" int nmx_w64q_launch_notch_slp(const NmxBankW64Args*, int, hipStream_t);
-extern "C" int nmx_w64q_launch_notch_scalar(const NmxBankW64Args*, int, hipStream_t);
 extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
                                            hipStream_t s);
-// returns the persistent launcher's flags (nmx_w64.hip): bit 1 = the sharp-wave analysis ran inside the
-// bank kernel (the caller then only launches the fallback over the flagged items), bit 2 = the Hilbert
-// envelopes were written by the bank kernel (no Hilbert launch); 0 = one-wave-per-workgroup kernel
-static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s,
-                               const NmxSharpArgs* sharp = nullptr) {
-  static int variant = -1;
-  if (variant < 0) {
-    const char* v = getenv("NMX_W64_VARIANT");
-    variant = (v && v[0] == 's' && v[1] == 'l') ? 1 : (v && v[0] == 's' && v[1] == 'c') ? 0 : 2;  // "slp" | "scalar" | "rd64" (default)
-  }
-  static int persistent = -1, n_cu = 0;
-  if (persistent < 0) {
-    const char* v = getenv("NMX_W64_PERSISTENT");
-    persistent = (v && v[0] == '0') ? 0 : 1;
+// One-wave FIR kernels (nmx_w64.hip), one kernel per shape class:
+//   M = 4096 (windows + filter half-length in (2048, 4096])            nmx_kern_bank_w64x2
+//   channel pairs, M = 1536 / 1024 (every filter that fits)            nmx_kern_bank_w64c / w64d
+//   M = 2048, >= 4096 items: persistent 8-wave workgroups, pipelined   nmx_kern_bank_w64pp
+//   notch (odd-reflected window), >= 1024 items: four items / workgroup nmx_kern_notch_w64q
+//   a window or two (nmx_process_window): one wave per workgroup        nmx_kern_bank_w64 / nmx_kern_notch_w64
+static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s) {
+  static int n_cu = -1;
+  if (n_cu < 0) {
     hipDeviceProp_t prop;
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
   }
-  if (A.tw2) {   // M = 4096 path (nmx_k_bank_w64x2.h): one kernel for every batch size
+  if (A.tw2) {
     if (!nmx_w64x2_launch_rd64(&A, n_items, n_cu, s)) g_be_rc = nmx_fail(NMX_E_INVALID, "M = 4096 FIR path: LDS budget");
-    return 0;
+    return;
   }
-  // channel-pair paths (M = 1536 / M = 1024): one kernel for every batch size
-  if (A.hc && (A.pair_m == 1024 ? nmx_w64d_launch_rd64(&A, n_items, n_cu, s) : nmx_w64c_launch_rd64(&A, n_items, n_cu, s))) return 0;
-  if (persistent && n_items >= 4096) {   // tables staged in LDS once per workgroup
-    const int rc = variant == 1 ? nmx_w64p_launch_slp(&A, n_items, n_cu, s, sharp)
-                 : variant == 2 ? nmx_w64p_launch_rd64(&A, n_items, n_cu, s, sharp)
-                                : nmx_w64p_launch_scalar(&A, n_items, n_cu, s, sharp);
-    if (rc) return rc;
-  }
-  static int notch_q = -1;
-  if (notch_q < 0) { const char* v = getenv("NMX_NOTCH_QUAD"); notch_q = !(v && v[0] == '0'); }
-  if (notch_q && A.b.pad_mode != 0 && n_items >= 1024 &&
-      (variant == 1 ? nmx_w64q_launch_notch_slp(&A, n_items, s)
-       : variant == 2 ? nmx_w64q_launch_notch_rd64(&A, n_items, s) : nmx_w64q_launch_notch_scalar(&A, n_items, s)))
-    return 0;
-  if (variant == 1) nmx_w64_launch_slp(&A, n_items, lds, s);
-  else if (variant == 2) nmx_w64_launch_rd64(&A, n_items, lds, s);
-  else nmx_w64_launch_scalar(&A, n_items, lds, s);
-  return 0;
+  if (A.hc && (A.pair_m == 1024 ? nmx_w64d_launch_rd64(&A, n_items, n_cu, s) : nmx_w64c_launch_rd64(&A, n_items, n_cu, s))) return;
+  if (n_items >= 4096 && nmx_w64p_launch_rd64(&A, n_items, n_cu, s)) return;
+  if (A.b.pad_mode != 0 && n_items >= 1024 && nmx_w64q_launch_notch_rd64(&A, n_items, s)) return;
+  nmx_w64_launch_rd64(&A, n_items, lds, s);
 }
 extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s);
 static void be_launch_sharp_dense(const NmxSharpArgs& A, int n_items, be_stream_t s) {

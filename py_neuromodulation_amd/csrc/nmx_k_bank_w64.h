@@ -77,9 +77,6 @@ struct NmxBankW64Args {
   const float* Hs[NMX_MAX_FILTERS_DEV];   // A_k = (a + b) - (a - b) sin(th_k)
   const float* Hd[NMX_MAX_FILTERS_DEV];   // B_k = (a - b) cos(th_k)
   float* yb_out;          // burst bands: filtered series [n_windows][C][Bb][W] (Hilbert kernel input)
-  // fused Hilbert envelope (persistent kernel, W = 1000): burst-band series never leave the wave, the
-  // envelope goes to b.env_out [n_windows][C][Bb][W]; table layout: nmx_k_fft500.h
-  const float* hil_tab;
   const float* twl;       // NMX_W64_TWL_FLOATS floats: per-lane twiddles of passes B and C (persistent kernel)
   const float* hc;        // M = 1536 channel-pair path (nmx_k_bank_w64c.h): [n_filters][12][64] pairs of the REAL spectrum in
                           // register order; twc = [24][64] complex pass-A twiddles, then [8][8] complex exp(-2 pi i a b / 64)
@@ -88,10 +85,6 @@ struct NmxBankW64Args {
                           // twiddles = twl)
   const float* tw2;       // M = 4096 path (nmx_k_bank_w64x2.h): [1024] complex exp(-2 pi i k / 2048); Hs[f] then holds the
                           // INTERLEAVED (A_k, B_k) table of filter f, 2048 pairs
-  // fused sharp-wave analysis (persistent kernel): list offsets inside the exchange tile (floats,
-  // the series itself sits at 0) and the per-(item, filter) flag "needs the generic kernel"
-  int fz_emax, fz_emin, fz_selt, fz_lf, fz_rt, fz_selp, fz_res;
-  unsigned char* sw_todo;
   int off_Z, off_X, off_red, lds_floats;
 };
 
@@ -337,13 +330,10 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
 // TAB = 1: the A/B tables of all filters sit in LDS at `tab` ([filter][A[n], B[n]]), staged once
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
-// HIL = 1 (needs TAB = 1, W = 1000): Hilbert envelope of the burst bands inside the wave; `tab` then
-// continues with the NMX_W500_TAB_FLOATS table after the pass B / C twiddles.
 // HALF = 1 (PAD = 0, W <= 1024): only the output registers v[4 t + r], r < 2 (samples < 1024) exist -- the
 // others are never computed, reduced or stored.
-template <int PAD, int TAB, int MC, int FUSE = 0, int HIL = 0, int HALF = 0, int HOIST = 1>
-NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
-                                  const NmxSharpArgs* S = nullptr) {
+template <int PAD, int TAB, int MC, int HALF = 0, int HOIST = 1>
+NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
   c = nmx_uniform_i(c);
   const NmxBankArgs& A = AA.b;
@@ -614,69 +604,11 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       }
     }
     NMX_PROF(5)
-    // ---- fused sharp-wave analysis: the series goes registers -> LDS, never to HBM ---------------
-    bool sw_done = false;
-#ifndef NMX_HOST_EMU
-    if (FUSE && PAD == 0 && F.sw_index >= 0) {
-      const int l = (int)(threadIdx.x & 63);
-      float* zf = (float*)X;   // pass C has consumed the exchange tile
-      NMX_WSYNC();
-      NMX_UNROLL
-      for (int i = 0; i < 16; ++i) {
-        const int m = l + 64 * (i >> 2) + 256 * (i & 3);
-        if (2 * m + 1 < W) ((nmx_c2*)zf)[m] = v[0][i];
-        else if (2 * m < W) zf[2 * m] = v[0][i].x;
-      }
-      NMX_WSYNC();
-      NmxSharpLds L;
-      L.z = zf;
-      L.emax = (nmx_u16*)(zf + AA.fz_emax); L.emin = (nmx_u16*)(zf + AA.fz_emin);
-      L.selT = (nmx_u16*)(zf + AA.fz_selt); L.lf = (nmx_u16*)(zf + AA.fz_lf);
-      L.rt = (nmx_u16*)(zf + AA.fz_rt); L.selP = (nmx_u16*)(zf + AA.fz_selp);
-      L.st = nullptr; L.vals = nullptr; L.res = zf + AA.fz_res; L.red = nullptr;
-      sw_done = nmx_sharp_body(*S, L, w, c, F.sw_index, true);
-      if (l == 0) AA.sw_todo[((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index] = sw_done ? 0 : 1;
-      NMX_WSYNC();
-    }
-#endif
-    // ---- fused Hilbert envelope of a burst band: registers -> LDS -> two 500-point transforms ----
-#ifndef NMX_HOST_EMU
-    if (HIL && TAB && PAD == 0 && F.burst_index >= 0) {
-      const int l = (int)(threadIdx.x & 63);
-      nmx_c2* hb = X;          // [501]  (pass C has consumed the exchange tile)
-      nmx_c2* ha = X + 504;    // [500]
-      const nmx_c2* htab = (const nmx_c2*)(twC + NMX_W64_TWC_N);
-      NMX_WSYNC();
-      // lane l holds (y[2m], y[2m+1]) in v[4 t + r], m = l + 64 t + 256 r: m < 500 <=> r = 0, or r = 1 and
-      // (t < 3 or l < 52)
-      NMX_UNROLL
-      for (int t = 0; t < 4; ++t) {
-        hb[l + 64 * t] = v[0][4 * t];
-        if (t < 3 || l < 52) hb[l + 64 * t + 256] = v[0][4 * t + 1];
-      }
-      NMX_WSYNC();
-      NmxW500TwLds T;
-      T.p = htab + l;
-      const nmx_c2* ht = nmx_w500_hilbert(ha, hb, T, htab + NMX_W500_TW_N, l);
-      float* de = A.env_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W;
-      const nmx_rsrc rs = nmx_make_rsrc(de, 4 * W);
-      NMX_UNROLL
-      for (int t = 0; t < 4; ++t) {
-        NMX_UNROLL
-        for (int r = 0; r < 2; ++r) {
-          const nmx_c2 y = v[0][4 * t + r], h = ht[l + 64 * t + 256 * r];   // (m >= 500: dropped by the range check)
-          const nmx_c2 e = nmx_mk2(sqrtf(y.x * y.x + h.x * h.x), sqrtf(y.y * y.y + h.y * h.y));
-          __builtin_amdgcn_raw_buffer_store_b64(e, rs, 8 * l + 512 * t + 2048 * r, 0, NMX_SERIES_STORE_AUX);
-        }
-      }
-      NMX_WSYNC();
-    }
-#endif
     // ---- filtered series to HBM (lane-consecutive) ---------------------------------------------
     if (PAD == 0) {
-      float* dsw = (F.sw_index >= 0 && !sw_done)
+      float* dsw = F.sw_index >= 0
           ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
-      float* dyb = (F.burst_index >= 0 && !HIL)
+      float* dyb = F.burst_index >= 0
           ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
 #ifdef NMX_HOST_EMU
       NMX_LANE_LOOP {

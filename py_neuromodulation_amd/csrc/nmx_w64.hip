@@ -1,8 +1,7 @@
-// nmx_w64.hip -- translation unit of the single-wave FIR-bank kernel (nmx_k_bank_w64.h).
-// Built twice by __graft_entry__.build_lib(): default flags (-> *_slp: clang's SLP vectoriser
-// packs the complex arithmetic into v_pk_*_f32) and -fno-slp-vectorize (-> *_scalar: no
-// packing, fewer register-pair moves, no scratch spills).  libnmx picks one at run time
-// (NMX_W64_VARIANT, default chosen from measurements -- see DESIGN.md).
+// nmx_w64.hip -- translation unit of the one-wave FIR kernels (nmx_k_bank_w64*.h): notch, band-pass bank
+// (M = 1024 / 1536 channel pairs, M = 2048, M = 4096).  Built ONCE by __graft_entry__.build_lib() with
+// -fno-slp-vectorize -DNMX_LDS_ASM=1 -DNMX_W64_NAME=rd64: complex arithmetic is packed explicitly (inline asm with
+// operand modifiers, unpaired ds_read_b64); clang's SLP vectoriser on top of that spills.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -13,8 +12,8 @@
 #include "nmx_k_bank_w64c.h"
 #include "nmx_k_bank_w64d.h"
 
-#ifndef NMX_W64_NAME
-#error "define NMX_W64_NAME"
+#if !defined(NMX_W64_NAME) || !defined(NMX_LDS_ASM)
+#error "compile with -DNMX_W64_NAME=rd64 -DNMX_LDS_ASM=1"
 #endif
 // waves per persistent workgroup (= per CU): 8 leaves the 256-VGPR budget (2 waves/SIMD) that the
 // packed-complex formulation needs to stay out of scratch
@@ -45,7 +44,6 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // the kernel's time), then every wave walks its own items with wave-local fences only.
 // HIL = 1: Hilbert envelopes of the burst bands inside the kernel (tables after the twiddles in LDS).
 // HALF = 1: windows of at most 1024 samples -- the upper half of each inverse transform's outputs is never formed.
-#ifdef NMX_LDS_ASM
 // Pipelined persistent kernel (nmx_k_bank_w64p.h): the A / B tables are staged INTERLEAVED ((A_k, B_k) pairs: one
 // 8-byte read per point), everything else as below.
 template <int HALF>
@@ -65,49 +63,6 @@ __global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_
   for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
     nmx_bank_w64_item_pipe<HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
 }
-#endif
-
-template <int WAVES, int FUSE, int HIL, int HALF = 0>
-__global__ void __launch_bounds__(64 * WAVES) NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
-                                                                                     int n_items, int x_floats,
-                                                                                     const NmxSharpArgs S) {
-  float* tab = nmx_smem_w64;
-  const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
-  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
-    const int fi = i / (2 * n), k = i - fi * 2 * n;
-    tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
-  }
-  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
-  if (HIL)
-    for (int i = threadIdx.x; i < NMX_W500_TAB_FLOATS; i += blockDim.x)
-      tab[tab_floats + NMX_W64_TWL_FLOATS + i] = A.hil_tab[i];
-  __syncthreads();
-  // readfirstlane: the wave index is wave-uniform, but only this tells the compiler (item-derived
-  // addresses, descriptors and branches then live in SGPRs)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + (HIL ? NMX_W500_TAB_FLOATS : 0) + wave * x_floats;
-#pragma nounroll
-  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<0, 1, 0, FUSE, HIL, HALF, (WAVES <= 8)>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, &S);
-}
-
-// same structure for the notch (odd-reflected window, one filter)
-__global__ void __launch_bounds__(64 * NMX_W64P_WAVES) NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME)(const NmxBankW64Args A,
-                                                                                                 int n_items, int x_floats) {
-  float* tab = nmx_smem_w64;
-  const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
-  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
-    const int fi = i / (2 * n), k = i - fi * 2 * n;
-    tab[i] = k < n ? A.Hs[fi][k] : A.Hd[fi][k - n];
-  }
-  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
-#pragma nounroll
-  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
-    nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
-}
 
 // Notch, four items per workgroup: the filter's A / B tables and the twiddles are staged in LDS once per
 // FOUR items (the one-wave-per-workgroup kernel fetches ~27 KB of tables from L2 per item); no item loop,
@@ -126,7 +81,6 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_
                              nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats, tab);
 }
 
-#ifdef NMX_LDS_ASM
 // M = 4096 (nmx_k_bank_w64x2.h): persistent workgroups of `nw` waves; LDS = tables of the first n_tab filters,
 // pass B / C twiddles, w^k, one exchange tile per wave
 template <int HALF>
@@ -171,9 +125,7 @@ extern "C" int NMX_CAT(nmx_w64x2_launch_, NMX_W64_NAME)(const NmxBankW64Args* A,
   }
   return 1;
 }
-#endif
 
-#ifdef NMX_LDS_ASM
 // M = 1536, one wave per (window, channel pair) (nmx_k_bank_w64c.h): workgroups of `nw` waves; LDS = the real spectra of
 // all filters, the pass-A twiddles, one exchange tile per wave.  A wave walks a CONTIGUOUS run of `chunk` items in the
 // order (channel pair, window): consecutive items are consecutive hops of the same two channels, whose windows
@@ -269,7 +221,6 @@ extern "C" int NMX_CAT(nmx_w64c_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   NMX_KNAME("nmx_kern_bank_w64c_", "");
   return 1;
 }
-#endif
 
 // returns 0 when the configuration does not fit (caller falls back to one wave per workgroup)
 extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, hipStream_t s) {
@@ -287,113 +238,32 @@ extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Arg
   return 1;
 }
 
-// Return value: 0 = configuration does not fit the persistent kernel (caller falls back), else bit 0 set,
-// bit 1 = the sharp-wave analysis ran inside the kernel (sharp != nullptr), bit 2 = the Hilbert envelopes
-// of the burst bands were written to b.env_out (hil_tab given, W = 1000) instead of the series to yb_out.
-extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu,
-                                                       hipStream_t s, const NmxSharpArgs* sharp) {
-  if (A->b.bp_features & 6u) return 0;
-  const bool notch = A->b.pad_mode != 0;
-  int x_floats = A->lds_floats;                  // per-wave exchange tile (+ scratch)
+// M = 2048 band-pass bank, persistent 8-wave workgroups with the software-pipelined item (nmx_k_bank_w64p.h).
+// Returns 0 when the configuration does not fit (caller falls back to one wave per workgroup).
+extern "C" int NMX_CAT(nmx_w64p_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
+  if ((A->b.bp_features & 6u) || A->b.pad_mode != 0 || !A->twl || (A->b.W & 1)) return 0;
+  const int x_floats = A->lds_floats;                  // per-wave exchange tile (+ scratch)
   const int tab_floats = A->b.n_filters * 2 * NMX_W64_N;
-  if (!A->twl) return 0;
-  static int want_bank = 0, notch_on = 1, half_ok = 1;
-  if (!want_bank) {
-    const char* h = getenv("NMX_W64_HALF");
-    half_ok = !(h && h[0] == '0');
-    const char* v = getenv("NMX_W64P_WAVES");
-    want_bank = (v && atoi(v) == 12) ? 12 : 8;
-    const char* u = getenv("NMX_W64P_NOTCH");
-    notch_on = (u && u[0] == '1');   // measured slower than one wave per workgroup (1.58 vs 1.30 ms)
-  }
-  if (notch && !notch_on) return 0;
-  int want = notch ? NMX_W64P_WAVES : want_bank;
-  if (want == 12) {   // 3 waves/SIMD: W <= 1024 only, the 64-float reduction scratch of each wave is not needed (MC = 0)
-    if (notch || sharp || A->b.W > 1024) want = 8;
-    else x_floats -= 64;
-  }
-  bool hil = !notch && !sharp && want == 8 && A->hil_tab && A->b.W == 1000 && A->b.env_out && A->b.n_burst_bands > 0;
-  int nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS - (hil ? NMX_W500_TAB_FLOATS : 0)) / x_floats;
-  if (hil && nw < want) {   // no room for the Hilbert tables next to the filter tables: separate kernel
-    hil = false;
-    nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats;
-  }
-  if (nw > want) nw = want;
-  if (nw < want && want == 12) {   // does not fit next to this many filter tables: 8 waves
-    want = 8;
-    x_floats += 64;
-    nw = (160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS - (hil ? NMX_W500_TAB_FLOATS : 0)) / x_floats;
-    if (nw > want) nw = want;
-  }
-  if (nw < want) return 0;
+  const int nw = 8;
+  if ((160 * 1024 / 4 - tab_floats - NMX_W64_TWL_FLOATS) / x_floats < nw) return 0;
   static unsigned long long seen = 0;
   if (nmx_first_on_device(seen)) {
-#ifdef NMX_LDS_ASM
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + (hil ? NMX_W500_TAB_FLOATS : 0) + nw * x_floats) * 4;
+  const size_t lds = (size_t)(tab_floats + NMX_W64_TWL_FLOATS + nw * x_floats) * 4;
   int grid = n_cu > 0 ? n_cu : 256;
   if (grid * nw > n_items) grid = (n_items + nw - 1) / nw;
-  if (notch) {
-    hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64p_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A,
-                       n_items, x_floats);
-    NMX_KNAME("nmx_kern_notch_w64p_", "");
-  } else if (sharp && nw == 8) {
-    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 1, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
-                       n_items, x_floats, *sharp);
-    NMX_KNAME("nmx_kern_bank_w64p_", "<8, 1, 0, 0>");
-    return 3;
+  if (A->b.W <= 1024) {   // the upper half of every inverse transform's outputs is never formed
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
+    NMX_KNAME("nmx_kern_bank_w64pp_", "<1>");
   } else {
-    static const NmxSharpArgs none{};
-#ifdef NMX_LDS_ASM
-    static int pipe_ok = -1;
-    if (pipe_ok < 0) { const char* pv = getenv("NMX_W64_PIPE"); pipe_ok = !(pv && pv[0] == '0'); }
-    if (pipe_ok && nw == 8 && !hil && (A->b.W & 1) == 0) {   // software-pipelined item (nmx_k_bank_w64p.h)
-      if (A->b.W <= 1024 && half_ok) {
-        hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
-        NMX_KNAME("nmx_kern_bank_w64pp_", "<1>");
-      } else {
-        hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
-        NMX_KNAME("nmx_kern_bank_w64pp_", "<0>");
-      }
-      return 1;
-    }
-#endif
-    if (nw == 12) {
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<12, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
-                         n_items, x_floats, none);
-      NMX_KNAME("nmx_kern_bank_w64p_", "<12, 0, 0, 1>");
-    } else if (hil) {
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
-                         n_items, x_floats, none);
-      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 1, 0>");
-    } else if (A->b.W <= 1024 && half_ok) {
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0, 1>), dim3(grid), dim3(64 * nw), lds, s, *A,
-                         n_items, x_floats, none);
-      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 0, 1>");
-    } else {
-      hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64p_, NMX_W64_NAME)<8, 0, 0>), dim3(grid), dim3(64 * nw), lds, s, *A,
-                         n_items, x_floats, none);
-      NMX_KNAME("nmx_kern_bank_w64p_", "<8, 0, 0, 0>");
-    }
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_items, x_floats);
+    NMX_KNAME("nmx_kern_bank_w64pp_", "<0>");
   }
-  return hil ? 5 : 1;
+  return 1;
 }
 
 extern "C" void NMX_CAT(nmx_w64_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, size_t lds,

@@ -74,14 +74,12 @@ static void be_launch_bank(const NmxBankArgs& A, int n_items, int, size_t lds, b
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_bank_item(A, it / A.n_channels, it % A.n_channels, sm.data());
 }
-static int be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t,
-                               const NmxSharpArgs* = nullptr) {
+static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) {
     if (A.b.pad_mode == 0) nmx_bank_w64_item<0, 0, 1>(A, it / A.b.n_channels, it % A.b.n_channels, sm.data(), nullptr);
     else nmx_bank_w64_item<1, 0, 0>(A, it / A.b.n_channels, it % A.b.n_channels, sm.data(), nullptr);
   }
-  return 0;   // the fused sharp-wave / Hilbert paths are device only
 }
 static void be_launch_sharp_todo(const NmxSharpArgs&, int, size_t, const unsigned char*, be_stream_t) {}
 static void be_launch_sharp_dense(const NmxSharpArgs&, int, be_stream_t) {}

@@ -447,11 +447,12 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
             assert b == 0, f"{tag} hop {i}\n{rep}"
 
     check("default", default)
-    m2048 = {"NMX_BANK_W64C": "0"}   # every filter on the M = 2048 one-channel kernels (and their fused variants)
-    for knobs in ({"NMX_SW_DENSE": "0"}, {"NMX_SW_DENSE_FIRST": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"}, {"NMX_OVERLAP": "3"},
-                  m2048, {**m2048, "NMX_FUSE_SHARP": "1"}, {**m2048, "NMX_FUSE_HILBERT": "1"}, {**m2048, "NMX_W64_PIPE": "0"},
-                  {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_STFT_PER_WAVE": "0"}, {"NMX_TIMEOSC_W1000": "0"},
-                  {"NMX_SHARP_FIRST": "1"}, {"NMX_CHUNK_WINDOWS": "9"}):
+    # the code paths a SHAPE can select that this shape does not reach by itself: every filter on the M = 2048
+    # one-channel kernel, the generic sharp-wave / time-oscillatory / threshold-walk kernels, the schedules, a
+    # chunk boundary every 9 hops
+    for knobs in ({"NMX_BANK_W64C": "0"}, {"NMX_SW_DENSE": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
+                  {"NMX_OVERLAP": "2"}, {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_TIMEOSC_W1000": "0"},
+                  {"NMX_TOW_PERSISTENT": "0"}, {"NMX_CHUNK_WINDOWS": "9"}):
         for knob, val in knobs.items():
             monkeypatch.setenv(knob, val)
         _, keys2, got = run()
