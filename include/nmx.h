@@ -265,6 +265,11 @@ int nmx_last_kernels(nmx_plan* plan, int which, char* buf, int64_t n);
 #define NMX_NORM_ZSCORE 1
 #define NMX_NORM_MEDIAN 2          /* (x - median) / median        (normalization.py:155-157) */
 #define NMX_NORM_ZSCORE_MEDIAN 3   /* (x - median) / std, std 0 -> 1 (normalization.py:166-169) */
+/* the scikit-learn based methods (normalization.py:57-70,172-186): the scaler is FITTED on nan_to_num(history) every hop */
+#define NMX_NORM_ROBUST 4          /* RobustScaler */
+#define NMX_NORM_MINMAX 5          /* MinMaxScaler */
+#define NMX_NORM_QUANTILE 6        /* QuantileTransformer(n_quantiles = 300) */
+#define NMX_NORM_POWER 7           /* PowerTransformer (Yeo-Johnson, lambda by maximum likelihood, standardised) */
 typedef struct nmx_norm nmx_norm;
 int nmx_norm_create(int32_t device, int32_t n_cols, int32_t method, float clip, int32_t n_hist,
                     const uint8_t* colmask, nmx_norm** out);

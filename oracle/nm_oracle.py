@@ -859,11 +859,198 @@ class Resampler:
 #       nanpercentile(history, linspace(0, 1, n_q) * 100); y = (interp(x, q, r) - interp(-x, -q[::-1], -r[::-1])) / 2,
 #       x == q[0] -> 0, x == q[-1] -> 1.  Histories of more than 10 000 rows are randomly subsampled by
 #       scikit-learn (subsample = 10 000, random_state = None): the reference itself is not reproducible there.
-#   PowerTransformer    (Yeo-Johnson, lambda by maximum likelihood through scipy.stats.yeojohnson) is NOT restated.
+#   PowerTransformer    Yeo-Johnson, standardize=True: per column lambda = scipy.stats.yeojohnson_normmax (bounded Brent
+#       search, scipy.optimize.fminbound, xtol 1.48e-8, on scipy's expm1 / log1p form of the log-likelihood, bounds
+#       from the largest |x|), lambda = 1 for a constant column; the column is transformed with scikit-learn's
+#       np.power form and standardised with the mean / variance of the transformed history (_yj_* below;
+#       scikit-learn 1.7 with scipy >= 1.9, the versions of this image -- tests/test_oracle_golden.py checks the
+#       restatement against PowerTransformer itself).
 _SK_EPS10 = 10 * np.finfo(np.float64).eps
+_F64 = np.finfo(np.float64)
 
 
-def _sk_fit_transform(method, prev, cur):
+def _yj_llf_neg(lmb, x, sl_sum):
+    """-yeojohnson_llf(lmb, x) (scipy/stats/_morestats.py), +inf where the transformed variance underflows."""
+    pos = x >= 0
+    out = np.zeros_like(x)
+    if abs(lmb) < np.spacing(1.0):
+        out[pos] = np.log1p(x[pos])
+    else:
+        out[pos] = np.expm1(lmb * np.log1p(x[pos])) / lmb
+    if abs(lmb - 2) > np.spacing(1.0):
+        out[~pos] = -np.expm1((2 - lmb) * np.log1p(-x[~pos])) / (2 - lmb)
+    else:
+        out[~pos] = -np.log1p(-x[~pos])
+    var = out.var()
+    if var < _F64.tiny:
+        return np.inf
+    llf = -x.shape[0] / 2 * np.log(var) + (lmb - 1) * sl_sum
+    return np.inf if np.isinf(llf) else -llf
+
+
+def _fminbound(func, x1, x2, xatol=1.48e-8, maxfun=500):
+    """scipy.optimize._optimize._minimize_scalar_bounded, statement for statement."""
+    sqrt_eps = np.sqrt(2.2e-16)
+    golden_mean = 0.5 * (3.0 - np.sqrt(5.0))
+    a, b = x1, x2
+    fulc = a + golden_mean * (b - a)
+    nfc, xf = fulc, fulc
+    rat = e = 0.0
+    x = xf
+    fx = func(x)
+    num = 1
+    ffulc = fnfc = fx
+    xm = 0.5 * (a + b)
+    tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+    tol2 = 2.0 * tol1
+    while abs(xf - xm) > (tol2 - 0.5 * (b - a)):
+        golden = 1
+        if abs(e) > tol1:
+            golden = 0
+            r = (xf - nfc) * (fx - ffulc)
+            q = (xf - fulc) * (fx - fnfc)
+            p = (xf - fulc) * q - (xf - nfc) * r
+            q = 2.0 * (q - r)
+            if q > 0.0:
+                p = -p
+            q = abs(q)
+            r = e
+            e = rat
+            if (abs(p) < abs(0.5 * q * r)) and (p > q * (a - xf)) and (p < q * (b - xf)):
+                rat = (p + 0.0) / q
+                x = xf + rat
+                if ((x - a) < tol2) or ((b - x) < tol2):
+                    si = np.sign(xm - xf) + ((xm - xf) == 0)
+                    rat = tol1 * si
+            else:
+                golden = 1
+        if golden:
+            e = a - xf if xf >= xm else b - xf
+            rat = golden_mean * e
+        si = np.sign(rat) + (rat == 0)
+        x = xf + si * max(abs(rat), tol1)
+        fu = func(x)
+        num += 1
+        if fu <= fx:
+            if x >= xf:
+                a = xf
+            else:
+                b = xf
+            fulc, ffulc = nfc, fnfc
+            nfc, fnfc = xf, fx
+            xf, fx = x, fu
+        else:
+            if x < xf:
+                a = x
+            else:
+                b = x
+            if (fu <= fnfc) or (nfc == xf):
+                fulc, ffulc = nfc, fnfc
+                nfc, fnfc = x, fu
+            elif (fu <= ffulc) or (fulc == xf) or (fulc == nfc):
+                fulc, ffulc = x, fu
+        xm = 0.5 * (a + b)
+        tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+        tol2 = 2.0 * tol1
+        if num >= maxfun:
+            break
+    return xf
+
+
+def _yj_lambda(x):
+    """scipy.stats.yeojohnson_normmax(x) for float64 data (brack=None): the bounded search."""
+    if np.all(x == 0):
+        return 1.0
+    log1p_max_x = np.log1p(20 * np.max(np.abs(x)))
+    log_eps = np.log(_F64.eps)
+    lb = (np.log(_F64.tiny) - log_eps) / 2 / log1p_max_x
+    ub = (np.log(_F64.max) + log_eps) / 2 / log1p_max_x
+    if np.all(x < 0):
+        lb, ub = 2 - ub, 2 - lb
+    elif np.any(x < 0):
+        lb, ub = max(2 - ub, lb), min(2 - lb, ub)
+    sl_sum = (np.sign(x) * np.log1p(np.abs(x))).sum()
+    return _fminbound(lambda l: _yj_llf_neg(l, x, sl_sum), lb, ub)
+
+
+def yeo_johnson_conditioning(col, x_now, rel_noise=1e-13):
+    """How far the standardised Yeo-Johnson output of `x_now` can move for likelihood-equivalent lambdas.  The
+    log-likelihood is evaluated with a relative noise of ~rel_noise (float64 sums of n transcendental values; libm
+    and summation order differ between NumPy and any other implementation); every lambda whose likelihood lies within
+    that noise of the maximum is as good an answer as the one the bounded search happens to return.  Returns
+    max |out(lambda) - out(lambda*)| over that interval (0 for a constant column)."""
+    col = np.asarray(col, np.float64)
+    n = col.shape[0]
+    if _sk_constant(np.var(col), np.mean(col), n) or np.all(col == 0):
+        return 0.0
+    lmb = _yj_lambda(col)
+    sl_sum = (np.sign(col) * np.log1p(np.abs(col))).sum()
+    f0 = _yj_llf_neg(lmb, col, sl_sum)
+    if not np.isfinite(f0):
+        return np.inf
+    # the noise of -llf = n/2 log(var) - ...: var itself carries rel_noise * (mean^2 / var + 1) from its cancellation
+    with np.errstate(all="ignore"):
+        t = _yj_transform(col, lmb)
+    cond = 1.0 + np.mean(t) ** 2 / max(np.var(t), _F64.tiny)
+    tol_f = rel_noise * cond * n / 2 + rel_noise * abs(f0)
+
+    def out(l):
+        with np.errstate(all="ignore"):
+            tt = _yj_transform(col, l)
+            m, v = np.mean(tt), np.var(tt)
+            sc = 1.0 if _sk_constant(v, m, n) else np.sqrt(v)
+            return float((_yj_transform(np.array([x_now], np.float64), l)[0] - m) / sc)
+
+    o0, worst = out(lmb), 0.0
+    for sign in (-1.0, 1.0):
+        step = 1e-6
+        while step < 64.0:
+            l = lmb + sign * step
+            f = _yj_llf_neg(l, col, sl_sum)
+            if not np.isfinite(f) or f - f0 > tol_f:
+                break
+            o1 = out(l)
+            if np.isfinite(o1):
+                worst = max(worst, abs(o1 - o0))
+            step *= 2.0
+    return worst
+
+
+def _yj_transform(x, lmb):
+    """sklearn.preprocessing.PowerTransformer._yeo_johnson_transform (the np.power form)."""
+    out = np.zeros_like(x)
+    pos = x >= 0
+    if abs(lmb) < np.spacing(1.0):
+        out[pos] = np.log1p(x[pos])
+    else:
+        out[pos] = (np.power(x[pos] + 1, lmb) - 1) / lmb
+    if abs(lmb - 2) > np.spacing(1.0):
+        out[~pos] = -(np.power(-x[~pos] + 1, 2 - lmb) - 1) / (2 - lmb)
+    else:
+        out[~pos] = -np.log1p(-x[~pos])
+    return out
+
+
+def _sk_constant(var, mean, n):
+    """sklearn.preprocessing._data._is_constant_feature."""
+    eps = _F64.eps
+    return var <= n * eps * var + (n * mean * eps) ** 2
+
+
+def yeo_johnson_fit(col):
+    """(lambda, mean, scale) of one history column the way PowerTransformer(standardize=True).fit does."""
+    n = col.shape[0]
+    lmb = 1.0 if _sk_constant(np.var(col), np.mean(col), n) else _yj_lambda(col)
+    with np.errstate(all="ignore"):
+        t = _yj_transform(col, lmb)
+    mean, var = np.mean(t), np.var(t)
+    scale = 1.0 if _sk_constant(var, mean, n) else np.sqrt(var)   # (_handle_zeros_in_scale with the constant mask)
+    return lmb, mean, scale
+
+
+def _sk_fit_transform(method, prev, cur, rng=None):
+    """`rng`: numpy Generator for QuantileTransformer's random subsample of histories > 10 000 rows (the reference
+    uses random_state=None: one realisation of a random variable; without `rng` such histories raise)."""
     X = np.nan_to_num(np.asarray(prev, np.float64))
     cur = np.array(cur, dtype=np.float64)
     one_d = cur.ndim == 1
@@ -884,7 +1071,10 @@ def _sk_fit_transform(method, prev, cur):
         elif method == "quantile":
             n = X.shape[0]
             if n > 10000:
-                raise NotImplementedError("QuantileTransformer subsamples histories of more than 10 000 rows at random")
+                if rng is None:
+                    raise NotImplementedError("QuantileTransformer subsamples histories of more than 10 000 rows at random")
+                X = X[rng.choice(n, 10000, replace=False)]   # sklearn.utils.resample(replace=False): rows, jointly
+                n = 10000
             nq = min(300, n)
             refs = np.linspace(0, 1, nq, endpoint=True)
             quant = np.maximum.accumulate(np.nanpercentile(X, refs * 100, axis=0))
@@ -898,12 +1088,17 @@ def _sk_fit_transform(method, prev, cur):
                 col[upper] = 1.0
                 col[lower] = 0.0
                 out[:, j] = col
+        elif method == "power":
+            out = np.empty_like(Y)
+            for j in range(Y.shape[1]):
+                lmb, mean, scale = yeo_johnson_fit(X[:, j].copy())
+                out[:, j] = (_yj_transform(Y[:, j].copy(), lmb) - mean) / scale
         else:
             raise NotImplementedError(method)
     return out[0] if one_d else out
 
 
-_SK_METHODS = ("robust", "minmax", "quantile")
+_SK_METHODS = ("robust", "minmax", "quantile", "power")
 
 
 class RawNormalizer:
@@ -911,8 +1106,9 @@ class RawNormalizer:
     int(sfreq / feat_hz) samples of every later window, statistics over it incl. the current tail,
     trimmed to N - 1 = int(normalization_time_s * sfreq) - 1 samples afterwards."""
 
-    def __init__(self, sfreq, settings) -> None:
+    def __init__(self, sfreq, settings, rng=None) -> None:
         rs = settings.raw_normalization_settings
+        self.rng = rng
         self.method = rs.normalization_method
         self.clip = rs.clip
         self.add = int(sfreq / settings.sampling_rate_features_hz)
@@ -926,7 +1122,7 @@ class RawNormalizer:
         cur = data.T
         self.prev = np.vstack((self.prev, cur[-self.add:]))
         if self.method in _SK_METHODS:
-            out = _sk_fit_transform(self.method, self.prev, cur)
+            out = _sk_fit_transform(self.method, self.prev, cur, self.rng)
         else:
             has_nan = np.any(np.isnan(sum(self.prev)))
             mean = (np.nanmean if has_nan else np.mean)(self.prev, axis=0)

@@ -9,6 +9,7 @@
 #include "nmx_k_burst_fill.h"
 #include "nmx_k_kalman.h"
 #include "nmx_k_norm.h"
+#include "nmx_k_power.h"
 #include "nmx_k_prep.h"
 #include "nmx_k_rawnorm.h"
 #include "nmx_k_resample.h"
@@ -79,6 +80,15 @@ __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
 }
 __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(256) nmx_kern_power_prep(const NmxPowerPrepArgs P) {
+  nmx_power_prep_at(P, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+__global__ void __launch_bounds__(64) nmx_kern_power(const NmxPowerArgs A) {
+  nmx_power_cell(A, (int)blockIdx.y, (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(256) nmx_kern_power_ring(const NmxPowerPrepArgs P) {
+  nmx_power_ring_at(P, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
   __shared__ float red[256];
@@ -344,7 +354,7 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, si
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
   be_init_once();
-  if (A.method >= NMX_RAWNORM_MEDIAN) {
+  if (A.method >= NMX_RAWNORM_MEDIAN && A.method != NMX_RAWNORM_POWER) {
     const size_t lds = (size_t)24 * A.max_list + 8 * NMX_RAWNORM_ORDER_NT;
     hipLaunchKernelGGL(nmx_kern_rawnorm_order, dim3(A.n_channels), dim3(NMX_RAWNORM_ORDER_NT), lds, s, A);
     const long long n = (long long)A.n_windows * A.n_channels * A.W;
@@ -365,6 +375,13 @@ static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   // one thread per column, one wave per workgroup: columns spread over as many CUs as possible
   hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
+}
+static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be_stream_t s) {
+  const unsigned gx = (unsigned)((P.n_cols + 255) / 256);
+  hipLaunchKernelGGL(nmx_kern_power_prep, dim3(gx, (unsigned)(P.have + P.n_rows)), dim3(256), 0, s, P);
+  // one wave per 64 columns of one hop: the ~30 likelihood evaluations of a fit diverge little inside a wave
+  hipLaunchKernelGGL(nmx_kern_power, dim3((unsigned)((A.n_cols + 63) / 64), (unsigned)A.n_rows), dim3(64), 0, s, A);
+  hipLaunchKernelGGL(nmx_kern_power_ring, dim3(gx, (unsigned)P.n_rows), dim3(256), 0, s, P);
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);

@@ -18,6 +18,7 @@ struct float2 {
 };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #define NMX_DEV static inline
+#define NMX_DEVM inline            /* member functions */
 #define NMX_TID 0
 #define NMX_NT 1
 #define NMX_SYNC() ((void)0)
@@ -25,6 +26,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #else
 #include <hip/hip_runtime.h>
 #define NMX_DEV __device__ __forceinline__
+#define NMX_DEVM __device__ __forceinline__
 #ifdef NMX_NT_FIXED
 // translation units of the one-item-per-WAVE kernels (nmx_wave.hip): the workgroup size is a
 // compile-time 64, so no blockDim load from the implicit kernel arguments (a dependent global

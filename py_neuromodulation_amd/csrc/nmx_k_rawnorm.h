@@ -16,6 +16,7 @@
 #pragma once
 
 #include "nmx_device.h"
+#include "nmx_k_power.h"
 
 #define NMX_RAWNORM_MEAN 1
 #define NMX_RAWNORM_ZSCORE 2
@@ -24,6 +25,10 @@
 #define NMX_RAWNORM_ZSCORE_MEDIAN 4   // (x - nanmedian) / nanstd               normalization.py:166-169
 #define NMX_RAWNORM_ROBUST 5          // sklearn RobustScaler  fitted on the history every hop (:57-70,172-186)
 #define NMX_RAWNORM_MINMAX 6          // sklearn MinMaxScaler
+#define NMX_RAWNORM_QUANTILE 7        // sklearn QuantileTransformer(n_quantiles = 300): a 300-entry table per (hop, channel)
+#define NMX_RAWNORM_POWER 8           // sklearn PowerTransformer (Yeo-Johnson): (lambda, mean, scale) per (hop, channel)
+#define NMX_RAWNORM_NQ 300
+#define NMX_RAWNORM_SUBSAMPLE 10000   // QuantileTransformer.subsample: longer histories are randomly subsampled
 
 struct NmxRawNormArgs {
   const float* x;            // windows: stream + starts, or materialised [n][C][W]
@@ -49,6 +54,15 @@ struct NmxRawNormArgs {
   int* cur;
   int sorted_valid;
   int max_list;              // LDS list capacity: W + add (inserted / dropped values of one hop)
+  // "quantile": qt[n_windows][C][300] the fitted quantiles, qn[n_windows][C] how many of them (min(300, history));
+  // sub[C][10000] scratch of the random subsample, seed of its hash
+  double* qt;
+  int* qn;
+  float* sub;
+  unsigned seed;
+  // "power": ring_sl[C][cap] = sign(x) log1p|x| of the ring's samples; pw[n_windows][C][3] = (lambda, mean, scale)
+  double* ring_sl;
+  double* pw;
 };
 
 #ifdef NMX_HOST_EMU
@@ -60,9 +74,99 @@ NMX_DEV double nmx_wave_sum_d(double v) {
 }
 #endif
 
+#ifdef NMX_HOST_EMU
+NMX_DEV double nmx_wave_max_d(double v) { return v; }
+#else
+NMX_DEV double nmx_wave_max_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+  return v;
+}
+#endif
+
+// "power" on the raw history of one channel, the lanes of ONE WAVE sharing the history (nmx_k_power.h has the
+// thread-serial form and the arithmetic: scipy's bounded Brent search of the Yeo-Johnson likelihood).  Every lane
+// evaluates its stride of the history, the sums are wave reductions, so the search runs in lock step on all lanes.
+struct NmxRnHist {
+  const float* ring;
+  const double* rsl;
+  int cap, len;
+  long long cnt;
+  NMX_DEVM float x(int i) const { return ring[(cnt - len + i) % cap]; }
+  NMX_DEVM double sl(int i) const { return rsl[(cnt - len + i) % cap]; }
+};
+NMX_DEV double nmx_rn_negllf(double lmb, const NmxRnHist& h, double sl_sum, double t0) {
+  const double eps = 2.220446049250313e-16, tiny = 2.2250738585072014e-308;
+  const bool l0 = fabs(lmb) < eps, l2 = !(fabs(lmb - 2.0) > eps);
+  const double c2 = 2.0 - lmb;
+  auto tr = [&](double s) {
+    const double l = fabs(s);
+    return s >= 0.0 ? (l0 ? l : expm1(lmb * l) / lmb) : (l2 ? -l : -expm1(c2 * l) / c2);
+  };
+  const double k = tr(t0);   // shift = the transformed first sample of the history
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = NMX_TID; i < h.len; i += NMX_NT) {
+    const double d = tr(h.sl(i)) - k;
+    s1 += d; s2 += d * d;
+  }
+  s1 = nmx_wave_sum_d(s1); s2 = nmx_wave_sum_d(s2);
+  double var = (s2 - s1 * s1 / (double)h.len) / (double)h.len;
+  if (var < 0.0) var = 0.0;
+  if (var < tiny) return INFINITY;
+  const double llf = -(double)h.len / 2.0 * log(var) + (lmb - 1.0) * sl_sum;
+  if (llf == INFINITY || llf == -INFINITY) return INFINITY;
+  return -llf;
+}
+NMX_DEV void nmx_rn_power_fit(const NmxRnHist& h, double& lmb, double& mean_t, double& scale_t) {
+  const int n = h.len;
+  double s = 0.0, amax = 0.0, sl_sum = 0.0, n_neg = 0.0, n_zero = 0.0;
+  for (int i = NMX_TID; i < n; i += NMX_NT) {
+    const double x = nmx_pw_clean(h.x(i));
+    s += x;
+    const double ax = fabs(x);
+    amax = ax > amax ? ax : amax;
+    n_neg += x < 0.0; n_zero += x == 0.0;
+    sl_sum += h.sl(i);
+  }
+  s = nmx_wave_sum_d(s); sl_sum = nmx_wave_sum_d(sl_sum); n_neg = nmx_wave_sum_d(n_neg); n_zero = nmx_wave_sum_d(n_zero);
+  amax = nmx_wave_max_d(amax);
+  const double mean = s / (double)n;
+  double q = 0.0;
+  for (int i = NMX_TID; i < n; i += NMX_NT) { const double d = nmx_pw_clean(h.x(i)) - mean; q += d * d; }
+  q = nmx_wave_sum_d(q);
+  if (nmx_pw_constant(q / (double)n, mean, n) || n_zero == (double)n) {
+    lmb = 1.0;
+  } else {
+    const double log_eps = log(2.220446049250313e-16), log1p_max_x = log1p(20.0 * amax);
+    double lb = (log(2.2250738585072014e-308) - log_eps) / 2.0 / log1p_max_x;
+    double ub = (log(1.7976931348623157e308) + log_eps) / 2.0 / log1p_max_x;
+    if (n_neg == (double)n) { const double t = lb; lb = 2.0 - ub; ub = 2.0 - t; }
+    else if (n_neg > 0.0) { const double l2 = 2.0 - ub, u2 = 2.0 - lb; lb = l2 > lb ? l2 : lb; ub = u2 < ub ? u2 : ub; }
+    const double t0 = h.sl(0);
+    lmb = nmx_pw_fminbound_f([&](double l) { return nmx_rn_negllf(l, h, sl_sum, t0); }, lb, ub);
+  }
+  const double k = nmx_pw_transform(nmx_pw_clean(h.x(0)), lmb);
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = NMX_TID; i < n; i += NMX_NT) {
+    const double d = nmx_pw_transform(nmx_pw_clean(h.x(i)), lmb) - k;
+    s1 += d; s2 += d * d;
+  }
+  s1 = nmx_wave_sum_d(s1); s2 = nmx_wave_sum_d(s2);
+  mean_t = k + s1 / (double)n;
+  double var_t = (s2 - s1 * s1 / (double)n) / (double)n;
+  if (var_t < 0.0) var_t = 0.0;
+  scale_t = nmx_pw_constant(var_t, mean_t, n) ? 1.0 : sqrt(var_t);
+}
+
 // one wave per channel
 NMX_DEV void nmx_rawnorm_stats_item(const NmxRawNormArgs& A, int c) {
   float* ring = A.ring + (long long)c * A.cap;
+  double* rsl = A.method == NMX_RAWNORM_POWER ? A.ring_sl + (long long)c * A.cap : nullptr;
+  if (rsl && !A.sorted_valid) {   // fresh plan / reset / imported state: derive it from the kept history
+    const long long c0 = A.count[c];
+    const int l0 = A.len[c];
+    for (int i = NMX_TID; i < l0; i += NMX_NT) rsl[(c0 - l0 + i) % A.cap] = nmx_pw_sl(ring[(c0 - l0 + i) % A.cap]);
+    NMX_SYNC();
+  }
   long long cnt = A.count[c];
   int len = A.len[c];
   // sums of the kept history (rebuilt once per batch)
@@ -81,13 +185,24 @@ NMX_DEV void nmx_rawnorm_stats_item(const NmxRawNormArgs& A, int c) {
     for (int i = NMX_TID; i < n_new; i += NMX_NT) {
       const float v = A.clean_on_load ? nmx_clean(tail[i]) : tail[i];
       ring[(cnt + i) % A.cap] = v;
+      if (rsl) rsl[(cnt + i) % A.cap] = nmx_pw_sl(v);
       a1 += (double)v; a2 += (double)v * (double)v;
     }
     s1 += nmx_wave_sum_d(a1); s2 += nmx_wave_sum_d(a2);
     cnt += n_new; len += n_new;
     NMX_SYNC();
     float mean = 0.f, scale = 0.f;
-    if (!first) {
+    if (!first && A.method == NMX_RAWNORM_POWER) {
+      NmxRnHist h;
+      h.ring = ring; h.rsl = rsl; h.cap = A.cap; h.len = len; h.cnt = cnt;
+      double lmb, mt, st;
+      nmx_rn_power_fit(h, lmb, mt, st);
+      if (NMX_TID == 0) {
+        double* pw = A.pw + ((long long)w * A.n_channels + c) * 3;
+        pw[0] = lmb; pw[1] = mt; pw[2] = st;
+      }
+      scale = 1.f;   // (not the pass-through marker)
+    } else if (!first) {
       const double m = s1 / (double)len;
       if (A.method == NMX_RAWNORM_MEAN) {
         scale = (float)(1.0 / m);
@@ -201,6 +316,82 @@ NMX_DEV double nmx_rawnorm_quantile(const float* S, int n, double q) {
   return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
 }
 
+// A uniformly random m-subset (m = 10 000) of the sorted history, in sorted order: every element gets a 32-bit hash
+// key of (seed, index); the m smallest keys are the subset (ties by index).  The m-th smallest key comes from a
+// four-pass radix select (256-bin histograms in LDS), the subset from a block scan of per-thread counts.
+// `scr`: >= 2 * NMX_NT + 264 ints of LDS scratch (the whole carve-up of the item: 6 max_list + 2 NT words).  Statistically this is scikit-learn's resample(replace=False) per
+// column (scikit-learn >= 1.5 draws ONE row subset for all columns; the sorted copies here are per channel).
+NMX_DEV unsigned nmx_rawnorm_hash(unsigned seed, unsigned i) {
+  unsigned h = seed ^ (i * 0x9E3779B9u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+NMX_DEV void nmx_rawnorm_subsample(const float* S, int n, float* sub, unsigned seed, int* scr) {
+  const int m = NMX_RAWNORM_SUBSAMPLE;
+  int* hist = scr;                 // [256] + [8] control words
+  int* ctl = scr + 256;            // ctl[0] = key prefix, ctl[1] = keys still to take inside the prefix class
+  int* cntA = scr + 264;           // [NT]
+  int* cntB = cntA + NMX_NT;       // [NT]
+  if (NMX_TID == 0) { ctl[0] = 0; ctl[1] = m; }
+  NMX_SYNC();
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = NMX_TID; i < 256; i += NMX_NT) hist[i] = 0;
+    NMX_SYNC();
+    const unsigned prefix = (unsigned)ctl[0];
+    const int sh = 8 * pass;
+    for (int i = NMX_TID; i < n; i += NMX_NT) {
+      const unsigned k = nmx_rawnorm_hash(seed, (unsigned)i);
+      if (pass == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))) {
+#ifdef NMX_HOST_EMU
+        ++hist[(k >> sh) & 255u];
+#else
+        atomicAdd(&hist[(k >> sh) & 255u], 1);
+#endif
+      }
+    }
+    NMX_SYNC();
+    if (NMX_TID == 0) {
+      int need = ctl[1], b = 0;
+      while (b < 255 && hist[b] < need) { need -= hist[b]; ++b; }
+      ctl[0] = (int)(prefix | ((unsigned)b << sh));
+      ctl[1] = need;   // keys to take among those equal to the prefix so far
+    }
+    NMX_SYNC();
+  }
+  const unsigned T = (unsigned)ctl[0];
+  const int need_eq = ctl[1];      // of the keys == T, the first need_eq (by index) belong to the subset
+  // contiguous blocks per thread: counts of (key < T) and (key == T)
+  const int B = (n + NMX_NT - 1) / NMX_NT, i0 = NMX_TID * B, i1 = i0 + B < n ? i0 + B : n;
+  int lt = 0, eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const unsigned k = nmx_rawnorm_hash(seed, (unsigned)i);
+    lt += k < T; eq += k == T;
+  }
+  cntA[NMX_TID] = lt; cntB[NMX_TID] = eq;
+  NMX_SYNC();
+#ifndef NMX_HOST_EMU
+  for (int o = 1; o < NMX_NT; o <<= 1) {   // inclusive Hillis-Steele scans of both count arrays
+    const int a = NMX_TID >= o ? cntA[NMX_TID - o] : 0, b = NMX_TID >= o ? cntB[NMX_TID - o] : 0;
+    __syncthreads();
+    cntA[NMX_TID] += a; cntB[NMX_TID] += b;
+    __syncthreads();
+  }
+#endif
+  int out_lt = cntA[NMX_TID] - lt, seen_eq = cntB[NMX_TID] - eq;   // exclusive prefixes
+  for (int i = i0; i < i1; ++i) {
+    const unsigned k = nmx_rawnorm_hash(seed, (unsigned)i);
+    if (k < T) {
+      const int eq_before = seen_eq < need_eq ? seen_eq : need_eq;
+      sub[out_lt + eq_before] = S[i];
+      ++out_lt;
+    } else if (k == T) {
+      if (seen_eq < need_eq) sub[out_lt + seen_eq] = S[i];
+      ++seen_eq;
+    }
+  }
+  NMX_SYNC();
+}
+
 NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem) {
   float* ring = A.ring + (long long)c * A.cap;
   float* Sbuf = A.sorted + (long long)c * 2 * A.cap;
@@ -308,10 +499,29 @@ NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem)
     S = S2;
     n_drop = 0;
     if (flush) break;
+    // ---- "quantile": QuantileTransformer(n_quantiles = 300) fitted on this hop's history --------------------
+    if (A.method == NMX_RAWNORM_QUANTILE && !first) {
+      const float* Qs = S;
+      int nqs = n_sorted;
+      if (n_sorted > NMX_RAWNORM_SUBSAMPLE) {   // scikit-learn draws 10 000 of the history's rows at random
+        float* sub = A.sub + (long long)c * NMX_RAWNORM_SUBSAMPLE;
+        nmx_rawnorm_subsample(S, n_sorted, sub, A.seed ^ (unsigned)((A.hop0 + w) * 2654435761u) ^ ((unsigned)c * 40503u), (int*)smem);   // (the merge lists are dead here)
+        Qs = sub;
+        nqs = NMX_RAWNORM_SUBSAMPLE;
+      }
+      const int nq = nqs < NMX_RAWNORM_NQ ? nqs : NMX_RAWNORM_NQ;
+      double* qt = A.qt + ((long long)w * A.n_channels + c) * NMX_RAWNORM_NQ;
+      for (int i = NMX_TID; i < nq; i += NMX_NT)   // references = linspace(0, 1, nq); np.nanpercentile(history, references * 100)
+        qt[i] = nq == 1 ? (double)Qs[0] : nmx_rawnorm_quantile(Qs, nqs, i < nq - 1 ? (double)i * (1.0 / (double)(nq - 1)) : 1.0);
+      if (NMX_TID == 0) A.qn[(long long)w * A.n_channels + c] = nq;
+      NMX_SYNC();
+    }
     // ---- statistics of the hop ------------------------------------------------------------------------------
     if (NMX_TID == 0) {
       float center = 0.f, scale = 0.f;
-      if (!first) {
+      if (!first && A.method == NMX_RAWNORM_QUANTILE) {
+        scale = 1.f;   // (not the pass-through marker; the apply kernel reads the table)
+      } else if (!first) {
         const int n = n_sorted;
         const double med = (n & 1) ? (double)S[n >> 1] : 0.5 * ((double)S[(n >> 1) - 1] + (double)S[n >> 1]);
         if (A.method == NMX_RAWNORM_MEDIAN) {
@@ -369,6 +579,30 @@ NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem)
   if (NMX_TID == 0) { A.count[c] = cnt; A.len[c] = len; A.cur[c] = cur; }
 }
 
+// QuantileTransformer.transform (uniform output) of one value against the fitted table Q[0..nq), references
+// R[i] = i / (nq - 1):  y = (interp(x, Q, R) - interp(-x, -Q[::-1], -R[::-1])) / 2, x == Q[0] -> 0, x == Q[-1] -> 1
+NMX_DEV double nmx_rawnorm_qt_apply(const double* Q, int nq, double x) {
+  if (x != x) return x;
+  const double q0 = Q[0], q1 = Q[nq - 1];
+  if (x == q0) return 0.0;
+  if (x == q1) return 1.0;
+  if (x < q0) return 0.0;
+  if (x > q1) return 1.0;
+  auto ref = [&](int i) { return (i < nq - 1) ? (double)i * (1.0 / (double)(nq - 1)) : 1.0; };
+  int lo = 0, hi = nq - 1;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (Q[mid] <= x) lo = mid; else hi = mid; }
+  const int a = lo;      // LAST index with Q[a] <= x
+  lo = 0; hi = nq - 1;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (Q[mid] >= x) hi = mid; else lo = mid; }
+  const int b = hi;      // FIRST index with Q[b] >= x
+  double r1, r2;
+  if (Q[a] == x) r1 = ref(a);
+  else r1 = (ref(a + 1) - ref(a)) / (Q[a + 1] - Q[a]) * (x - Q[a]) + ref(a);
+  if (Q[b] == x) r2 = -ref(b);
+  else r2 = ((-ref(b - 1)) - (-ref(b))) / ((-Q[b - 1]) - (-Q[b])) * ((-x) - (-Q[b])) + (-ref(b));
+  return 0.5 * (r1 - r2);
+}
+
 // element i of window (w, c)
 NMX_DEV void nmx_rawnorm_apply(const NmxRawNormArgs& A, long long idx) {
   const long long per_w = (long long)A.n_channels * A.W;
@@ -380,7 +614,17 @@ NMX_DEV void nmx_rawnorm_apply(const NmxRawNormArgs& A, long long idx) {
   const float x = A.clean_on_load ? nmx_clean(src[i]) : src[i];
   const float sc = A.scale[(long long)w * A.n_channels + c];
   float out = x;
-  if (sc != 0.f) {
+  if (sc != 0.f && A.method == NMX_RAWNORM_QUANTILE) {
+    const long long wc = (long long)w * A.n_channels + c;
+    double o = nmx_rawnorm_qt_apply(A.qt + wc * NMX_RAWNORM_NQ, A.qn[wc], (double)x);
+    if (A.clip > 0.f) o = o < -(double)A.clip ? -(double)A.clip : (o > (double)A.clip ? (double)A.clip : o);
+    out = nmx_clean((float)o);
+  } else if (sc != 0.f && A.method == NMX_RAWNORM_POWER) {
+    const double* pw = A.pw + ((long long)w * A.n_channels + c) * 3;
+    double o = (nmx_pw_transform((double)x, pw[0]) - pw[1]) / pw[2];
+    if (A.clip > 0.f) o = o < -(double)A.clip ? -(double)A.clip : (o > (double)A.clip ? (double)A.clip : o);
+    out = nmx_clean((float)o);
+  } else if (sc != 0.f) {
     out = (x - A.mean[(long long)w * A.n_channels + c]) * sc;
     if (A.clip > 0.f) out = out < -A.clip ? -A.clip : (out > A.clip ? A.clip : out);
     out = nmx_clean(out);

@@ -250,12 +250,11 @@ class HotPathEngine:
             d.resample_ratio = float(self.resample_ratio)
         if self._raw_norm is not None:              # raw_normalization, last pre-processor
             method, clip, n_hist, add = self._raw_norm
-            codes = {"mean": 1, "zscore": 2, "median": 3, "zscore-median": 4, "robust": 5, "minmax": 6}
-            if method == "quantile":
-                raise NotImplementedError(
-                    "raw_normalization method 'quantile': scikit-learn's QuantileTransformer draws a random subsample "
-                    "of histories longer than 10 000 samples (random_state=None), so the reference itself is not "
-                    "reproducible for raw data; not implemented")
+            # "quantile": scikit-learn's QuantileTransformer subsamples histories of more than 10 000 samples at random
+            # (random_state=None: the reference is not reproducible there); the device draws its own uniformly
+            # random subset per hop and channel (nmx_k_rawnorm.h) -- equal in distribution, exact below 10 000 samples
+            codes = {"mean": 1, "zscore": 2, "median": 3, "zscore-median": 4, "robust": 5, "minmax": 6,
+                     "quantile": 7, "power": 8}
             if method not in codes:
                 raise NotImplementedError(f"raw_normalization method {method!r} has no device implementation")
             d.raw_norm_method = codes[method]

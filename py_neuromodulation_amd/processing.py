@@ -98,19 +98,20 @@ class PreprocessingFilter:
 
 class RawNormalizer:
     """processing/normalization.py:113-116 (Normalizer with type "raw") on the device for "mean", "zscore",
-    "median", "zscore-median" and the scikit-learn based "robust" / "minmax" (nmx_k_rawnorm.h: sliding sums, and
-    for the order statistics a sorted copy of the history merged once per hop); stateful like the reference
-    (one instance = one stream)."""
+    "median", "zscore-median" and the scikit-learn based "robust" / "minmax" / "quantile" / "power"
+    (nmx_k_rawnorm.h: sliding sums; for the order statistics a sorted copy of the history merged once per hop, from
+    which "quantile" fits its 300-entry table -- histories of more than 10 000 samples through a uniformly random
+    10 000-subset like scikit-learn's; "power" fits Yeo-Johnson's lambda by the bounded Brent search of
+    nmx_k_power.h); stateful like the reference (one instance = one stream)."""
 
     def __init__(self, sfreq: float, settings, **kwargs) -> None:
         rs = settings.raw_normalization_settings
         self.sfreq = float(sfreq)
         self._spec = (rs.normalization_method, rs.clip, int(rs.normalization_time_s * sfreq),
                       int(sfreq / settings.sampling_rate_features_hz))
-        if rs.normalization_method not in ("mean", "zscore", "median", "zscore-median", "robust", "minmax"):
-            raise NotImplementedError(f"raw_normalization method {rs.normalization_method!r} has no device "
-                                      "implementation (quantile: the reference subsamples histories of more than "
-                                      "10 000 samples at random; power: Yeo-Johnson likelihood fit)")
+        if rs.normalization_method not in ("mean", "zscore", "median", "zscore-median", "robust", "minmax",
+                                           "quantile", "power"):
+            raise ValueError(f"unknown raw_normalization method {rs.normalization_method!r}")
         self._engine = None
 
     def process(self, data: np.ndarray) -> np.ndarray:
@@ -152,8 +153,7 @@ class FeatureNormalizer:
         if method not in DeviceFeatureNormalizer.METHODS:
             raise NotImplementedError(
                 f"feature normalization_method {method!r} has no device implementation (available: "
-                f"{', '.join(DeviceFeatureNormalizer.METHODS)}); 'power' is scikit-learn's PowerTransformer, whose "
-                "Yeo-Johnson likelihood fit is not restated")
+                f"{', '.join(DeviceFeatureNormalizer.METHODS)})")
         self._settings = settings
         self._dev = None
 
@@ -166,18 +166,18 @@ class FeatureNormalizer:
 
 class DeviceFeatureNormalizer:
     """processing/normalization.py:31-111 on the GPU for normalization_method in {"mean", "median", "zscore",
-    "zscore-median"} and the scikit-learn based "robust", "minmax" and "quantile" (RobustScaler / MinMaxScaler /
-    QuantileTransformer(n_quantiles=300) fitted on nan_to_num(history) every hop: restated in nmx_k_norm.h; histories
-    are at most N = normalization_time_s * sampling_rate_features_hz rows, far below QuantileTransformer's random
-    subsampling threshold of 10 000).  Only "power" (Yeo-Johnson, lambda by maximum likelihood inside
-    scipy.stats) has no device implementation and raises ``NotImplementedError``.
+    "zscore-median"} and the scikit-learn based "robust", "minmax", "quantile" and "power" (RobustScaler / MinMaxScaler /
+    QuantileTransformer(n_quantiles=300) / PowerTransformer fitted on nan_to_num(history) every hop: restated in
+    nmx_k_norm.h and nmx_k_power.h; histories are at most N = normalization_time_s * sampling_rate_features_hz rows, far
+    below QuantileTransformer's random subsampling threshold of 10 000).
 
     ``process(row)`` keeps the reference's call shape (one feature vector per hop);
     ``process_batch(rows)`` normalises ``rows[n_hops, n_features]`` with the same hop-by-hop
     semantics in one kernel launch (rows may also be a device pointer, see ``process_device``).
     """
 
-    METHODS = {"mean": 0, "zscore": 1, "median": 2, "zscore-median": 3, "robust": 4, "minmax": 5, "quantile": 6}
+    METHODS = {"mean": 0, "zscore": 1, "median": 2, "zscore-median": 3, "robust": 4, "minmax": 5, "quantile": 6,
+               "power": 7}
 
     def __init__(self, settings, n_features: int, colmask=None, device: int = 0, lib=None) -> None:
         import ctypes as C

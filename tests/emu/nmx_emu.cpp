@@ -19,6 +19,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_burst_fill.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_kalman.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_norm.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_power.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_rawnorm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_resample.h"
@@ -123,7 +124,7 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int, size_
   for (int it = 0; it < n_items; ++it) nmx_resample_item(A, it / A.n_channels, it % A.n_channels, sm.data());
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t) {
-  if (A.method >= NMX_RAWNORM_MEDIAN) {
+  if (A.method >= NMX_RAWNORM_MEDIAN && A.method != NMX_RAWNORM_POWER) {
     std::vector<float> sm(6 * (size_t)A.max_list + 2 * NMX_RAWNORM_ORDER_NT + 16);
     for (int c = 0; c < A.n_channels; ++c) nmx_rawnorm_order_item(A, c, sm.data());
   } else
@@ -137,6 +138,14 @@ static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t) {
 }
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t) {
   for (int j = 0; j < A.n_cols; ++j) nmx_norm_column(A, j);
+}
+static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be_stream_t) {
+  for (int e = 0; e < P.have + P.n_rows; ++e)
+    for (int j = 0; j < P.n_cols; ++j) nmx_power_prep_at(P, e, j);
+  for (int r = 0; r < A.n_rows; ++r)
+    for (int j = 0; j < A.n_cols; ++j) nmx_power_cell(A, r, j);
+  for (int r = 0; r < P.n_rows; ++r)
+    for (int j = 0; j < P.n_cols; ++j) nmx_power_ring_at(P, r, j);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
   float sm[64];

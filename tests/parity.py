@@ -120,6 +120,13 @@ DECISION_RTOL = 1e-6    # decision margin relative to max |input row| below whic
 STATS = {"compared": 0, "forgiven": {}, "notes": []}
 
 
+def note_forgiven(family: str, accepted: int, compared: int) -> None:
+    """Book entries a case compared (and accepted on a conditioning report) outside `compare`."""
+    STATS["compared"] += int(compared)
+    if accepted:
+        STATS["forgiven"][family] = STATS["forgiven"].get(family, 0) + int(accepted)
+
+
 def reset_stats():
     STATS["compared"] = 0
     STATS["forgiven"] = {}

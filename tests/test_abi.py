@@ -77,7 +77,7 @@ def test_product_loader_has_no_cpu_fallback(tmp_path):
 
 def test_product_package_has_no_host_compute_path():
     """The package neither imports the oracle nor scikit-learn / scipy.signal for a compute fall-back: every
-    normalisation method is either a device kernel or a NotImplementedError that names the setting."""
+    normalisation method is a device kernel."""
     import re
     from pathlib import Path
 
@@ -88,10 +88,12 @@ def test_product_package_has_no_host_compute_path():
     for f in pkg.glob("*.py"):
         src = f.read_text()
         assert not re.search(r"^\s*(import|from)\s+(sklearn|oracle)", src, re.M), f.name
-    assert set(DeviceFeatureNormalizer.METHODS) == {"mean", "median", "zscore", "zscore-median", "robust", "minmax", "quantile"}
+    # all eight methods of the reference (processing/normalization.py:57-70) are device kernels
+    assert set(DeviceFeatureNormalizer.METHODS) == {"mean", "median", "zscore", "zscore-median", "robust", "minmax",
+                                                    "quantile", "power"}
     s = NMSettings.get_default()
-    s.feature_normalization_settings.normalization_method = "power"
-    with pytest.raises(NotImplementedError, match="power"):
+    s.feature_normalization_settings.normalization_method = "no-such-method"
+    with pytest.raises(NotImplementedError, match="no-such-method"):
         FeatureNormalizer(s)
 
 

@@ -369,6 +369,14 @@ def test_feature_normalizer_batches(gpu_lib):
     pc.case_feature_normalizer_batches(gpu_lib)
 
 
+def test_feature_normalizer_power(gpu_lib):
+    pc.case_feature_normalizer_power(gpu_lib)
+
+
+def test_raw_quantile_subsample(gpu_lib):
+    pc.case_raw_quantile_subsample(gpu_lib)
+
+
 def test_bandpower_kalman_sequence(gpu_lib):
     pc.case_bandpower_kalman_sequence(gpu_lib)
 

@@ -82,6 +82,14 @@ def test_feature_normalizer_batches(emu_lib):
     pc.case_feature_normalizer_batches(emu_lib)
 
 
+def test_feature_normalizer_power(emu_lib):
+    pc.case_feature_normalizer_power(emu_lib)
+
+
+def test_raw_quantile_subsample(emu_lib):
+    pc.case_raw_quantile_subsample(emu_lib)
+
+
 def test_stream_output_files(emu_lib, tmp_path):
     pc.case_stream_output_files(emu_lib, tmp_path)
 
