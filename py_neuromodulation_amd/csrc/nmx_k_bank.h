@@ -28,6 +28,7 @@ struct NmxFilterDev {
   int burst_index;  // -1 = none
   int sw_index;     // -1 = none
   int store_raw;    // notch: write y to yout[w][c][W]
+  const float* taps;  // direct mode: the 2 half + 1 centred taps (fp32)
 };
 
 struct NmxBankArgs {
@@ -59,7 +60,54 @@ struct NmxBankArgs {
   float* y_out;     // notch: [n_windows][C][W]
   // LDS carve (float offsets)
   int off_X, off_a, off_b, off_red, lds_floats;
+  // DIRECT mode (windows x taps whose FFT convolution does not fit one LDS transform: >= 6 kHz recordings with 1 s
+  // windows): y[n] = sum_j h[j] x[n + half - j] evaluated as written -- O(W L) instead of O(M log M), any size, the
+  // window streamed from L1 / L2, only y[W] in LDS (at off_X) for the epilogues; burst bands leave as series (yb_out)
+  // for the stand-alone Hilbert kernel
+  int direct;
+  float* yb_out;    // [n_windows][C][n_burst_bands][W]
 };
+
+// direct "same" FIR of one filter into y[0..W) (LDS).  Partial sums of 32 taps in fp32, their total in float64: the
+// rounding of a 13 000-term fp32 chain would sit at the parity tolerance.
+NMX_DEV void nmx_bank_direct(const NmxBankArgs& A, const NmxFilterDev& F, const float* src, float* y) {
+  const int W = A.W, half = F.half, L = 2 * half + 1;
+  const float* NMX_RESTRICT h = F.taps;
+  const float x0 = A.clean_on_load ? nmx_clean(src[0]) : src[0];
+  const float xl = A.clean_on_load ? nmx_clean(src[W - 1]) : src[W - 1];
+  const int ne = A.n_edge;
+  for (int n = NMX_TID; n < W; n += NMX_NT) {
+    // k = n + half - j runs over the (extended) signal; pad_mode 0: x = 0 outside [0, W)
+    int jlo = 0, jhi = L - 1;
+    if (A.pad_mode == 0) {
+      jlo = n + half - (W - 1) > 0 ? n + half - (W - 1) : 0;
+      jhi = n + half < L - 1 ? n + half : L - 1;
+    }
+    double acc = 0.0;
+    for (int j0 = jlo; j0 <= jhi; j0 += 32) {
+      const int j1 = j0 + 31 < jhi ? j0 + 31 : jhi;
+      float part = 0.f;
+      for (int j = j0; j <= j1; ++j) {
+        const int k = n + half - j;
+        float v;
+        if (k >= 0 && k < W) {
+          v = src[k];
+          if (A.clean_on_load) v = nmx_clean(v);
+        } else if (A.pad_mode == 0) {
+          v = 0.f;
+        } else if (k < 0) {   // odd reflection about the first sample, reflect_limited (MNE _smart_pad)
+          v = (-k <= ne) ? 2.f * x0 - (A.clean_on_load ? nmx_clean(src[-k]) : src[-k]) : 0.f;
+        } else {
+          const int r = k - (W - 1);
+          v = (r <= ne) ? 2.f * xl - (A.clean_on_load ? nmx_clean(src[W - 1 - r]) : src[W - 1 - r]) : 0.f;
+        }
+        part = fmaf(h[j], v, part);
+      }
+      acc += (double)part;
+    }
+    y[n] = (float)acc;
+  }
+}
 
 NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
   float2* X = (float2*)(smem + A.off_X);
@@ -71,6 +119,37 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
                      (A.starts ? A.starts[w] : 0ll);
 
+  if (A.direct) {   // ---- direct convolution (see NmxBankArgs::direct): y in LDS, the same epilogues -----------
+    float* y = smem + A.off_X;
+    for (int fi = 0; fi < A.n_filters; ++fi) {
+      const NmxFilterDev& F = A.f[fi];
+      nmx_bank_direct(A, F, src, y);
+      NMX_SYNC();
+      if (F.bp_seglen > 0) {
+        const bool need_mc = (A.bp_features & 6u) != 0;
+        float act, mob, comp;
+        nmx_hjorth(y + (W - F.bp_seglen), F.bp_seglen, red, 1, need_mc, act, mob, comp);
+        if (NMX_TID == 0) {
+          int col = A.bp_cols.base + c * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
+          if (A.bp_features & 1u) {
+            out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u);
+            col += A.bp_cols.b_stride;
+          }
+          if (A.bp_features & 2u) { out_row[col] = nmx_nan_to_num(mob); col += A.bp_cols.b_stride; }
+          if (A.bp_features & 4u) out_row[col] = nmx_nan_to_num(comp);
+        }
+      }
+      float* dsts[3] = {
+          F.sw_index >= 0 ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr,
+          F.store_raw ? A.y_out + ((long long)w * A.n_channels + c) * W : nullptr,
+          F.burst_index >= 0 ? A.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr};
+      for (int d = 0; d < 3; ++d)
+        if (dsts[d])
+          for (int i = NMX_TID; i < W; i += NMX_NT) dsts[d][i] = y[i];
+      NMX_SYNC();
+    }
+    return;
+  }
   // ---- stage the (padded) window as M/2 packed complex samples in bufB -----------------
   if (A.pad_mode == 0) {
     for (int i = NMX_TID; i < Mh; i += NMX_NT) {

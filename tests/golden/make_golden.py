@@ -164,6 +164,66 @@ def case_bursts_sequence():
     print("bursts_sequence", out["values"].shape)
 
 
+def case_c5_degenerate():
+    """BASELINE config[4] (30 kHz, 17 ms windows, 1 kHz feature rate) where the reference degenerates:
+    * Bursts: samples_overlap = int(sfreq * seg_s / feat_hz) = int(0.51) = 0, and `filtered_data[:, :, -0:]` is the
+      WHOLE window -- every hop appends all 510 envelope samples to the percentile buffer (features/bursts.py:81-85,
+      155-166); recorded over 40 hops across the ring overflow (time_duration_s = 0.5 -> 15 000 samples);
+    * Welch: nperseg = sfreq = 30 000 > the window; scipy shrinks the segment to the window while the reference's
+      band indices keep the 1 Hz grid (features/oscillatory.py:136-144): bands below bin 256 read OTHER frequencies,
+      any band beyond raises IndexError.  Both recorded."""
+    sfreq, C = 30000, 2
+    base = nm.NMSettings.get_default()
+    base.frequency_ranges_hz = {"gamma": [60, 200], "HFA": [200, 500], "MUA": [500, 3000]}
+    base.sampling_rate_features_hz = 1000
+    base.segment_length_features_ms = 17
+    for name in ("fft_settings", "welch_settings", "stft_settings"):
+        base[name].windowlength_ms = 17
+    base.bandpass_filter_settings.segment_lengths_ms = {"gamma": 17, "HFA": 10, "MUA": 5}
+    base.bursts_settings.frequency_bands = ["HFA", "MUA"]
+    base.bursts_settings.time_duration_s = 0.5
+    s = base.validate()
+    W, hop, nh = 510, 30, 40
+    T = W + (nh - 1) * hop
+    rng = np.random.default_rng(55)
+    t = np.arange(T) / sfreq
+    amp = 1 + 0.8 * np.sin(2 * np.pi * 40 * t)
+    data = rng.standard_normal((C, T)) * 20 + 30 * amp * np.sin(2 * np.pi * 900 * t) + 15 * np.sin(2 * np.pi * 300 * t)
+    ch_names = [f"ch{i}" for i in range(C)]
+    out = {"settings_json": dump(s), "sfreq": sfreq, "data": data, "ch_names": np.array(ch_names), "W": W, "hop": hop}
+    bu = nm.features.Bursts(s, ch_names, sfreq)
+    assert bu.samples_overlap == 0
+    rows, keys = [], None
+    for i in range(nh):
+        d = bu.calc_feature(data[:, i * hop:i * hop + W])
+        keys = list(d.keys())
+        rows.append([float(v) for v in d.values()])
+    out["bursts_taps"] = bu.bandpass_filter.filter_bank
+    out["bursts_keys"] = np.array(keys)
+    out["bursts_values"] = np.array(rows)
+    # Welch with the three bands: IndexError; with the one band whose indices stay inside the shrunk spectrum: values
+    try:
+        nm.features.Welch(s, ch_names, sfreq).calc_feature(data[:, :W])
+        out["welch_error"] = ""
+    except Exception as e:   # noqa: BLE001
+        out["welch_error"] = type(e).__name__
+    s2 = nm.NMSettings.get_default()
+    s2.frequency_ranges_hz = {"gamma": [60, 200]}
+    s2.sampling_rate_features_hz = 1000
+    s2.segment_length_features_ms = 17
+    for name in ("fft_settings", "welch_settings", "stft_settings"):
+        s2[name].windowlength_ms = 17
+    s2.bandpass_filter_settings.segment_lengths_ms = {"gamma": 17}
+    s2.bursts_settings.frequency_bands = ["gamma"]
+    s2 = s2.validate()
+    out["welch1_settings_json"] = dump(s2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pack(nm.features.Welch(s2, ch_names, sfreq).calc_feature(data[:, :W]), "welch1", out)
+    np.savez_compressed(HERE / "c5_degenerate.npz", **out)
+    print("c5_degenerate", out["bursts_values"].shape, out["welch_error"], len(out["welch1_keys"]))
+
+
 def case_sharpwave_tests():
     """Inputs of the reference's tests/test_sharpwave.py (impulses, sines)."""
     sfreq = 1000
@@ -563,6 +623,7 @@ if __name__ == "__main__":
     case_feat_2k()
     case_special_rows()
     case_bursts_sequence()
+    case_c5_degenerate()
     case_sharpwave_tests()
     case_pipeline()
     case_nan_and_channels()

@@ -850,6 +850,51 @@ def case_config5_30khz_512pt(lib):
     eng.close()
 
 
+def case_config5_degenerate(lib):
+    """BASELINE config[4]'s rate with the two features the plain C5 case leaves out, against the REFERENCE golden
+    c5_degenerate.npz: Bursts with samples_overlap = 0 (the reference appends the whole window per hop, 40 hops
+    across the overflow of a 15 000-sample ring), Welch under a shrunk segment (IndexError with bands beyond the
+    shrunk spectrum; one low band: the reference's values at the frequencies the shrunk grid really has)."""
+    import warnings
+
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from tests.helpers import golden_dict, load_golden, settings_from_json
+
+    g = load_golden("c5_degenerate")
+    s = settings_from_json(g["settings_json"])
+    sfreq, W, hop = float(g["sfreq"]), int(g["W"]), int(g["hop"])
+    ch, data = [str(c) for c in g["ch_names"]], g["data"]
+    s.features.disable_all()
+    s.features.bursts = True
+    keys = [str(k) for k in g["bursts_keys"]]
+    want = g["bursts_values"]
+    nh = len(want)
+    eng = HotPathEngine(s, ch, sfreq, lib=lib, window=W, bank_taps=None)
+    assert eng.keys == keys
+    got = np.concatenate([eng.process_batch(data, np.arange(0, 13) * hop), eng.process_batch(data, np.arange(13, nh) * hop)])
+    eng.close()
+    for i in range(nh):
+        w = data[:, i * hop:i * hop + W]
+        n_bad, rep, _ = parity.compare(keys, got[i], want[i], s, sfreq, 60.0, W, verifier=parity.Verifier(s, ch, sfreq, w))
+        assert n_bad == 0, f"bursts hop {i}\n{rep}"
+    s.features.disable_all()
+    s.features.welch = True
+    with pytest.raises(IndexError):
+        HotPathEngine(s, ch, sfreq, lib=lib, window=W)
+    s1 = settings_from_json(g["welch1_settings_json"])
+    s1.features.disable_all()
+    s1.features.welch = True
+    eng = HotPathEngine(s1, ch, sfreq, lib=lib, window=W)
+    w1 = golden_dict(g, "welch1")
+    assert eng.keys == list(w1)
+    got1 = eng.process_window(data[:, :W])
+    n_bad, rep, _ = parity.compare(eng.keys, got1, list(w1.values()), s1, sfreq, 60.0, W,
+                                   verifier=parity.Verifier(s1, ch, sfreq, data[:, :W]))
+    assert n_bad == 0, rep
+    eng.close()
+
+
 def case_raw_normalizer_order_methods(lib):
     """raw_normalization "median", "zscore-median" and the scikit-learn based "robust" / "minmax" vs the
     REFERENCE golden norm_methods.npz (14 windows, 0.7 s history: trims of 401 then 100 samples, a coarsely quantised
@@ -1244,6 +1289,46 @@ def case_random_settings(lib, seed):
         n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[:-1], s, sfreq, 40.0, W, verifier=pv.row(i))
         assert n_bad == 0, f"seed {seed} ({sfreq} Hz, W {W}, {data.shape[0]} ch) hop {i}\n{rep}"
         assert got[i, -1] == want[-1]
+
+
+def case_high_rate_direct_fir(lib):
+    """A recording at 8 kHz with 1 s windows and NO resampling: the automatic band-pass taps are 13 201 long, the notch
+    7 999 -- the FFT convolution of a window (M >= 14 600 / 16 000) does not fit one LDS transform, so notch and
+    band-pass bank run as direct convolutions (nmx_k_bank.h: NmxBankArgs::direct; round 2 refused this shape), the
+    burst bands go through the stand-alone Hilbert kernel.  Stream.run against the oracle's run_stream."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.stream import Stream
+
+    sfreq, C = 8000.0, 2
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.bandpass_filter = s.features.raw_hjorth = s.features.bursts = True
+    s.frequency_ranges_hz = {"alpha": [8, 12], "high_beta": [20, 35]}
+    s.bandpass_filter_settings.segment_lengths_ms = {"alpha": 500, "high_beta": 333}
+    s.bursts_settings.frequency_bands = ["high_beta"]
+    s.bursts_settings.time_duration_s = 3
+    s.preprocessing = ["notch_filter"]
+    s.postprocessing.feature_normalization = False
+    s = s.validate() if hasattr(s, "validate") else s
+    rng = np.random.default_rng(8)
+    T = 8000 + 2 * 800
+    t = np.arange(T) / sfreq
+    data = rng.standard_normal((C, T)) * 30 + 15 * np.sin(2 * np.pi * 25 * t) + 8 * np.sin(2 * np.pi * 50 * t) + rng.uniform(-80, 80, (C, 1))
+    ch = chmod.get_default_channels_from_data(data).to_dict("list")
+    df = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+    rows = orc.run_stream(data, sfreq, s, ch, line_noise=50)
+    assert list(df.columns) == list(rows[0].keys()) and len(df) == len(rows) == 3
+    got = df.to_numpy(float)
+    starts, ends, _ = orc.window_schedule(T, sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    W = int(ends[0] - starts[0])
+    pv = parity.PipelineVerifiers(s, ch, sfreq, data, starts, W, line_noise=50, ends=ends)
+    cols = list(df.columns)
+    for i, r in enumerate(rows):
+        want = np.array(list(r.values()))
+        n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[:-1], s, sfreq, 40.0, W, verifier=pv.row(i))
+        assert n_bad == 0, f"hop {i}\n{rep}"
 
 
 def case_short_windows(lib):

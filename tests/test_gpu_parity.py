@@ -377,6 +377,14 @@ def test_raw_quantile_subsample(gpu_lib):
     pc.case_raw_quantile_subsample(gpu_lib)
 
 
+def test_high_rate_direct_fir(gpu_lib):
+    pc.case_high_rate_direct_fir(gpu_lib)
+
+
+def test_config5_degenerate_bursts_and_welch(gpu_lib):
+    pc.case_config5_degenerate(gpu_lib)
+
+
 def test_bandpower_kalman_sequence(gpu_lib):
     pc.case_bandpower_kalman_sequence(gpu_lib)
 

@@ -90,6 +90,14 @@ def test_raw_quantile_subsample(emu_lib):
     pc.case_raw_quantile_subsample(emu_lib)
 
 
+def test_high_rate_direct_fir(emu_lib):
+    pc.case_high_rate_direct_fir(emu_lib)
+
+
+def test_config5_degenerate_bursts_and_welch(emu_lib):
+    pc.case_config5_degenerate(emu_lib)
+
+
 def test_stream_output_files(emu_lib, tmp_path):
     pc.case_stream_output_files(emu_lib, tmp_path)
 
