@@ -80,14 +80,46 @@ def cpu_baseline(s, C: int, sfreq: float, n_windows: int, seed: int):
     channels = {"name": names, "rereference": ["average"] * C, "used": [1] * C, "target": [0] * C,
                 "type": ["ecog"] * C, "status": ["good"] * C, "new_name": [f"{n}_avgref" for n in names]}
     dp = orc.DataProcessor(sfreq, s, channels, line_noise=50)
+    rows = []
     for k in range(2):   # warm-up (the first hop also fills the burst ring like the reference's first hop)
-        dp.process(x[:, k * hop:k * hop + W])
+        rows.append(dp.process(x[:, k * hop:k * hop + W]))
     per = []
     for k in range(2, n_windows + 2):
         t0 = time.perf_counter()
-        dp.process(x[:, k * hop:k * hop + W])
+        rows.append(dp.process(x[:, k * hop:k * hop + W]))
         per.append(time.perf_counter() - t0)
-    return 1.0 / float(np.median(per)), float(np.sum(per))
+    return 1.0 / float(np.median(per)), float(np.sum(per)), x, rows
+
+
+FAMILIES = ("RawHjorth", "_raw", "LineLength", "_fft_", "_welch_", "_stft_", "_bandpass_", "_Sharpwave_", "_bursts_")
+
+
+def max_rel_err(eng_factory, x64, rows, W, hop):
+    """SURVEY 8(d) "max rel err" column: the hops the CPU oracle just processed (cpu_baseline leg, same data, fresh
+    state on both sides) through a fresh engine; per feature family the largest |gpu - cpu| / max(|cpu|, floor) with
+    floor = 1e-3 x the family's median magnitude (features that pass through zero), its 99.9th percentile and the
+    entry count.  Informational: the gate is tests/ (per-entry policy of tests/parity.py)."""
+    eng = eng_factory()
+    n = len(rows)
+    got = eng.process_batch(x64.astype(np.float32), np.arange(n, dtype=np.int64) * hop).astype(np.float64)
+    keys = list(rows[0].keys())
+    assert keys == list(eng.keys), "column order differs from the oracle's"
+    want = np.array([[r[k] for k in keys] for r in rows], dtype=np.float64)
+    eng.close()
+    out = {}
+    for fam in FAMILIES:
+        sel = np.array([fam in k for k in keys])
+        if not sel.any():
+            continue
+        g, w = got[:, sel], want[:, sel]
+        ok = np.isfinite(g) & np.isfinite(w)
+        floor = float(np.median(np.abs(w[ok]))) if ok.any() else 0.0
+        rel = np.abs(g[ok] - w[ok]) / np.maximum(np.abs(w[ok]), max(floor, 1e-30))
+        out[fam.strip("_")] = {"max": float(rel.max()) if rel.size else None,
+                               "p999": float(np.quantile(rel, 0.999)) if rel.size else None,
+                               "share_above_1e-5": float((rel > 1e-5).mean()) if rel.size else None,
+                               "entries": int(rel.size), "nonfinite_mismatch": int((np.isfinite(g) != np.isfinite(w)).sum())}
+    return out
 
 
 def _allcores_worker(args):
@@ -137,6 +169,50 @@ def bank_flops_per_item_pair(M: int, n_filters: int, seglens) -> float:
     complex FFT(M) ~ 5 M log2 M.  Returned per item (one channel)."""
     cfft = 5.0 * M * np.log2(M)
     return float(0.5 * (cfft + n_filters * (2 * M + cfft)) + 3 * sum(seglens))
+
+
+def roofline_mode_a(torch, dev, dev_index, channels=256, windows=4096, steps=5):
+    """SURVEY 8(d) "Mode A" for the HBM-bound half of the north star (BASELINE config[1]'s feature set: FFT band power +
+    Hjorth + LineLength): DISTINCT data per window (hop = W = 1000), 4.2 GB of input -- far beyond the 256 MB
+    Infinity Cache -- so every byte comes from HBM; ONE launch of the time / oscillatory kernel over all
+    channels x windows items, timed with HIP events on the launch stream (nmx_last_timing_ms stage 2)."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.fft = s.features.raw_hjorth = s.features.linelength = True
+    s.postprocessing.feature_normalization = False
+    W, T = 1000, windows * 1000
+    old = os.environ.get("NMX_CHUNK_WINDOWS")
+    os.environ["NMX_CHUNK_WINDOWS"] = str(windows)   # one launch covers the whole batch (read at plan creation)
+    try:
+        eng = HotPathEngine(s, [f"ch{i}" for i in range(channels)], 1000.0, device=dev_index)
+    finally:
+        if old is None:
+            del os.environ["NMX_CHUNK_WINDOWS"]
+        else:
+            os.environ["NMX_CHUNK_WINDOWS"] = old
+    x = torch.randn((channels, T), dtype=torch.float32, device=dev) * 50
+    out = torch.empty((windows, eng.n_outputs), dtype=torch.float32, device=dev)
+    starts = np.arange(windows, dtype=np.int64) * W
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ms = []
+    for i in range(steps + 2):
+        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
+        torch.cuda.synchronize(dev)
+        if i >= 2:
+            ms.append(eng.timing_ms(2))
+    t = float(np.mean(ms))
+    nbytes = windows * channels * (4 * W + 4 * eng.n_outputs / channels)
+    kern = eng.kernels(2)
+    eng.close()
+    del x, out
+    return {"bound": "hbm", "kernel": kern, "achieved": nbytes / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / t / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": t,
+            "algorithmic_bytes_per_launch": nbytes,
+            "workload": f"Mode A: {channels} ch x {windows} DISTINCT 1000-sample windows (hop = W), "
+                        "FFT band power + Hjorth + LineLength, no pre-processing"}
 
 
 def config_settings(name: str):
@@ -270,6 +346,7 @@ def main() -> None:
     ap.add_argument("--cpu-windows", type=int, default=24, help="hops timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=32, help="worker processes of cpu_baseline_allcores (0 = skip)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start_ms measurement")
+    ap.add_argument("--no-mode-a", action="store_true", help="skip the roofline_modeA measurement (time / oscillatory kernel from HBM)")
     ap.add_argument("--no-preproc", action="store_true", help="skip notch + re-referencing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
@@ -436,11 +513,25 @@ def main() -> None:
             "cold_start_ms": cold_ms,
             "regime": "steady state: warm-up steps fill the 30 s burst history; cold_start_ms = first step of a fresh plan",
         }
+        if world == 1 and not args.no_mode_a:
+            try:
+                eng.close()
+                del x, out
+                res["roofline_modeA"] = roofline_mode_a(torch, dev, dev_index)
+            except Exception as e:   # never let the context rows break the bench line
+                res["roofline_modeA"] = {"error": repr(e)}
         if args.cpu_windows > 0 and world == 1:   # CPU baseline: rank 0 at N = 1 only
-            v, secs = cpu_baseline(s, C, sfreq, args.cpu_windows, 99)
+            v, secs, x64, orows = cpu_baseline(s, C, sfreq, args.cpu_windows, 99)
             res["cpu_baseline"] = {"value": v, "unit": "windows/s", "cores": 1, "kind": "port",
                                    "sample": f"median hop time over {args.cpu_windows} hops (after 2 warm-up hops) of the "
                                              f"same {C}-channel workload through oracle.DataProcessor.process ({secs:.1f} s)"}
+            try:
+                res["max_rel_err_vs_cpu"] = max_rel_err(
+                    lambda: HotPathEngine(s, ch, sfreq, device=dev_index, ref_matrix=car_matrix(C) if pre else None,
+                                          notch_taps=fir_design.notch_bank(sfreq, 50) if pre else None),
+                    x64, orows, W, hop)
+            except Exception as e:   # never let the context rows break the bench line
+                res["max_rel_err_vs_cpu"] = {"error": repr(e)}
             if args.cpu_procs > 0 and C == 256:
                 try:
                     procs = min(args.cpu_procs, os.cpu_count() or 1)

@@ -12,6 +12,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 _FORGIVEN: list[tuple[str, int, dict, list]] = []
+_GPU_TESTS: set[str] = set()
+BUDGET_FILE = Path(__file__).resolve().parent / "accepted_miss_budget.json"
 
 
 def pytest_configure(config):
@@ -51,6 +53,8 @@ def _parity_stats(request):
     st = parity.STATS
     if st["compared"]:
         _FORGIVEN.append((request.node.nodeid, st["compared"], dict(st["forgiven"]), list(st["notes"])))
+        if request.node.get_closest_marker("gpu") is not None:
+            _GPU_TESTS.add(request.node.nodeid)
 
 
 def pytest_terminal_summary(terminalreporter):
@@ -63,6 +67,46 @@ def pytest_terminal_summary(terminalreporter):
         tr.write_line(f"{nodeid}: {n} compared, {tot} accepted {forgiven if tot else ''}")
         for note in notes[:6]:
             tr.write_line(f"    {note}")
+
+
+def _gpu_miss_totals():
+    tot, compared, n = {}, 0, 0
+    for nodeid, cmp_, forgiven, _ in _FORGIVEN:
+        if nodeid not in _GPU_TESTS:
+            continue
+        n += 1
+        compared += cmp_
+        for fam, k in forgiven.items():
+            tot[fam] = tot.get(fam, 0) + k
+    return tot, compared, n
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Drift guard of the tolerance policy (tests/parity.py): the fixed-seed GPU tier accepts a known number of
+    misses per family on verified conditioning reports (tests/accepted_miss_budget.json, recorded on the MI355X with
+    NMX_WRITE_MISS_TOTALS=<file>).  A run of the WHOLE tier that accepts more than 25 % (+ 3) above that in any
+    family fails: an fp32 regression that still hides inside the per-entry reports shows up as a count."""
+    import json
+    import math
+    import os
+
+    tot, compared, n = _gpu_miss_totals()
+    out = os.environ.get("NMX_WRITE_MISS_TOTALS")
+    if out and n:
+        Path(out).write_text(json.dumps({"_tests": n, "_compared": compared, **dict(sorted(tot.items()))}, indent=1))
+    if not BUDGET_FILE.exists() or not n:
+        return
+    budget = json.loads(BUDGET_FILE.read_text())
+    if n < int(budget.get("_tests", 0)):
+        return   # a subset of the tier (-k, -x after a failure): counts are not comparable
+    over = {f: (k, budget.get(f, 0)) for f, k in tot.items()
+            if not f.startswith("_") and k > math.ceil(1.25 * budget.get(f, 0)) + 3}
+    if over:
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        msg = f"accepted tolerance misses above the recorded budget (got, budget): {over}"
+        if tr is not None:
+            tr.write_sep("!", msg)
+        session.exitstatus = 1
 
 
 @pytest.fixture(scope="session")

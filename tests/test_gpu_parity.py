@@ -177,6 +177,50 @@ def test_full_size_properties_256ch(gpu_lib):
         e.close()
 
 
+def test_headline_bursts_through_the_ring_256ch(gpu_lib):
+    """The bursts columns at the headline width (256 ch @ 1 kHz, all features, notch + CAR over all 256 rows) against
+    the oracle THROUGH the 30 s percentile history: 330 hops (the ring is full from hop 291), two batches, 8 of the
+    256 channels.  The oracle gets those 8 rows of the common-average-referenced recording (float64 product) and
+    runs notch + Bursts hop by hop; every bursts column of those channels is compared under the standard policy
+    (decision-margin verifier for env >= thr)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+
+    C, n_hops = 256, 330
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(77)
+    t = np.arange(T) / 1000.0
+    amp = 1 + 0.7 * np.sin(2 * np.pi * 0.31 * t)
+    x = (rng.standard_normal((C, T)) * 50 + 25 * amp * np.sin(2 * np.pi * 18 * t) + 5 * np.sin(2 * np.pi * 70 * t)
+         + rng.uniform(-500, 500, (C, 1))).astype(np.float32)
+    starts = np.arange(n_hops) * 100
+    s, eng = _bench_like_engine(gpu_lib, C)
+    got = np.concatenate([eng.process_batch(x, starts[:200]), eng.process_batch(x, starts[200:])])
+    eng.close()
+    pick = [0, 3, 64, 65, 127, 128, 200, 255]
+    R = np.full((C, C), -1.0 / (C - 1))
+    np.fill_diagonal(R, 1.0)
+    xr = R[pick] @ x.astype(np.float64)
+    names = [f"ch{i}_avgref" for i in pick]
+    so = NMSettings.get_default()
+    so.features.disable_all()
+    so.features.bursts = True
+    so.postprocessing.feature_normalization = False
+    notch = orc.NotchFilter(1000.0, 50)
+    bu = orc.Bursts(so, names, 1000.0)
+    cols = [i for i, k in enumerate(eng.keys) if "_bursts_" in k and k.split("_bursts_")[0] in names]
+    keys = [eng.keys[i] for i in cols]
+    for i in range(n_hops):
+        w = notch.process(xr[:, starts[i]:starts[i] + 1000])
+        want = bu.calc_feature(w)
+        assert list(want) == keys
+        if i % 10 and i < 280:
+            continue   # every tenth hop while the history fills, every hop across and after the overflow
+        n_bad, rep, _ = parity.compare(keys, got[i][cols], list(want.values()), so, 1000.0, 60.0, 1000,
+                                       verifier=parity.Verifier(so, names, 1000.0, w, bursts=bu, raw=x[:, starts[i]:starts[i] + 1000].astype(np.float64), n_stages=2))
+        assert n_bad == 0, f"hop {i}\n{rep}"
+
+
 def _config3_settings():
     from py_neuromodulation_amd import NMSettings
 
