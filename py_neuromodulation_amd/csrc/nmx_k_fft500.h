@@ -38,6 +38,27 @@ struct NmxW500TwReg {
   }
   NMX_DEV nmx_c2 get(int i) const { return a[i]; }
 };
+// 11 instead of 17 twiddle registers: the stage-3 twiddles w^(j r), r = 2, 3, 4, are formed from w^j when they are
+// asked for (three complex products per half) -- for kernels that are short of registers, not of issue slots
+struct NmxW500TwRegC {
+  nmx_c2 a[9], b[2];
+  NMX_DEV void load(const float* tab, int lane) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = ((const nmx_c2*)tab)[i * 64 + lane];
+    b[0] = ((const nmx_c2*)tab)[9 * 64 + lane];
+    b[1] = ((const nmx_c2*)tab)[13 * 64 + lane];
+  }
+  NMX_DEV nmx_c2 get(int i) const {
+    if (i < 9) return a[i];
+    const nmx_c2 w1 = b[(i - 9) >> 2];
+    const int r = (i - 9) & 3;   // 0..3: w^1 .. w^4
+    if (r == 0) return w1;
+    const nmx_c2 w2 = nmx_cmul(w1, w1);
+    if (r == 1) return w2;
+    if (r == 2) return nmx_cmul(w2, w1);
+    return nmx_cmul(w2, w2);
+  }
+};
 struct NmxW500TwLds {
   const nmx_c2* p;   // table + lane
   NMX_DEV nmx_c2 get(int i) const { return p[64 * i]; }

@@ -96,28 +96,30 @@ struct NmxTdMask {
 // caller then runs the cleaning path).  `cen`: when not null, the centred window x - mean is written there (LDS,
 // natural order, W floats; entries beyond W are not touched).
 // WC: the window length when it is a compile-time constant (the reciprocals below then are constants too), 0 = A.W.
-template <int WC = 0>
+// SUM4: the four wave sums of pass 2 through nmx_wave_sum4 (14 instead of 32 instructions; off in the prefetching
+// kernel, where the longer live range of the line-length sum costs it a register spill -- and a spill reload is a
+// vector-memory load that waits for the prefetch).
+template <int WC = 0, bool SUM4 = true>
 NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, float* cen) {
   const int lane = (int)(threadIdx.x & 63);
   const int W = WC ? WC : A.W;
   auto add = [](float a, float b) { return a + b; };
   // ---- pass 1: sum x, first differences, sum |d1| ----------------------------------------------------------
-  nmx_c2 D[4][2], Y[4][2];
+  nmx_c2 D[4][2];
   nmx_c2 a0 = nmx_mk2(0.f, 0.f);
   float p3 = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (256 * k >= W) {
-      D[k][0] = D[k][1] = Y[k][0] = Y[k][1] = nmx_mk2(0.f, 0.f);
+      D[k][0] = D[k][1] = nmx_mk2(0.f, 0.f);
       continue;
     }
     const nmx_c2 X0 = R.x[k].xy, X1 = R.x[k].zw;
-    Y[k][0] = nmx_mk2(R.x[k].y, R.x[k].z);
-    Y[k][1] = nmx_mk2(R.x[k].w, R.s[k].x);
+    const nmx_c2 Y0 = nmx_mk2(R.x[k].y, R.x[k].z), Y1 = nmx_mk2(R.x[k].w, R.s[k].x);
     a0 += X0;
     a0 += X1;
-    D[k][0] = Y[k][0] - X0;
-    D[k][1] = Y[k][1] - X1;
+    D[k][0] = Y0 - X0;
+    D[k][1] = Y1 - X1;
     if (!(4 * (63 + 64 * k) + 5 < W)) {   // ragged group: d1 of the samples without a successor := 0
       const NmxTdMask m(4 * (lane + 64 * k), W);
       D[k][0] *= m.xx;
@@ -130,17 +132,18 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
   }
   const float p0 = nmx_wave_reduce(a0.x + a0.y, 0.f, add);
   if (!(fabsf(p0) < INFINITY)) return false;   // NaN / +-inf in the window (wave-uniform)
-  p3 = nmx_wave_reduce(p3, 0.f, add);
+  if (!SUM4) p3 = nmx_wave_reduce(p3, 0.f, add);
   R.sum = p0;
   const float rW = 1.f / (float)W, rW1 = 1.f / (float)(W - 1), rW2 = 1.f / (float)(W - 2);   // (scalar unit: W is uniform)
   const float m0 = p0 * rW;
   float* out_row = A.out + (long long)w * A.n_outputs;
   const bool hj = (A.features & NMXD_F_HJORTH) != 0;
+  bool p3_done = !SUM4;
   if (hj || cen) {
     // sums of d1 and d2 telescope
     const float d_first = R.first.y - R.first.x, d_last = R.last.y - R.last.x;
     const float m1 = (R.last.y - R.first.x) * rW1, m2 = (d_last - d_first) * rW2;
-    const nmx_c2 M0 = nmx_mk2(m0, m0), M1 = nmx_mk2(m1, m1), M2 = nmx_mk2(m2, m2), two = nmx_mk2(-2.f, -2.f);
+    const nmx_c2 M0 = nmx_mk2(m0, m0), M1 = nmx_mk2(m1, m1), M2 = nmx_mk2(m2, m2);
     nmx_c2 q0 = nmx_mk2(0.f, 0.f), q1 = q0, q2 = q0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -156,8 +159,10 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       q0 = nmx_c2_fma(E0, E0, q0);
       q0 = nmx_c2_fma(E1, E1, q0);
       nmx_c2 F0 = D[k][0] - M1, F1 = D[k][1] - M1;
-      // second differences: Z - 2 Y + X, Z = the next aligned pair
-      nmx_c2 G0 = nmx_c2_fma(Y[k][0], two, X1) + X0 - M2, G1 = nmx_c2_fma(Y[k][1], two, R.s[k]) + X1 - M2;
+      // second differences = differences of the first ones, d1[4] = x5 - x4 (the shifted pairs are rebuilt here
+      // rather than kept from pass 1: registers)
+      const nmx_c2 S0 = nmx_mk2(D[k][0].y, D[k][1].x), S1 = nmx_mk2(D[k][1].y, R.s[k].y - R.s[k].x);
+      nmx_c2 G0 = S0 - D[k][0] - M2, G1 = S1 - D[k][1] - M2;
       if (!full) {
         F0 *= m.xx; F1 *= m.x1;
         G0 *= m.xx; G1 *= m.n1;
@@ -168,8 +173,13 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       q2 = nmx_c2_fma(G1, G1, q2);
     }
     if (hj) {
-      const float s0 = nmx_wave_reduce(q0.x + q0.y, 0.f, add), s1 = nmx_wave_reduce(q1.x + q1.y, 0.f, add),
-                  s2 = nmx_wave_reduce(q2.x + q2.y, 0.f, add);
+      float s0 = q0.x + q0.y, s1 = q1.x + q1.y, s2 = q2.x + q2.y;
+      if (SUM4) {
+        nmx_wave_sum4(p3, s0, s1, s2);   // (the line length rides along)
+        p3_done = true;
+      } else {
+        s0 = nmx_wave_reduce(s0, 0.f, add); s1 = nmx_wave_reduce(s1, 0.f, add); s2 = nmx_wave_reduce(s2, 0.f, add);
+      }
       if (lane == 0) {
         const float v0 = s0 * rW, v1 = s1 * rW1, v2 = s2 * rW2;
         float act, mob, comp;
@@ -191,6 +201,7 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       }
     }
   }
+  if (!p3_done && (A.features & NMXD_F_LINELENGTH)) p3 = nmx_wave_reduce(p3, 0.f, add);
   if (lane == 0) {
     if (A.features & NMXD_F_LINELENGTH) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = p3 * rW1 * rW1;
     if (A.features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = R.last.y;

@@ -66,12 +66,16 @@ struct NmxBandAcc {
       if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
   }
   NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
+    float tot[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) tot[b] = s[b];
+#pragma unroll
+    for (int b = 0; b < NB; b += 4) nmx_wave_sum4(tot[b], tot[b + 1], tot[b + 2], tot[b + 3]);   // (NB is 4 or 8)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= n_bands) continue;
-      const float tot = nmx_wave_reduce(s[b], 0.f, [](float a_, float b_) { return a_ + b_; });
       const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
-      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot * __builtin_amdgcn_rcpf((float)cnt) : NAN;
+      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot[b] * __builtin_amdgcn_rcpf((float)cnt) : NAN;
     }
   }
 };
@@ -81,8 +85,9 @@ struct NmxBandAcc {
 // LOW: the persistent kernel's form -- no STFT, every band below bin 100 (nmx_timeosc_w1000_low_ok), the first 102
 // entries of the real-transform twiddle table in LDS at smem + 2016: NO vector-memory load inside the item (loads retire
 // in order, so one would wait for the prefetch of the next window to land first).
-template <int NB, bool LOW = false>
-NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& Rt, const NmxW500TwReg& T, float* smem) {
+// LOWNP: the low-band form WITHOUT the LDS twiddle copy (one item per workgroup: nothing to amortise a copy over).
+template <int NB, bool LOW = false, typename TW = NmxW500TwReg, bool LOWNP = false>
+NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& Rt, const TW& T, float* smem) {
   const int lane = (int)(threadIdx.x & 63);
   nmx_c2* fa = (nmx_c2*)smem;                    // [500]
   nmx_c2* fb = (nmx_c2*)(smem + 1008);           // [501]
@@ -96,7 +101,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
     const bool td = (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
     // (always: the window sum it forms is also the NaN / infinity test of the window)
-    const bool fast = nmx_td_emit<1000>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
+    const bool fast = nmx_td_emit<1000, !LOW>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
     wsum = Rt.sum;
     if (fast) {
       if (!LOW && A.stft.enabled) {   // park the window in LDS (group 3: lanes 0..57)
@@ -144,7 +149,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
                          ? A.fft.k_hi : (A.welch.enabled ? A.welch.k_hi + 1 : 0);
     const float2* Z = (const float2*)((LOW || kmax <= 100) ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
                                                            : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
-    const float2* twr = LOW ? (const float2*)(smem + 2016) : (A.fft.enabled ? A.fft : A.welch).fft.twr;
+    const float2* twr = (LOW && !LOWNP) ? (const float2*)(smem + 2016) : (A.fft.enabled ? A.fft : A.welch).fft.twr;
     auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
       const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
       if (kk == 0) return make_float2(0.f, 0.f);

@@ -83,6 +83,21 @@ __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArg
   nmx_timeosc_w1000_body<NB>(A, w, c, R, T, nmx_smem_wave);
 }
 
+// low bands, no STFT, ONE item per workgroup at 5 waves per SIMD (96 VGPRs: compact twiddles, no prefetch registers):
+// the per-item critical path (three LDS round trips of the transform, DPP chains) is what bounds a wave, so resident
+// waves are what buys throughput
+template <int NB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+nmx_kern_timeosc_w1000_low1(const NmxTimeOscArgs A) {
+  const int item = blockIdx.x;
+  const int w = nmx_uniform_i(item / A.n_channels), c = nmx_uniform_i(item % A.n_channels);
+  NmxW500TwRegC T;
+  T.load(A.w500_tab, (int)(threadIdx.x & 63));
+  NmxTdRegs R;
+  nmx_td_load<1000>(A, w, c, R);
+  nmx_timeosc_w1000_body<NB, true, NmxW500TwRegC, true>(A, w, c, R, T, nmx_smem_wave);
+}
+
 // The same without an STFT and with low bands only (nmx_timeosc_w1000_low_ok: the default 4 - 35 Hz bands, BASELINE
 // config[1]): PERSISTENT waves (one-wave workgroups, grid = what the chip holds at once) walk the items with stride
 // gridDim, and the 16-byte loads of a wave's NEXT window are issued before it works on the current one -- the HBM
@@ -152,6 +167,19 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     want = (v && atoi(v) >= 1 && atoi(v) <= 16) ? atoi(v) : 12;
     const char* u = getenv("NMX_TOW_PERSISTENT");
     low_ok = !(u && u[0] == '0');
+  }
+  static int low1 = -1;
+  if (low1 < 0) { const char* v = getenv("NMX_TOW_LOW1"); low1 = (v && v[0] == '1') ? 1 : 0; }
+  if (low1 && nmx_timeosc_w1000_low_ok(*A)) {
+    const size_t lds1 = (size_t)NMX_TOW_LDS_FLOATS_NOSTFT * 4;
+    if (A->n_bands <= 4) {
+      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low1<4>, dim3(n_items), dim3(64), lds1, s, *A);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low1<4>");
+    } else {
+      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low1<8>, dim3(n_items), dim3(64), lds1, s, *A);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low1<8>");
+    }
+    return 1;
   }
   if (low_ok && nmx_timeosc_w1000_low_ok(*A)) {
     // resident waves per CU: 3 per SIMD (168 VGPRs).  The channel of a wave's items stays fixed -- and with it the XCD
