@@ -110,3 +110,28 @@ def test_abi_from_plain_c(tmp_path):
     subprocess.run(cmd, check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_bench_refuses_missing_gpus():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself or fail loudly when fewer than N devices
+    are visible -- never a 1-GPU number under an N-GPU label; under a launcher --gpus must equal WORLD_SIZE."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NMX_BENCH_FORCE_DEVICE")}
+    try:
+        import torch
+
+        n_dev = torch.cuda.device_count()
+    except Exception:
+        n_dev = 0
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(n_dev + 7)], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "HIP device(s) visible" in (r.stdout + r.stderr)
+    assert '"n_gpus"' not in r.stdout
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "!= WORLD_SIZE" in (r.stdout + r.stderr)
