@@ -99,8 +99,11 @@ struct NmxTdMask {
 // SUM4: the four wave sums of pass 2 through nmx_wave_sum4 (14 instead of 32 instructions; off in the prefetching
 // kernel, where the longer live range of the line-length sum costs it a register spill -- and a spill reload is a
 // vector-memory load that waits for the prefetch).
-template <int WC = 0, bool SUM4 = true>
+// FEATC: the enabled features when the kernel is compiled for ONE set (0: read A.features) -- every feature test then
+// folds away; a test that stays costs a scalar load, a compare and a branch of the wave's issue slots per item.
+template <int WC = 0, bool SUM4 = true, unsigned FEATC = 0>
 NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, float* cen) {
+  const unsigned features = FEATC ? FEATC : A.features;
   const int lane = (int)(threadIdx.x & 63);
   const int W = WC ? WC : A.W;
   auto add = [](float a, float b) { return a + b; };
@@ -137,7 +140,7 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
   const float rW = 1.f / (float)W, rW1 = 1.f / (float)(W - 1), rW2 = 1.f / (float)(W - 2);   // (scalar unit: W is uniform)
   const float m0 = p0 * rW;
   float* out_row = A.out + (long long)w * A.n_outputs;
-  const bool hj = (A.features & NMXD_F_HJORTH) != 0;
+  const bool hj = (features & NMXD_F_HJORTH) != 0;
   bool p3_done = !SUM4;
   if (hj || cen) {
     // sums of d1 and d2 telescope
@@ -201,10 +204,10 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       }
     }
   }
-  if (!p3_done && (A.features & NMXD_F_LINELENGTH)) p3 = nmx_wave_reduce(p3, 0.f, add);
+  if (!p3_done && (features & NMXD_F_LINELENGTH)) p3 = nmx_wave_reduce(p3, 0.f, add);
   if (lane == 0) {
-    if (A.features & NMXD_F_LINELENGTH) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = p3 * rW1 * rW1;
-    if (A.features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = R.last.y;
+    if (features & NMXD_F_LINELENGTH) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = p3 * rW1 * rW1;
+    if (features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = R.last.y;
   }
   return true;
 }

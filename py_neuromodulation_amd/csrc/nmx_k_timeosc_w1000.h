@@ -86,8 +86,27 @@ struct NmxBandAcc {
 // entries of the real-transform twiddle table in LDS at smem + 2016: NO vector-memory load inside the item (loads retire
 // in order, so one would wait for the prefetch of the next window to land first).
 // LOWNP: the low-band form WITHOUT the LDS twiddle copy (one item per workgroup: nothing to amortise a copy over).
-template <int NB, bool LOW = false, typename TW = NmxW500TwReg, bool LOWNP = false>
+// SPEC != 0: compiled for ONE feature set -- bits 0..8 the NMXD_F_* features, bit 16 / 17 the log_transform of the FFT /
+// Welch family -- (nmx_tow_spec): the flags below are constants and their tests fold away.
+#define NMX_TOW_SPEC_LOG_FFT (1u << 16)
+#define NMX_TOW_SPEC_LOG_WELCH (1u << 17)
+#define NMX_TOW_FEATS (NMXD_F_HJORTH | NMXD_F_RAW | NMXD_F_LINELENGTH | NMXD_F_FFT | NMXD_F_WELCH | NMXD_F_STFT)
+// the two sets that get their own build of the persistent kernel: BASELINE config[1] (FFT band power + Hjorth +
+// LineLength) and the time / oscillatory features of default_settings.yaml (+ Raw + Welch), log10 band powers
+#define NMX_TOW_SPEC_C2 (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_FFT | NMX_TOW_SPEC_LOG_FFT)
+#define NMX_TOW_SPEC_DEFAULT (NMXD_F_HJORTH | NMXD_F_RAW | NMXD_F_LINELENGTH | NMXD_F_FFT | NMXD_F_WELCH | NMX_TOW_SPEC_LOG_FFT | NMX_TOW_SPEC_LOG_WELCH)
+static inline unsigned nmx_tow_spec(const NmxTimeOscArgs& A) {
+  return (A.features & NMX_TOW_FEATS) | (A.fft.enabled && A.fft.log_transform ? NMX_TOW_SPEC_LOG_FFT : 0u) |
+         (A.welch.enabled && A.welch.log_transform ? NMX_TOW_SPEC_LOG_WELCH : 0u);
+}
+template <int NB, bool LOW = false, typename TW = NmxW500TwReg, bool LOWNP = false, unsigned SPEC = 0>
 NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& Rt, const TW& T, float* smem) {
+  const unsigned features = SPEC ? (SPEC & NMX_TOW_FEATS) : A.features;
+  const bool fft_on = SPEC ? (SPEC & NMXD_F_FFT) != 0 : A.fft.enabled != 0;
+  const bool welch_on = SPEC ? (SPEC & NMXD_F_WELCH) != 0 : A.welch.enabled != 0;
+  const bool stft_on = !LOW && (SPEC ? (SPEC & NMXD_F_STFT) != 0 : A.stft.enabled != 0);
+  const bool fft_log = SPEC ? (SPEC & NMX_TOW_SPEC_LOG_FFT) != 0 : A.fft.log_transform != 0;
+  const bool welch_log = SPEC ? (SPEC & NMX_TOW_SPEC_LOG_WELCH) != 0 : A.welch.log_transform != 0;
   const int lane = (int)(threadIdx.x & 63);
   nmx_c2* fa = (nmx_c2*)smem;                    // [500]
   nmx_c2* fb = (nmx_c2*)(smem + 1008);           // [501]
@@ -95,16 +114,16 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
   float* out_row = A.out + (long long)w * A.n_outputs;
   const int nb = A.n_bands;
 
-  const bool spec1000 = A.fft.enabled || A.welch.enabled;
+  const bool spec1000 = fft_on || welch_on;
   float wsum;
   {
     // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
-    const bool td = (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
+    const bool td = (features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
     // (always: the window sum it forms is also the NaN / infinity test of the window)
-    const bool fast = nmx_td_emit<1000, !LOW>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
+    const bool fast = nmx_td_emit<1000, !LOW, (SPEC & NMX_TOW_FEATS)>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
     wsum = Rt.sum;
     if (fast) {
-      if (!LOW && A.stft.enabled) {   // park the window in LDS (group 3: lanes 0..57)
+      if (stft_on) {   // park the window in LDS (group 3: lanes 0..57)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = Rt.x[k];
@@ -127,7 +146,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < 3 || lane < 58) {
-          if (!LOW && A.stft.enabled) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
+          if (stft_on) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
           if (spec1000) ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
         }
     }
@@ -145,29 +164,29 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
   //     so no second transform and no windowed copy of the window are needed.
   if (spec1000) {
     // bins read below: up to max(k_hi) (+1 for Welch's neighbours) and their mirror images 500 - k
-    const int kmax = (A.fft.enabled ? A.fft.k_hi : 0) > (A.welch.enabled ? A.welch.k_hi + 1 : 0)
-                         ? A.fft.k_hi : (A.welch.enabled ? A.welch.k_hi + 1 : 0);
+    const int kmax = (fft_on ? A.fft.k_hi : 0) > (welch_on ? A.welch.k_hi + 1 : 0)
+                         ? A.fft.k_hi : (welch_on ? A.welch.k_hi + 1 : 0);
     const float2* Z = (const float2*)((LOW || kmax <= 100) ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
                                                            : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
-    const float2* twr = (LOW && !LOWNP) ? (const float2*)(smem + 2016) : (A.fft.enabled ? A.fft : A.welch).fft.twr;
+    const float2* twr = (LOW && !LOWNP) ? (const float2*)(smem + 2016) : (fft_on ? A.fft : A.welch).fft.twr;
     auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
       const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
       if (kk == 0) return make_float2(0.f, 0.f);
       const float2 X = nmx_rfft_bin(Z, twr, 500, kk);
       return (k < 0 || k > 500) ? make_float2(X.x, -X.y) : X;
     };
-    if (A.fft.enabled) {
+    if (fft_on) {
       const NmxOsc& O = A.fft;
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
         const float2 X = k == 0 ? make_float2(wsum, 0.f) : xbin(k);
         const float pw = X.x * X.x + X.y * X.y;
-        const float v = O.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
+        const float v = fft_log ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
       }
       acc.emit(O, nb, 1, out_row, c, lane);
     }
-    if (A.welch.enabled) {
+    if (welch_on) {
       const NmxOsc& O = A.welch;
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
@@ -175,7 +194,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
         const float yr = 0.5f * X0.x - 0.25f * (Xm.x + Xp.x), yi = 0.5f * X0.y - 0.25f * (Xm.y + Xp.y);
         float p = (yr * yr + yi * yi) * O.scale;
         if (!(k == 0 || k == 500)) p *= 2.f;
-        if (O.log_transform) p = nmx_log10_fast(p);
+        if (welch_log) p = nmx_log10_fast(p);
         acc.add(O, nb, k, p);
       }
       acc.emit(O, nb, 1, out_row, c, lane);
@@ -183,7 +202,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     NMX_WAVE_FENCE();
   }
   // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
-  if (!LOW && A.stft.enabled) {
+  if (stft_on) {
     const NmxOsc& O = A.stft;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 2000, 0x00020000);
     float hw[8];

@@ -111,7 +111,10 @@ nmx_kern_timeosc_w1000_low1(const NmxTimeOscArgs A) {
 //     registers -- it does not fit, and spilled scalars come back as v_readlane VALU instructions (500 of them in a
 //     first build): the kernel-argument pointer is laundered once per iteration, so every use re-reads its dwords with
 //     s_load from the constant cache, as the one-item-per-workgroup kernel does.
-template <int NB>
+//   * SPEC: the kernel is also built for two fixed feature sets (nmx_k_timeosc_w1000.h: NMX_TOW_SPEC_*): with the
+//     feature tests folded away an item is ~120 scalar instructions and branches shorter, and those share the wave's
+//     issue slots with everything else.
+template <int NB, unsigned SPEC = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
 nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
   typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;
@@ -147,7 +150,7 @@ nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
       Xn[0] = Rn.x[0]; Xn[1] = Rn.x[1]; Xn[2] = Rn.x[2]; Xn[3] = Rn.x[3];
     }
     asm volatile("" : "+s"(Ap));
-    nmx_timeosc_w1000_body<NB, true>(*(const NmxTimeOscArgs*)Ap, w, c, R, T, nmx_smem_wave);
+    nmx_timeosc_w1000_body<NB, true, NmxW500TwReg, false, SPEC>(*(const NmxTimeOscArgs*)Ap, w, c, R, T, nmx_smem_wave);
     NMX_WAVE_FENCE();
     if (nxt >= n_items) break;
     item = nxt; w = wn; c = cn;
@@ -189,7 +192,16 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     if (grid > C && grid % C) grid -= grid % C;
     if (grid > n_items) grid = n_items;
     const size_t lds = (size_t)NMX_TOW_LOW_LDS_FLOATS * 4;
-    if (A->n_bands <= 4) {
+    static int spec_ok = -1;
+    if (spec_ok < 0) { const char* v = getenv("NMX_TOW_SPEC"); spec_ok = !(v && v[0] == '0'); }
+    const unsigned spec = spec_ok ? nmx_tow_spec(*A) : 0u;
+    if (A->n_bands <= 4 && spec == NMX_TOW_SPEC_C2) {
+      hipLaunchKernelGGL((nmx_kern_timeosc_w1000_low<4, NMX_TOW_SPEC_C2>), dim3(grid), dim3(64), lds, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low<4, 65809u>");
+    } else if (A->n_bands <= 4 && spec == NMX_TOW_SPEC_DEFAULT) {
+      hipLaunchKernelGGL((nmx_kern_timeosc_w1000_low<4, NMX_TOW_SPEC_DEFAULT>), dim3(grid), dim3(64), lds, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_timeosc_w1000_low<4, 196915u>");
+    } else if (A->n_bands <= 4) {
       hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low<4>, dim3(grid), dim3(64), lds, s, *A, n_items);
       nmxi_note_kernel("nmx_kern_timeosc_w1000_low<4>");
     } else {
