@@ -27,6 +27,14 @@ from .generator import window_schedule
 from .settings import NMSettings
 
 
+def _force_collectives() -> bool:
+    """NMX_FORCE_COLLECTIVES=1: run the exchange step through the process group even when it has ONE rank (a 1-GPU
+    box can then exercise the RCCL code path -- device tensors, object collectives -- that a multi-GPU node takes)."""
+    import os
+
+    return os.environ.get("NMX_FORCE_COLLECTIVES", "0") == "1"
+
+
 def channel_shard(n_channels: int, world_size: int, rank: int) -> range:
     """Contiguous block of channels for ``rank`` (sizes differ by at most one)."""
     base, rem = divmod(n_channels, world_size)
@@ -92,7 +100,8 @@ class ShardedStream:
             idx = [pos[int(j)] for j in members if int(j) in own]
             if idx:
                 part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float64)).sum(axis=0)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and part.size:
+        if dist.is_available() and dist.is_initialized() and part.size and (
+                dist.get_world_size(group) > 1 or _force_collectives()):
             t = torch.from_numpy(part).to(self._comm_device(group))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             part = t.cpu().numpy()
@@ -105,7 +114,7 @@ class ShardedStream:
 
         pos = {j: i for i, j in enumerate(self.local_rows)}
         mine = (np.asarray(self.owned_rows, np.int64), mask_local[:, [pos[j] for j in self.owned_rows]].astype(np.uint8))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force_collectives()):
             parts = [None] * dist.get_world_size(group)
             self._comm_device(group)
             dist.all_gather_object(parts, mine, group=group)
