@@ -26,9 +26,10 @@ __global__ void __launch_bounds__(256) nmx_kern_timeosc(const NmxTimeOscArgs A) 
   const int item = blockIdx.x;
   nmx_time_osc_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
 }
-__global__ void __launch_bounds__(256) nmx_kern_bank(const NmxBankArgs A) {
-  const int item = blockIdx.x;
-  nmx_bank_item(A, item / A.n_channels, item % A.n_channels, nmx_smem);
+__global__ void __launch_bounds__(256) nmx_kern_bank(const NmxBankArgs A, int n_items) {
+  // one item per workgroup; partitioned mode (NmxBankArgs::ups_*): a workgroup walks items with its scratch slot
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x)
+    nmx_bank_item(A, item / A.n_channels, item % A.n_channels, nmx_smem, (int)blockIdx.x);
 }
 __global__ void __launch_bounds__(256) nmx_kern_hilbert(const NmxHilbertArgs A) {
   nmx_hilbert_item(A, (long long)blockIdx.x, nmx_smem);
@@ -260,7 +261,8 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
 }
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
-  hipLaunchKernelGGL(nmx_kern_bank, dim3(n_items), dim3(nt), lds, s, A);
+  const int grid = (A.partitioned && n_items > NMX_UPS_SLOTS) ? NMX_UPS_SLOTS : n_items;
+  hipLaunchKernelGGL(nmx_kern_bank, dim3(grid), dim3(nt), lds, s, A, n_items);
   nmxi_note_kernel("nmx_kern_bank");
 }
 extern "C" void nmx_w64_launch_rd64(const NmxBankW64Args*, int, size_t, hipStream_t);

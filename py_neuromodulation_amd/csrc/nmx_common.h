@@ -22,6 +22,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #define NMX_TID 0
 #define NMX_NT 1
 #define NMX_SYNC() ((void)0)
+#define NMX_GLOBAL_FENCE() ((void)0)
 #define NMX_RESTRICT
 #else
 #include <hip/hip_runtime.h>
@@ -63,6 +64,8 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
   } while (0)
 #endif
 #define NMX_RESTRICT __restrict__
+// global-memory writes of this thread become visible to the other threads of the workgroup (followed by NMX_SYNC)
+#define NMX_GLOBAL_FENCE() __threadfence_block()
 // host-side helpers shared by the translation units of libnmx.so
 // nmxi_note_kernel: every launcher records the kernel it actually launched (name as rocprofv3 prints it)
 // under the current stage; nmx_last_kernels() reports them (bench.py's roofline names the kernel from here).

@@ -20,15 +20,16 @@
 
 #include "nmx_k_timeosc.h"
 
+#define NMX_UPS_SLOTS 512   // workgroups of a partitioned-mode launch (two per CU; one scratch slot each)
+
 struct NmxFilterDev {
-  const float* H;  // [M/2 + 1] real spectrum of centred taps, pre-scaled by 1/M
+  const float* H;  // [M/2 + 1] real spectrum of centred taps, pre-scaled by 1/M (partitioned mode: [P][B + 1] complex)
   int half;        // (L - 1) / 2
   int bp_seglen;   // 0 = no BandPower epilogue
   int bp_band;
   int burst_index;  // -1 = none
   int sw_index;     // -1 = none
   int store_raw;    // notch: write y to yout[w][c][W]
-  const float* taps;  // direct mode: the 2 half + 1 centred taps (fp32)
 };
 
 struct NmxBankArgs {
@@ -60,56 +61,82 @@ struct NmxBankArgs {
   float* y_out;     // notch: [n_windows][C][W]
   // LDS carve (float offsets)
   int off_X, off_a, off_b, off_red, lds_floats;
-  // DIRECT mode (windows x taps whose FFT convolution does not fit one LDS transform: >= 6 kHz recordings with 1 s
-  // windows): y[n] = sum_j h[j] x[n + half - j] evaluated as written -- O(W L) instead of O(M log M), any size, the
-  // window streamed from L1 / L2, only y[W] in LDS (at off_X) for the epilogues; burst bands leave as series (yb_out)
-  // for the stand-alone Hilbert kernel
-  int direct;
+  // PARTITIONED mode (partitioned != 0: windows x taps whose FFT convolution does not fit one LDS transform -- >= 6 kHz
+  // recordings with 1 s windows): uniformly partitioned overlap-save, O((W + L) / B x L / B x B) where the definition
+  // y[n] = sum_j h[j] x[n + half - j] costs O(W L).  With Hm = the longest half length and u[t] = x_ext[t - Hm],
+  // t in [0, W + 2 Hm), filter f's output is y[n] = (h_f * u)[n + half_f + Hm].  Blocks of B samples, transforms of 2 B
+  // real points (complex length B: `fft`):
+  //   frame b  = u[(b - 1) B, (b + 1) B)          U_b = rfft(frame b)          computed ONCE per (window, channel)
+  //   block b of h_f * u = last B samples of irfft(sum_p U_(b-p) H_(f,p)),      H_(f,p) = rfft(h_f[p B, (p + 1) B))
+  // U_b of the item live in a scratch slot of the workgroup (global memory, L2 / MALL), the partition spectra
+  // F.H = [P_f][B + 1] complex (pre-scaled by 1 / 2B) are shared by all items; y[W] in LDS (at off_X) for the epilogues;
+  // burst bands leave as series (yb_out) for the stand-alone Hilbert kernel.  A workgroup walks items blockIdx.x,
+  // blockIdx.x + gridDim.x, ... (one scratch slot per workgroup).
+  int partitioned;
   float* yb_out;    // [n_windows][C][n_burst_bands][W]
+  int ups_B, ups_frames, ups_hm;
+  float2* ups_scratch;          // [gridDim.x][ups_frames][B + 1]
 };
 
-// direct "same" FIR of one filter into y[0..W) (LDS).  Partial sums of 32 taps in fp32, their total in float64: the
-// rounding of a 13 000-term fp32 chain would sit at the parity tolerance.
-NMX_DEV void nmx_bank_direct(const NmxBankArgs& A, const NmxFilterDev& F, const float* src, float* y) {
-  const int W = A.W, half = F.half, L = 2 * half + 1;
-  const float* NMX_RESTRICT h = F.taps;
-  const float x0 = A.clean_on_load ? nmx_clean(src[0]) : src[0];
-  const float xl = A.clean_on_load ? nmx_clean(src[W - 1]) : src[W - 1];
-  const int ne = A.n_edge;
-  for (int n = NMX_TID; n < W; n += NMX_NT) {
-    // k = n + half - j runs over the (extended) signal; pad_mode 0: x = 0 outside [0, W)
-    int jlo = 0, jhi = L - 1;
-    if (A.pad_mode == 0) {
-      jlo = n + half - (W - 1) > 0 ? n + half - (W - 1) : 0;
-      jhi = n + half < L - 1 ? n + half : L - 1;
-    }
-    double acc = 0.0;
-    for (int j0 = jlo; j0 <= jhi; j0 += 32) {
-      const int j1 = j0 + 31 < jhi ? j0 + 31 : jhi;
-      float part = 0.f;
-      for (int j = j0; j <= j1; ++j) {
-        const int k = n + half - j;
-        float v;
-        if (k >= 0 && k < W) {
-          v = src[k];
-          if (A.clean_on_load) v = nmx_clean(v);
-        } else if (A.pad_mode == 0) {
-          v = 0.f;
-        } else if (k < 0) {   // odd reflection about the first sample, reflect_limited (MNE _smart_pad)
-          v = (-k <= ne) ? 2.f * x0 - (A.clean_on_load ? nmx_clean(src[-k]) : src[-k]) : 0.f;
-        } else {
-          const int r = k - (W - 1);
-          v = (r <= ne) ? 2.f * xl - (A.clean_on_load ? nmx_clean(src[W - 1 - r]) : src[W - 1 - r]) : 0.f;
-        }
-        part = fmaf(h[j], v, part);
+// partitioned overlap-save (NmxBankArgs::ups_*), step 1: the spectra of all frames of one (window, channel)
+NMX_DEV void nmx_bank_ups_frames(const NmxBankArgs& A, const float* src, float2* S, float2* bufA, float2* bufB) {
+  const int W = A.W, B = A.ups_B, hm = A.ups_hm, ne = A.n_edge, clean = A.clean_on_load;
+  auto raw = [&](int k) -> float { const float v = src[k]; return clean ? nmx_clean(v) : v; };
+  const float x0 = raw(0), xl = raw(W - 1);
+  auto u = [&](int t) -> float {   // u[t] = x_ext[t - hm] on [0, W + 2 hm), 0 elsewhere
+    if (t < 0 || t >= W + 2 * hm) return 0.f;
+    const int k = t - hm;
+    if (k >= 0 && k < W) return raw(k);
+    if (A.pad_mode == 0) return 0.f;
+    if (k < 0) return (-k <= ne) ? 2.f * x0 - raw(-k) : 0.f;   // odd reflection, reflect_limited (MNE _smart_pad)
+    const int r = k - (W - 1);
+    return (r <= ne) ? 2.f * xl - raw(W - 1 - r) : 0.f;
+  };
+  for (int b = 0; b < A.ups_frames; ++b) {
+    const int t0 = (b - 1) * B;
+    for (int i = NMX_TID; i < B; i += NMX_NT) bufB[i] = make_float2(u(t0 + 2 * i), u(t0 + 2 * i + 1));
+    NMX_SYNC();
+    const float2* Z = nmx_fft<-1>(A.fft, bufB, bufA, bufB);
+    float2* Sb = S + (long long)b * (B + 1);
+    for (int k = NMX_TID; k <= B; k += NMX_NT) Sb[k] = nmx_rfft_bin(Z, A.fft.twr, B, k);
+    NMX_SYNC();
+  }
+  NMX_GLOBAL_FENCE();   // the frames are read back by other threads of the workgroup
+  NMX_SYNC();
+}
+
+// step 2: filter F of the item into y[0..W) (LDS)
+NMX_DEV void nmx_bank_ups_filter(const NmxBankArgs& A, const NmxFilterDev& F, const float2* S, float* y, float2* bufA,
+                                 float2* bufB) {
+  const int W = A.W, B = A.ups_B, Bh = B >> 1;
+  const int L = 2 * F.half + 1, P = (L + B - 1) / B;
+  const int off = F.half + A.ups_hm;   // y[n] = (h * u)[n + off]
+  const float2* NMX_RESTRICT H = (const float2*)F.H;
+  for (int b = off / B; b <= (off + W - 1) / B; ++b) {
+    const int pmax = (P - 1 < b) ? P - 1 : b;   // frames below 0 are zero
+    for (int k = NMX_TID; k <= Bh; k += NMX_NT) {
+      const int k2 = B - k;
+      float2 a1 = make_float2(0.f, 0.f), a2 = make_float2(0.f, 0.f);
+      for (int p = 0; p <= pmax; ++p) {
+        const float2* Sb = S + (long long)(b - p) * (B + 1);
+        const float2* Hp = H + (long long)p * (B + 1);
+        a1 = nmx_cadd(a1, nmx_cmul(Sb[k], Hp[k]));
+        a2 = nmx_cadd(a2, nmx_cmul(Sb[k2], Hp[k2]));
       }
-      acc += (double)part;
+      bufB[k] = nmx_irfft_pre(a1, a2, A.fft.twr[k]);
+      if (k2 != k && k2 < B) bufB[k2] = nmx_irfft_pre(a2, a1, A.fft.twr[k2]);
     }
-    y[n] = (float)acc;
+    NMX_SYNC();
+    const float* yf = (const float*)nmx_fft<+1>(A.fft, bufB, bufA, bufB);
+    for (int i = NMX_TID; i < B; i += NMX_NT) {
+      const int n = b * B + i - off;
+      if (n >= 0 && n < W) y[n] = yf[B + i];
+    }
+    NMX_SYNC();
   }
 }
 
-NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
+NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int slot = 0) {
   float2* X = (float2*)(smem + A.off_X);
   float2* bufA = (float2*)(smem + A.off_a);
   float2* bufB = (float2*)(smem + A.off_b);
@@ -119,11 +146,13 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem) {
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
                      (A.starts ? A.starts[w] : 0ll);
 
-  if (A.direct) {   // ---- direct convolution (see NmxBankArgs::direct): y in LDS, the same epilogues -----------
+  if (A.partitioned) {   // ---- partitioned overlap-save (see NmxBankArgs::partitioned): y in LDS, the same epilogues ----------
     float* y = smem + A.off_X;
+    float2* S = A.ups_scratch + (long long)slot * A.ups_frames * (A.ups_B + 1);
+    nmx_bank_ups_frames(A, src, S, bufA, bufB);
     for (int fi = 0; fi < A.n_filters; ++fi) {
       const NmxFilterDev& F = A.f[fi];
-      nmx_bank_direct(A, F, src, y);
+      nmx_bank_ups_filter(A, F, S, y, bufA, bufB);
       NMX_SYNC();
       if (F.bp_seglen > 0) {
         const bool need_mc = (A.bp_features & 6u) != 0;

@@ -14,6 +14,7 @@
 
 #include "nmx_k_bursts.h"
 #include "nmx_k_bank_w64.h"
+#include "nmx_k_burst_stat_reg.h"
 #include "nmx_k_scan.h"
 #include "nmx_k_td.h"
 #include "nmx_k_timeosc_w1000.h"
@@ -28,6 +29,16 @@ __global__ void __launch_bounds__(256) nmx_kern_burst_stat(const NmxBurstStatArg
   if (item >= n_items) return;
   const int bi = item % A.n_bands, r = item / A.n_bands;
   nmx_burst_stat_item(A, r / A.n_channels, r % A.n_channels, bi, nmx_smem_wave + wave * slice);
+}
+
+// the envelope of one item in the registers of its wave (nmx_k_burst_stat_reg.h): W % 4 == 0, W <= 64 CH; no LDS
+template <int CH>
+__global__ void __launch_bounds__(256) nmx_kern_burst_stat_reg(const NmxBurstStatArgs A, int n_items) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;
+  const int bi = item % A.n_bands, r = item / A.n_bands;
+  nmx_burst_stat_item_reg<CH>(A, r / A.n_channels, r % A.n_channels, bi);
 }
 
 __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int n_items, int slice) {
@@ -322,6 +333,16 @@ extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_item
   static unsigned long long seen = 0;
   if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_burst_stat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if ((A->W & 3) == 0 && A->W <= 2048) {
+    if (A->W <= 1024) {
+      hipLaunchKernelGGL(nmx_kern_burst_stat_reg<16>, dim3((n_items + 3) / 4), dim3(256), 0, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_burst_stat_reg<16>");
+    } else {
+      hipLaunchKernelGGL(nmx_kern_burst_stat_reg<32>, dim3((n_items + 3) / 4), dim3(256), 0, s, *A, n_items);
+      nmxi_note_kernel("nmx_kern_burst_stat_reg<32>");
+    }
+    return;
   }
   const int k = waves_per_wg(lds);
   const int slice = (int)((lds / 4 + 3) & ~(size_t)3);

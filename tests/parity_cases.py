@@ -1149,6 +1149,76 @@ def case_reref_structured_matrices(lib, monkeypatch=None):
         eng.close()
 
 
+def case_resampler_long_windows(lib):
+    """raw_resampling of windows whose padded length (8192 < n_pad <= 65 536) does not fit one LDS transform -- 8 / 10 /
+    24 / 30 / 44.1 kHz recordings with 1 s windows brought to 1 kHz (the reference's DEFAULT pre-processing), one with
+    an ODD resampled padded length (24 kHz: round(32768 / 24) = 1365, full complex inverse) -- through the polyphase
+    path of nmx_k_resample.h, against the restated mne.filter.resample.  NMX_RESAMPLE_POLY=1 routes a short window
+    (4 kHz) through the same path: both paths must agree with the oracle.  Then Stream.run at 10 kHz with
+    resample_features_at_new_rate=True against the oracle's pipeline.  Tolerance as case_resampler (2e-5 x amplitude)."""
+    import os
+
+    from oracle import mne_restated as mr
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.stream import Stream
+
+    rng = np.random.default_rng(23)
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.return_raw = True
+    s.postprocessing.feature_normalization = False
+    for sf_old, sf_new, W, poly in ((8000, 1000, 8000, 0), (10000, 1000, 10000, 0), (24000, 1000, 24000, 0),
+                                    (30000, 1000, 30000, 0), (44100, 1000, 44100, 0), (30000, 2000, 15000, 0),
+                                    (4000, 1000, 4000, 1)):
+        t = np.arange(W) / sf_old
+        x = rng.standard_normal((2, W)) * 20 + 50 * np.sin(2 * np.pi * 11 * t) + rng.uniform(-300, 300, (2, 1))
+        x[1, W // 3] = np.nan
+        if poly:
+            os.environ["NMX_RESAMPLE_POLY"] = "1"
+        try:
+            eng = HotPathEngine(s, ["a", "b"], float(sf_new), resample_from=float(sf_old), raw_window=W,
+                                window=int(round(sf_new / sf_old * W)), lib=lib)
+        finally:
+            os.environ.pop("NMX_RESAMPLE_POLY", None)
+        want = mr.resample(np.nan_to_num(x), up=sf_new / sf_old, down=1.0)
+        got = eng.preprocess_window(x)
+        assert got.shape == want.shape == (2, int(round(sf_new / sf_old * W)))
+        amp = np.abs(np.nan_to_num(x)).max()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * amp, err_msg=f"{sf_old}->{sf_new}")
+        eng.close()
+    # Stream.run on a 10 kHz recording: notch at the raw rate (9999 taps: partitioned overlap-save), resampling to 1 kHz,
+    # common average, features designed for 1 kHz
+    from py_neuromodulation_amd import fir_design
+
+    s.features.fft = True
+    s.features.raw_hjorth = True
+    s.preprocessing = ["raw_resampling", "notch_filter", "re_referencing"]
+    sf, W = 10000.0, 10000
+    T = W + 3 * 1000 + 3
+    t = np.arange(T) / sf
+    xs = rng.standard_normal((2, T)) * 10 + 20 * np.sin(2 * np.pi * 21 * t) + 6 * np.sin(2 * np.pi * 50 * t)
+    st = Stream(sfreq=sf, data=xs, settings=s, line_noise=50, lib=lib, resample_features_at_new_rate=True)
+    df = st.run(xs, save_csv=False)
+    assert len(df) == 4 and st.data_processor.sfreq_raw == 1000.0
+    nf = orc.NotchFilter(sf, 50, taps=fir_design.notch_bank(sf, 50))
+    R = np.array([[1.0, -1.0], [-1.0, 1.0]])
+    names = [k for k in df.columns if k != "time"]
+    chn = ["ch0_avgref", "ch1_avgref"]
+    for i in range(4):
+        w = xs[:, i * 1000:i * 1000 + W]
+        y = R @ mr.resample(nf.process(w), up=0.1, down=1.0)
+        want = {}
+        for f in (orc.Hjorth(s, chn, 1000.0), orc.Raw(s, chn, 1000.0), orc.FFT(s, chn, 1000.0)):
+            want.update(f.calc_feature(y))
+        n_bad, rep, _ = parity.compare(names, df.iloc[i][names].to_numpy(dtype=np.float64), [want[k] for k in names], s,
+                                       1000.0, float(np.abs(xs).max()), 1000,
+                                       verifier=parity.Verifier(s, chn, 1000.0, y, raw=w))
+        assert n_bad == 0, f"stream hop {i}\n{rep}"
+
+
 def case_raw_resampling_reference_quirk(lib):
     """Default settings on recordings that are not sampled at resample_freq_hz: the reference resamples each
     window but keeps designing notch AND features with the raw rate (stream/data_processor.py:55,68,80;
@@ -1259,6 +1329,77 @@ def random_settings(seed):
     raise RuntimeError("no valid settings drawn")
 
 
+def random_settings_highrate(seed):
+    """Random settings at 6 / 8 kHz with 1 s windows and NO resampling -- the shapes of round 3's partitioned overlap-save
+    FIR mode (band-pass taps of ~10 000 - 13 000, notch taps of 5 999 / 7 999) -- with or without notch, re-referencing,
+    bursts (stand-alone Hilbert kernel behind the partitioned bank), a raw "quantile" / "zscore" normaliser (history of
+    <= 1 s: below scikit-learn's random subsampling).  Returns (settings, sfreq, data, line_noise)."""
+    from py_neuromodulation_amd import NMSettings
+
+    rng = np.random.default_rng(70_000 + seed)
+    sfreq = float(rng.choice([6000, 8000]))
+    n_ch = int(rng.choice([1, 2, 3]))
+    pool = [("theta", [4, 8]), ("alpha", [8, 12]), ("low_beta", [13, 20]), ("high_beta", [20, 35]),
+            ("low_gamma", [60, 80]), ("high_gamma", [90, 200])]
+    keep = [b for b in pool if rng.random() < 0.5]
+    if len(keep) < 2:
+        keep = pool[2:4]
+    base = NMSettings.get_default().to_dict()
+    base["frequency_ranges_hz"] = {n: r for n, r in keep}
+    s = NMSettings(**base)
+    s.features.disable_all()
+    on = [f for f in ("fft", "bandpass_filter", "raw_hjorth", "linelength", "return_raw", "bursts") if rng.random() < 0.6]
+    if "bandpass_filter" not in on and "bursts" not in on:
+        on.append("bandpass_filter")
+    for f in on:
+        setattr(s.features, f, True)
+    s.bandpass_filter_settings.segment_lengths_ms = {n: int(rng.choice([100, 333, 500, 1000])) for n, _ in keep}
+    s.bursts_settings.frequency_bands = [n for n, _ in keep][:int(rng.integers(1, 3))]
+    s.bursts_settings.time_duration_s = float(rng.choice([1, 2]))
+    s.bursts_settings.threshold = float(rng.choice([50, 75, 90]))
+    pre = []
+    if rng.random() < 0.6:
+        pre.append("notch_filter")
+    if rng.random() < 0.5 and n_ch >= 2:
+        pre.append("re_referencing")
+    if rng.random() < 0.3:
+        pre.append("raw_normalization")
+        s.raw_normalization_settings.normalization_method = str(rng.choice(["zscore", "quantile", "robust"]))
+        s.raw_normalization_settings.normalization_time_s = float(rng.choice([0.3, 1.0]))
+        s.raw_normalization_settings.clip = float(rng.choice([0, 3]))
+    s.preprocessing = pre
+    s.postprocessing.feature_normalization = False
+    s = NMSettings(**s.to_dict()).validate()
+    W, hop = int(sfreq), int(sfreq / 10)
+    T = W + int(rng.integers(2, 5)) * hop + int(rng.integers(0, 5))
+    t = np.arange(T) / sfreq
+    data = rng.standard_normal((n_ch, T)) * 10 + rng.uniform(-50, 50, (n_ch, 1))
+    data += 8 * np.sin(2 * np.pi * rng.uniform(5, 40) * t)[None] + 4 * np.sin(2 * np.pi * 50 * t)[None]
+    return s, sfreq, data, 50
+
+
+def case_random_settings_highrate(lib, seed):
+    """`random_settings_highrate` through `Stream.run` against the oracle's `run_stream` (as case_random_settings)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.stream import Stream
+
+    s, sfreq, data, line = random_settings_highrate(seed)
+    ch = chmod.get_default_channels_from_data(data).to_dict("list")
+    df = Stream(sfreq, data=data, settings=s, line_noise=line, lib=lib).run(save_csv=False)
+    rows = orc.run_stream(data, sfreq, s, ch, line_noise=line)
+    assert list(df.columns) == list(rows[0].keys()), f"seed {seed}: columns differ"
+    got = df.to_numpy(float)
+    starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    W = int(ends[0] - starts[0])
+    pv = parity.PipelineVerifiers(s, ch, sfreq, data, starts, W, line_noise=line, ends=ends)
+    cols = list(df.columns)
+    for i, r in enumerate(rows):
+        want = np.array(list(r.values()))
+        n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[:-1], s, sfreq, 40.0, W, verifier=pv.row(i))
+        assert n_bad == 0, f"seed {seed} ({sfreq} Hz, {data.shape[0]} ch, {s.features.get_enabled()}, {s.preprocessing}) hop {i}\n{rep}"
+
+
 def case_random_settings(lib, seed):
     """Drop-in check away from the benchmark shapes: a random valid settings object / sampling rate / channel count
     through `Stream.run`, against the oracle's `run_stream` on the same recording, column order included."""
@@ -1291,10 +1432,10 @@ def case_random_settings(lib, seed):
         assert got[i, -1] == want[-1]
 
 
-def case_high_rate_direct_fir(lib):
+def case_high_rate_partitioned_fir(lib):
     """A recording at 8 kHz with 1 s windows and NO resampling: the automatic band-pass taps are 13 201 long, the notch
     7 999 -- the FFT convolution of a window (M >= 14 600 / 16 000) does not fit one LDS transform, so notch and
-    band-pass bank run as direct convolutions (nmx_k_bank.h: NmxBankArgs::direct; round 2 refused this shape), the
+    band-pass bank run as partitioned overlap-save convolutions (nmx_k_bank.h: NmxBankArgs::partitioned; round 2 refused this shape), the
     burst bands go through the stand-alone Hilbert kernel.  Stream.run against the oracle's run_stream."""
     from oracle import nm_oracle as orc
     from py_neuromodulation_amd import NMSettings

@@ -421,8 +421,17 @@ def test_raw_quantile_subsample(gpu_lib):
     pc.case_raw_quantile_subsample(gpu_lib)
 
 
-def test_high_rate_direct_fir(gpu_lib):
-    pc.case_high_rate_direct_fir(gpu_lib)
+def test_resampler_long_windows(gpu_lib):
+    pc.case_resampler_long_windows(gpu_lib)
+
+
+def test_high_rate_partitioned_fir(gpu_lib):
+    pc.case_high_rate_partitioned_fir(gpu_lib)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_settings_highrate(gpu_lib, seed):
+    pc.case_random_settings_highrate(gpu_lib, seed)
 
 
 def test_config5_degenerate_bursts_and_welch(gpu_lib):

@@ -90,8 +90,17 @@ def test_raw_quantile_subsample(emu_lib):
     pc.case_raw_quantile_subsample(emu_lib)
 
 
-def test_high_rate_direct_fir(emu_lib):
-    pc.case_high_rate_direct_fir(emu_lib)
+def test_resampler_long_windows(emu_lib):
+    pc.case_resampler_long_windows(emu_lib)
+
+
+def test_high_rate_partitioned_fir(emu_lib):
+    pc.case_high_rate_partitioned_fir(emu_lib)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_settings_highrate(emu_lib, seed):
+    pc.case_random_settings_highrate(emu_lib, seed)
 
 
 def test_config5_degenerate_bursts_and_welch(emu_lib):
