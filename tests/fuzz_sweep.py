@@ -24,13 +24,13 @@ def main(lo, hi, budget_s=1500.0):
     import tempfile
 
     os.chdir(tempfile.mkdtemp(prefix="nmx_fuzz_"))   # Stream.run leaves its side-car files under the working directory
-    only = os.environ.get("NMX_FUZZ_ONLY")   # "narrow" / "wide" / "channels" / "bursts" / "windows"
+    only = os.environ.get("NMX_FUZZ_ONLY")   # "narrow" / "wide" / "channels" / "bursts" / "windows" / "highrate"
     t0 = time.time()
     n = bad = 0
     for seed in range(lo, hi):
         for name, fn in (("narrow", pc.case_random_settings), ("wide", pc.case_random_settings_wide),
                          ("channels", pc.case_random_channel_tables), ("bursts", pc.case_random_burst_streams),
-                         ("windows", pc.case_random_window_by_window),
+                         ("windows", pc.case_random_window_by_window), ("highrate", pc.case_random_settings_highrate),
                          ("windows_wide", lambda lib, seed: pc.case_random_window_by_window(lib, seed, wide=True))):
             if only and name != only:
                 continue

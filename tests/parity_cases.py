@@ -1331,13 +1331,14 @@ def random_settings(seed):
 
 def random_settings_highrate(seed):
     """Random settings at 6 / 8 kHz with 1 s windows and NO resampling -- the shapes of round 3's partitioned overlap-save
+    (or at 8 - 24 kHz WITH the default raw_resampling to 1 kHz: polyphase resampler behind a partitioned notch)
     FIR mode (band-pass taps of ~10 000 - 13 000, notch taps of 5 999 / 7 999) -- with or without notch, re-referencing,
-    bursts (stand-alone Hilbert kernel behind the partitioned bank), a raw "quantile" / "zscore" normaliser (history of
-    <= 1 s: below scikit-learn's random subsampling).  Returns (settings, sfreq, data, line_noise)."""
+    bursts (stand-alone Hilbert kernel behind the partitioned bank), a raw "zscore" / "mean" normaliser.  Returns (settings, sfreq, data, line_noise)."""
     from py_neuromodulation_amd import NMSettings
 
     rng = np.random.default_rng(70_000 + seed)
-    sfreq = float(rng.choice([6000, 8000]))
+    resample = rng.random() < 0.4   # the reference's default: windows brought to 1 kHz, designs at the RAW rate (quirk)
+    sfreq = float(rng.choice([8000, 10000, 16000, 24000]) if resample else rng.choice([6000, 8000]))
     n_ch = int(rng.choice([1, 2, 3]))
     pool = [("theta", [4, 8]), ("alpha", [8, 12]), ("low_beta", [13, 20]), ("high_beta", [20, 35]),
             ("low_gamma", [60, 80]), ("high_gamma", [90, 200])]
@@ -1357,14 +1358,15 @@ def random_settings_highrate(seed):
     s.bursts_settings.frequency_bands = [n for n, _ in keep][:int(rng.integers(1, 3))]
     s.bursts_settings.time_duration_s = float(rng.choice([1, 2]))
     s.bursts_settings.threshold = float(rng.choice([50, 75, 90]))
-    pre = []
+    pre = ["raw_resampling"] if resample else []
     if rng.random() < 0.6:
         pre.append("notch_filter")
     if rng.random() < 0.5 and n_ch >= 2:
         pre.append("re_referencing")
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 and not resample:
         pre.append("raw_normalization")
-        s.raw_normalization_settings.normalization_method = str(rng.choice(["zscore", "quantile", "robust"]))
+        # (the order-statistic raw normalisers keep window + hop <= 6484 samples in LDS: INTEGRATION.md section 4)
+        s.raw_normalization_settings.normalization_method = str(rng.choice(["zscore", "mean"]))
         s.raw_normalization_settings.normalization_time_s = float(rng.choice([0.3, 1.0]))
         s.raw_normalization_settings.clip = float(rng.choice([0, 3]))
     s.preprocessing = pre
