@@ -352,6 +352,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
   NMX_PROF_DECL
 
   // ---- forward: window -> registers (packed complex, lane-consecutive) -> pass A ------------
+#ifdef NMX_HOST_EMU
   if (PAD == 1) {  // notch: stage the window in LDS for the odd reflection
     float* xs = (float*)X;
     NMX_LANE_LOOP {
@@ -373,6 +374,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
     }
     NMX_WSYNC();
   }
+#endif
   NMX_LANE_LOOP {
     nmx_c2* vv = v[NMX_LI];
     if (PAD == 0) {
@@ -402,6 +404,45 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       }
 #endif
     } else {
+#ifndef NMX_HOST_EMU
+      // Notch: the odd-reflected window straight from global memory (L2), no LDS staging.  Sample jp of the staged
+      // signal is x[j], j = jp - h, inside the window and  2 x[0] - x[-j]  /  2 x[W-1] - x[2 (W-1) - j]  in the
+      // reflected flanks (MNE _smart_pad, reflect_limited: at most n_edge samples); every lane computes its 32
+      // indices branch-free and all loads are in flight before the first use (the staged form walked 18 of the 32
+      // elements through nested branches with one dependent LDS read each: 60 % of the notch item's cycles).
+      {
+        const nmx_rsrc rs = nmx_make_rsrc(src, 4 * W);
+        const int h = A.pad_half, ne = A.n_edge;
+        float t[32];
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          NMX_UNROLL
+          for (int u = 0; u < 2; ++u) {
+            const int j = 2 * (l + 64 * r) + u - h;
+            const int idx = j < 0 ? -j : (j >= W ? 2 * (W - 1) - j : j);
+            t[2 * r + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * idx, 0, 0));   // out of range: 0
+          }
+        }
+        float x0 = src[0], xl = src[W - 1];
+        if (A.clean_on_load) { x0 = nmx_clean(x0); xl = nmx_clean(xl); }
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          float e2[2];
+          NMX_UNROLL
+          for (int u = 0; u < 2; ++u) {
+            const int jp = 2 * (l + 64 * r) + u, j = jp - h;
+            float x = t[2 * r + u];
+            if (A.clean_on_load) x = nmx_clean_bl(x);
+            const bool lo = j < 0, hi = j >= W;
+            const int dist = lo ? -j : j - (W - 1);
+            const float refl = (lo ? 2.f * x0 : 2.f * xl) - x;
+            const float val = (lo || hi) ? (dist <= ne ? refl : 0.f) : x;
+            e2[u] = jp < W + 2 * h ? val : 0.f;
+          }
+          vv[r] = nmx_mk2(e2[0], e2[1]);
+        }
+      }
+#else
       const float* xs = (const float*)X;
       const int h = A.pad_half, ne = A.n_edge;
       const float x0 = xs[0], xl = xs[W - 1];
@@ -426,9 +467,10 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         }
         vv[r] = nmx_mk2(e2[0], e2[1]);
       }
+#endif
     }
   }
-  NMX_WSYNC();  // (pad_mode 1: everyone has read xs before X is overwritten)
+  NMX_WSYNC();  // (emulator, pad_mode 1: everyone has read xs before X is overwritten)
   NMX_LANE_LOOP { nmx_w64_passA<-1>(v[NMX_LI], X, l); }
   NMX_WSYNC();
   NMX_LANE_LOOP { nmx_w64_passB_load_lds<-1, TAB>(v[NMX_LI], X, twB, l); }

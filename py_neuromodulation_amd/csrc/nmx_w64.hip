@@ -81,6 +81,33 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_
                              nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats, tab);
 }
 
+// Persistent form of the above: workgroups of four waves, three per CU, walk the items -- the tables are staged once
+// per workgroup instead of once per four items (the staging + its barrier + the workgroup launch were a quarter of
+// the four-item kernel's time).  The kernel-argument pointer is laundered once per iteration so that the plan is
+// re-read with s_load instead of being hoisted into (spilled) scalar registers (nmx_wave.hip).
+__global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_items,
+                                                                                       int x_floats) {
+  typedef const NmxBankW64Args __attribute__((address_space(4)))* nmx_karg_p;
+  nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+  float* tab = nmx_smem_w64;
+  const int n = NMX_W64_N, tab_floats = 2 * n;
+  {
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    for (int i = threadIdx.x; i < tab_floats; i += 256) tab[i] = i < n ? A.Hs[0][i] : A.Hd[0][i - n];
+    for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += 256) tab[tab_floats + i] = A.twl[i];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
+#pragma nounroll
+  for (int item = blockIdx.x * 4 + wave; item < n_items; item += (int)gridDim.x * 4) {
+    asm volatile("" : "+s"(Ap));
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+    NMX_WAVE_FENCE();
+  }
+}
+
 // M = 4096 (nmx_k_bank_w64x2.h): persistent workgroups of `nw` waves; LDS = tables of the first n_tab filters,
 // pass B / C twiddles, w^k, one exchange tile per wave
 template <int HALF>
@@ -232,6 +259,15 @@ extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Arg
   }
   const int x_floats = A->lds_floats;
   const size_t lds = (size_t)(2 * NMX_W64_N + NMX_W64_TWL_FLOATS + 4 * x_floats) * 4;
+  if (n_items >= 3 * 256 * 4 * 8) {   // eight items or more per wave: persistent workgroups
+    static unsigned long long seen_p = 0;
+    if (nmx_first_on_device(seen_p))
+      (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME), dim3(3 * 256), dim3(256), lds, s, *A, n_items, x_floats);
+    NMX_KNAME("nmx_kern_notch_w64qp_", "");
+    return 1;
+  }
   hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_NAME), dim3((n_items + 3) / 4), dim3(256), lds, s, *A, n_items,
                      x_floats);
   NMX_KNAME("nmx_kern_notch_w64q_", "");
