@@ -75,6 +75,32 @@ NMX_DEV void nmx_td_load_rest(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& 
   R.first = nmx_td_ldc2(rs, 0);
   R.last = nmx_td_ldc2(rs, 4 * ((WC ? WC : A.W) - 2));
 }
+// The same successors / row ends WITHOUT memory: from the x registers of the neighbouring lanes (wave_shl:1; lane 63
+// takes lane 0 of the next group).  For the persistent kernel: its item then starts with no vector-memory wait at all --
+// loads retire in order, so a load issued at the top of an item also waits for the previous item's result stores.
+template <int WC>
+NMX_DEV void nmx_td_rest_from_x(NmxTdRegs& R) {
+  static_assert(WC % 4 == 0 && WC >= 8 && WC <= 1024, "window length");
+  const int lane = (int)(threadIdx.x & 63);
+  auto shl1 = [](float v) {   // lane l <- lane l + 1, lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+  };
+  auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  const bool top = lane == 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float nx = shl1(R.x[k][0]), ny = shl1(R.x[k][1]);
+    if (k < 3) {
+      const float wx = rl(R.x[k + 1][0], 0), wy = rl(R.x[k + 1][1], 0);
+      nx = top ? wx : nx;
+      ny = top ? wy : ny;
+    }
+    R.s[k] = nmx_mk2(nx, ny);
+  }
+  R.first = nmx_mk2(rl(R.x[0][0], 0), rl(R.x[0][1], 0));
+  constexpr int g = WC / 4 - 1;   // the last group of four
+  R.last = nmx_mk2(rl(R.x[g / 64][2], g % 64), rl(R.x[g / 64][3], g % 64));
+}
 template <int WC = 0>
 NMX_DEV void nmx_td_load(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R) {
   nmx_td_load_x<WC>(A, w, c, R);

@@ -48,7 +48,10 @@ static inline bool nmx_timeosc_w1000_low_ok(const NmxTimeOscArgs& A) {
   if (A.welch.enabled && A.welch.k_hi + 1 > 100) return false;
   return true;
 }
-#define NMX_TOW_LOW_LDS_FLOATS (1008 + 1008 + 2 * 102)
+// LDS of a wave in the low-band forms: ONE transform buffer -- a single wave reads all the points of a stage before it
+// writes any, so the Stockham stages run in place -- and the 102 real-transform twiddles behind it
+#define NMX_TOW_LOW_TWL_OFF 1008
+#define NMX_TOW_LOW_LDS_FLOATS (1008 + 2 * 102)
 
 // NB = compile-time bound on the number of bands (4 covers the default settings: half the select / add
 // instructions per spectral value of the 8-band build)
@@ -83,7 +86,7 @@ struct NmxBandAcc {
 // Rt: the window of (w, c), loads issued by the caller (or in flight: the persistent kernel issues the loads of a wave's NEXT item
 // before it works on the current one); T: the lane's twiddles.  LDS: fa[500] | fb[501] | xs[1000] (xs only with the STFT).
 // LOW: the persistent kernel's form -- no STFT, every band below bin 100 (nmx_timeosc_w1000_low_ok), the first 102
-// entries of the real-transform twiddle table in LDS at smem + 2016: NO vector-memory load inside the item (loads retire
+// entries of the real-transform twiddle table in LDS at smem + NMX_TOW_LOW_TWL_OFF: NO vector-memory load inside the item (loads retire
 // in order, so one would wait for the prefetch of the next window to land first).
 // LOWNP: the low-band form WITHOUT the LDS twiddle copy (one item per workgroup: nothing to amortise a copy over).
 // SPEC != 0: compiled for ONE feature set -- bits 0..8 the NMXD_F_* features, bit 16 / 17 the log_transform of the FFT /
@@ -109,13 +112,14 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
   const bool welch_log = SPEC ? (SPEC & NMX_TOW_SPEC_LOG_WELCH) != 0 : A.welch.log_transform != 0;
   const int lane = (int)(threadIdx.x & 63);
   nmx_c2* fa = (nmx_c2*)smem;                    // [500]
-  nmx_c2* fb = (nmx_c2*)(smem + 1008);           // [501]
+  nmx_c2* fb = LOW ? fa : (nmx_c2*)(smem + 1008);   // [501] (low-band forms: the transform runs in place)
   float* xs = smem + 2016;                       // [1000] the window, natural order
   float* out_row = A.out + (long long)w * A.n_outputs;
   const int nb = A.n_bands;
 
   const bool spec1000 = fft_on || welch_on;
   float wsum;
+  NMX_PROF_DECL
   {
     // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
     const bool td = (features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
@@ -152,6 +156,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     }
   }
   NMX_WAVE_FENCE();
+  NMX_PROF(0)
 
   NmxBandAcc<NB> acc;
   // ---- FFT and Welch share ONE transform: Z' = FFT_500 of the packed CENTRED window x - mean ----------
@@ -168,7 +173,8 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
                          ? A.fft.k_hi : (welch_on ? A.welch.k_hi + 1 : 0);
     const float2* Z = (const float2*)((LOW || kmax <= 100) ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, kmax)
                                                            : nmx_w500_fft<-1>(fb, fa, fb, T, lane));
-    const float2* twr = (LOW && !LOWNP) ? (const float2*)(smem + 2016) : (fft_on ? A.fft : A.welch).fft.twr;
+    NMX_PROF(1)
+    const float2* twr = (LOW && !LOWNP) ? (const float2*)(smem + NMX_TOW_LOW_TWL_OFF) : (fft_on ? A.fft : A.welch).fft.twr;
     auto xbin = [&](int k) -> float2 {   // X'[k], any k in [-1, 501]
       const int kk = k < 0 ? -k : (k > 500 ? 1000 - k : k);
       if (kk == 0) return make_float2(0.f, 0.f);
@@ -186,6 +192,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       }
       acc.emit(O, nb, 1, out_row, c, lane);
     }
+    NMX_PROF(2)
     if (welch_on) {
       const NmxOsc& O = A.welch;
       acc.clear();
@@ -200,7 +207,13 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       acc.emit(O, nb, 1, out_row, c, lane);
     }
     NMX_WAVE_FENCE();
+    NMX_PROF(3)
   }
+#if defined(NMX_BANK_PROFILE) && !defined(NMX_HOST_EMU)
+  if (w == 5 && (c == 3 || c == 40) && lane == 0)
+    printf("timeosc profile w=%d c=%d: time domain %lld | transform %lld | fft bands %lld | welch bands %lld (cycles)\n", w, c,
+           pf_acc[0], pf_acc[1], pf_acc[2], pf_acc[3]);
+#endif
   // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
   if (stft_on) {
     const NmxOsc& O = A.stft;

@@ -136,7 +136,7 @@ nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
   T.load(A.w500_tab, lane);
   {
     const float2* twr = (A.fft.enabled ? A.fft : A.welch).fft.twr;
-    float2* twl = (float2*)(nmx_smem_wave + 2016);
+    float2* twl = (float2*)(nmx_smem_wave + NMX_TOW_LOW_TWL_OFF);
     twl[lane] = twr[lane];
     if (lane < 38) twl[64 + lane] = twr[64 + lane];
   }
@@ -152,7 +152,7 @@ nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
   for (;;) {
     const int nxt = item + step;
     int wn = 0, cn = 0;
-    nmx_td_load_rest<1000>(A, w, c, R);
+    nmx_td_rest_from_x<1000>(R);
     {
       const int pf = nxt < n_items ? nxt : item;   // (the last iteration re-reads its own item)
       wn = nmx_uniform_i(pf / C); cn = nmx_uniform_i(pf - wn * C);
@@ -168,6 +168,7 @@ nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
     R.x[0] = Xn[0]; R.x[1] = Xn[1]; R.x[2] = Xn[2]; R.x[3] = Xn[3];
   }
 }
+
 
 // returns 0 when the configuration needs the generic kernel
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
@@ -185,7 +186,7 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
   static int low1 = -1;
   if (low1 < 0) { const char* v = getenv("NMX_TOW_LOW1"); low1 = (v && v[0] == '1') ? 1 : 0; }
   if (low1 && nmx_timeosc_w1000_low_ok(*A)) {
-    const size_t lds1 = (size_t)NMX_TOW_LDS_FLOATS_NOSTFT * 4;
+    const size_t lds1 = (size_t)1008 * 4;   // (one transform buffer: in place)
     if (A->n_bands <= 4) {
       hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low1<4>, dim3(n_items), dim3(64), lds1, s, *A);
       nmxi_note_kernel("nmx_kern_timeosc_w1000_low1<4>");
