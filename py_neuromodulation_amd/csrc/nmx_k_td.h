@@ -43,6 +43,20 @@ NMX_DEV nmx_c2 nmx_td_ldc2(const __amdgpu_buffer_rsrc_t rs, int off) {
   return nmx_mk2(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 
+// (a.y, b.x): a pair that straddles two aligned register pairs, assembled by ONE v_pk_mov_b32 (the compiler builds it
+// from two v_mov_b32 -- and an instruction that only moves data costs the issue slot of one that computes)
+NMX_DEV nmx_c2 nmx_pk_hilo(nmx_c2 a, nmx_c2 b) {
+  nmx_c2 r;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (a.y - a.x) in both halves, one instruction
+NMX_DEV nmx_c2 nmx_pk_diff(nmx_c2 a) {
+  nmx_c2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+
 // window -> registers, NO cleaning (w, c wave-uniform).  Two halves so that a persistent kernel can issue the 16-byte
 // loads of its NEXT item early (the part that goes to HBM) and fetch the successors / row ends -- bytes of the same
 // cache lines -- when it starts on the item.
@@ -144,7 +158,7 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       continue;
     }
     const nmx_c2 X0 = R.x[k].xy, X1 = R.x[k].zw;
-    const nmx_c2 Y0 = nmx_mk2(R.x[k].y, R.x[k].z), Y1 = nmx_mk2(R.x[k].w, R.s[k].x);
+    const nmx_c2 Y0 = nmx_pk_hilo(X0, X1), Y1 = nmx_pk_hilo(X1, R.s[k]);   // (x1, x2), (x3, x4)
     a0 += X0;
     a0 += X1;
     D[k][0] = Y0 - X0;
@@ -190,7 +204,7 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
       nmx_c2 F0 = D[k][0] - M1, F1 = D[k][1] - M1;
       // second differences = differences of the first ones, d1[4] = x5 - x4 (the shifted pairs are rebuilt here
       // rather than kept from pass 1: registers)
-      const nmx_c2 S0 = nmx_mk2(D[k][0].y, D[k][1].x), S1 = nmx_mk2(D[k][1].y, R.s[k].y - R.s[k].x);
+      const nmx_c2 S0 = nmx_pk_hilo(D[k][0], D[k][1]), S1 = nmx_pk_hilo(D[k][1], nmx_pk_diff(R.s[k]));
       nmx_c2 G0 = S0 - D[k][0] - M2, G1 = S1 - D[k][1] - M2;
       if (!full) {
         F0 *= m.xx; F1 *= m.x1;
