@@ -291,7 +291,7 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
       float2* Zbuf = (Ab == bufA) ? bufB : bufA;
       const float2* an = nmx_fft<+1>(A.hil_c, Ab, Zbuf, Ab);
       float* dst = A.env_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W;
-      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
+      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = nmx_sqrt_fast(an[i].x * an[i].x + an[i].y * an[i].y);
     }
     NMX_SYNC();
   }

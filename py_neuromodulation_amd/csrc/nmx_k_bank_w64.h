@@ -746,7 +746,7 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
     const float invW = 1.f / (float)W;
     for (int i = NMX_TID; i < W; i += NMX_NT) {
       const float re = ys[i], im = ht[i] * invW;
-      dst[i] = sqrtf(re * re + im * im);
+      dst[i] = nmx_sqrt_fast(re * re + im * im);
     }
     return;
   }
@@ -765,7 +765,7 @@ NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* sm
   NMX_SYNC();
   float2* Zbuf = (Ab == bufA) ? bufB : bufA;
   const float2* an = nmx_fft_auto<+1, true>(A.hil_c, Ab, Zbuf, Ab);
-  for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = sqrtf(an[i].x * an[i].x + an[i].y * an[i].y);
+  for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = nmx_sqrt_fast(an[i].x * an[i].x + an[i].y * an[i].y);
 }
 
 #ifndef NMX_HOST_EMU
@@ -792,7 +792,7 @@ NMX_DEV void nmx_hilbert_w500_item(const NmxHilbertArgs& A, long long item, floa
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const nmx_c2 h = ht[l + 64 * q];
-    const nmx_c2 e = nmx_mk2(sqrtf(y[q].x * y[q].x + h.x * h.x), sqrtf(y[q].y * y[q].y + h.y * h.y));
+    const nmx_c2 e = nmx_mk2(nmx_sqrt_fast(y[q].x * y[q].x + h.x * h.x), nmx_sqrt_fast(y[q].y * y[q].y + h.y * h.y));
     __builtin_amdgcn_raw_buffer_store_b64(e, rout, 8 * l + 512 * q, 0, 0);
   }
 }
