@@ -413,6 +413,9 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       {
         const nmx_rsrc rs = nmx_make_rsrc(src, 4 * W);
         const int h = A.pad_half, ne = A.n_edge;
+        // (branch-free for every register: wave-uniform region tests -- interior / left flank / right flank / beyond the
+        // staged signal, one subtraction each -- execute a third of the instructions and were SLOWER, 1.12 -> 1.30 ms:
+        // the branches between the load groups cost more than the index arithmetic they save)
         float t[32];
         NMX_UNROLL
         for (int r = 0; r < 16; ++r) {
@@ -686,6 +689,20 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       }
 #endif
     } else if (F.store_raw) {
+#ifndef NMX_HOST_EMU
+      {   // offsets relative to sample yoff: what lies in front wraps to a huge unsigned offset, what lies behind
+          // exceeds num_records -- both are dropped by the buffer unit, no compares
+        const int l = (int)(threadIdx.x & 63);
+        const nmx_rsrc rd = nmx_make_rsrc(A.y_out + ((long long)w * A.n_channels + c) * W, 4 * W);
+        NMX_UNROLL
+        for (int i = 0; i < 16; ++i) {
+          const int s0 = 2 * (l + 64 * (i >> 2) + 256 * (i & 3)) - yoff;
+          const nmx_c2 val = v[0][i];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val.x), rd, 4 * s0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val.y), rd, 4 * s0 + 4, 0, 0);
+        }
+      }
+#else
       float* d2 = A.y_out + ((long long)w * A.n_channels + c) * W - yoff;
       NMX_LANE_LOOP {
         NMX_UNROLL
@@ -696,6 +713,7 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
           if (s0 + 1 >= yoff && s0 + 1 < W + yoff) d2[s0 + 1] = val.y;
         }
       }
+#endif
     }
     NMX_WSYNC();
     NMX_PROF(7)
