@@ -11,6 +11,7 @@ static inline unsigned nmx_umulhi(unsigned a, unsigned b) {
   return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
 }
 static inline float nmx_sqrt_fast(float x) { return sqrtf(x); }
+static inline float nmx_log10_fast(float x) { return log10f(x); }
 #else
 NMX_DEV unsigned nmx_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 #endif

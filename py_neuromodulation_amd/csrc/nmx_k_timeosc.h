@@ -218,8 +218,8 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     const float2* Z = nmx_osc_fft(O, bufA, bufB);
     for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
       const float2 X = nmx_osc_bin(O, Z, k);
-      float v = sqrtf(X.x * X.x + X.y * X.y);
-      if (O.log_transform) v = log10f(v);
+      float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y);
+      if (O.log_transform) v = nmx_log10_fast(v);
       spec[k - O.k_lo] = v;
     }
     NMX_SYNC();
@@ -261,7 +261,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     const float inv = 1.f / (float)O.nseg;
     for (int k = NMX_TID; k < O.k_hi - O.k_lo; k += NMX_NT) {
       float v = spec[k] * inv;
-      if (O.log_transform) v = log10f(v);
+      if (O.log_transform) v = nmx_log10_fast(v);
       spec[k] = v;
     }
     NMX_SYNC();
@@ -299,8 +299,8 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
         const float2* Z = nmx_fft4_wave<-1, 250, 5, 5, 5, 2>(wB, wA, wB, O.fft.tw);
         for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
           const float2 X = nmx_rfft_bin(Z, O.fft.twr, 250, k);
-          float v = sqrtf(X.x * X.x + X.y * X.y) * O.scale;
-          if (O.log_transform) v = log10f(v);
+          float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y) * O.scale;
+          if (O.log_transform) v = nmx_log10_fast(v);
           spec[(k - O.k_lo) * O.nseg + sgi] = v;
         }
         NMX_WAVE_FENCE();
@@ -329,8 +329,8 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
           re += v * cs;
           im += v * sn;
         }
-        float v = sqrtf(re * re + im * im) * O.scale;
-        if (O.log_transform) v = log10f(v);
+        float v = nmx_sqrt_fast(re * re + im * im) * O.scale;
+        if (O.log_transform) v = nmx_log10_fast(v);
         spec[(k - O.k_lo) * O.nseg + sgi] = v;
       }
       sg_first = O.nseg;
@@ -348,8 +348,8 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       const float2* Z = nmx_osc_fft(O, bufA, bufB);
       for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
         const float2 X = nmx_osc_bin(O, Z, k);
-        float v = sqrtf(X.x * X.x + X.y * X.y) * O.scale;
-        if (O.log_transform) v = log10f(v);
+        float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y) * O.scale;
+        if (O.log_transform) v = nmx_log10_fast(v);
         spec[(k - O.k_lo) * O.nseg + sgi] = v;
       }
     }

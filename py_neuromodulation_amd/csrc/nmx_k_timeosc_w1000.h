@@ -222,7 +222,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 #pragma unroll
     for (int q = 0; q < 8; ++q) hw[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, 4 * lane + 256 * q, 0, 0));
     acc.clear();
-    const float lscale = O.log_transform ? log10f(O.scale) : 0.f;   // log10(|X| scale) = log10(|X|^2) / 2 + log10(scale)
+    const float lscale = O.log_transform ? O.log10_scale : 0.f;   // log10(|X| scale) = log10(|X|^2) / 2 + log10(scale)
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
@@ -309,7 +309,7 @@ NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, flo
   };
   NmxBandAcc<NB> acc;
   acc.clear();
-  const float lscale = O.log_transform ? log10f(O.scale) : 0.f;
+  const float lscale = O.log_transform ? O.log10_scale : 0.f;
   for (int sa = 0; sa < O.nseg; sa += 2) {
     const bool two = sa + 1 < O.nseg;
 #pragma unroll

@@ -140,7 +140,7 @@ template <int NB, int NBK>
 NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2* rootsL, const float* winL, int W, int nb,
                                  int b0, int lane, NmxBandAcc<NB>& acc_s) {
   const int N = OS.n, h = OS.half;
-  const float lscale = OS.log_transform ? log10f(OS.scale) : 0.f;
+  const float lscale = OS.log_transform ? OS.log10_scale : 0.f;
   for (int sgi = lane; sgi < OS.nseg; sgi += 64) {
     const int s0 = sgi * OS.step;
     float re[NBK], im[NBK];
@@ -230,7 +230,7 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
           if (k >= A.fft.k_lo && k < A.fft.k_hi)
             acc_f.add(A.fft, nb, k, A.fft.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw));
         } else if (k >= OS.k_lo && k < OS.k_hi) {
-          acc_s.add(OS, nb, k, OS.log_transform ? 0.5f * nmx_log10_fast(pw) + log10f(OS.scale) : sqrtf(pw) * OS.scale);
+          acc_s.add(OS, nb, k, OS.log_transform ? 0.5f * nmx_log10_fast(pw) + OS.log10_scale : sqrtf(pw) * OS.scale);
         }
       }
     }
