@@ -174,6 +174,22 @@ def bank_flops_per_item_pair(M: int, n_filters: int, seglens) -> float:
     return float(0.5 * (cfft + n_filters * (2 * M + cfft)) + 3 * sum(seglens))
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest round's PMC passes (profiles/r0N_hbm_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command) and the commit they were taken at, or (None, None)."""
+    tfiles = sorted((ROOT / "profiles").glob("r[0-9][0-9]_hbm_traffic.json"))
+    if not tfiles:
+        return None, None
+    try:
+        doc = json.loads(tfiles[-1].read_text())
+        hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == kernel.replace("void ", "")]
+        if hit:   # only reported for the kernel that ran now
+            return hit[0]["hbm_bytes_per_launch"], doc.get("measured_at_commit")
+    except Exception:
+        pass
+    return None, None
+
+
 def roofline_mode_a(torch, dev, dev_index, channels=256, windows=4096, steps=5):
     """SURVEY 8(d) "Mode A" for the HBM-bound half of the north star (BASELINE config[1]'s feature set: FFT band power +
     Hjorth + LineLength): DISTINCT data per window (hop = W = 1000), 4.2 GB of input -- far beyond the 256 MB
@@ -211,8 +227,10 @@ def roofline_mode_a(torch, dev, dev_index, channels=256, windows=4096, steps=5):
     kern = eng.kernels(2)
     eng.close()
     del x, out
+    traffic, traffic_at = measured_traffic(kern)
     return {"bound": "hbm", "kernel": kern, "achieved": nbytes / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / t / 1e6 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": t,
+            "frac": nbytes / t / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_at,
+            "ms_per_launch": t,
             "algorithmic_bytes_per_launch": nbytes,
             "workload": f"Mode A: {channels} ch x {windows} DISTINCT 1000-sample windows (hop = W), "
                         "FFT band power + Hjorth + LineLength, no pre-processing"}
@@ -467,18 +485,7 @@ def main() -> None:
         bank_bytes = n_win * C * (4 * W + 4 * n_bp)
         achieved = bank_bytes / (bank_ms * 1e-3) / 1e9 if bank_ms > 0 else 0.0
         kernel = eng.kernels(3)   # what the plan launched in the FIR-bank stage of the last step
-        traffic = traffic_at = None
-        tfiles = sorted((ROOT / "profiles").glob("r[0-9][0-9]_hbm_traffic.json"))   # newest round's PMC passes
-        tfile = tfiles[-1] if tfiles else None
-        if tfile is not None:
-            try:
-                doc = json.loads(tfile.read_text())
-                hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == kernel]
-                if hit:   # PMC passes are separate runs: only reported for the kernel that ran now
-                    traffic = hit[0]["hbm_bytes_per_launch"]
-                    traffic_at = doc.get("measured_at_commit")
-            except Exception:
-                traffic = None
+        traffic, traffic_at = measured_traffic(kernel)
         nf = int(eng.desc.n_filters)
         if "w64c" in kernel:   # the M = 1536 channel-pair kernel took the filters with W + (L - 1) / 2 <= 1536
             sel = [i for i in range(nf) if W + (int(eng.desc.filters[i].n_taps) - 1) // 2 <= 1536]
