@@ -139,6 +139,7 @@ struct NmxOsc {
   float scale;   // Welch: 1 / (fs * sum w^2); STFT: 1 / sum w
   float log10_scale;   // log10(scale), formed on the host (the library log10f of a plan constant was ~40 VALU instructions per item)
   int bin_lo[NMX_MAX_BANDS_DEV], bin_hi[NMX_MAX_BANDS_DEV];
+  float inv_bins[NMX_MAX_BANDS_DEV];   // 1 / (bin_hi - bin_lo), NaN for an empty band (the reference's mean of nothing)
   NmxCols cols, psd_cols;
   NmxFft fft;    // complex length n/2 (or n when complex_full)
   const float* win;  // [n] window (Welch: hann, STFT: hamming), NULL for FFT

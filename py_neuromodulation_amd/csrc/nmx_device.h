@@ -73,6 +73,27 @@ NMX_DEV void nmx_wave_sum4(float& a, float& b, float& c, float& d) {
   d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
 }
 
+// nmx_wave_sum4 without the broadcast: the sums of a, c, b, d are left in lanes 0, 16, 32, 48 (10 instructions) for
+// callers whose consumers are those four lanes (one store instruction for four results)
+NMX_DEV float nmx_wave_sum4_rows(float a, float b, float c, float d) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  auto bits = [](float v) { return __builtin_bit_cast(unsigned, v); };
+  auto flt = [](unsigned v) { return __builtin_bit_cast(float, v); };
+  const u2v ab = __builtin_amdgcn_permlane32_swap(bits(a), bits(b), false, false);
+  const u2v cd = __builtin_amdgcn_permlane32_swap(bits(c), bits(d), false, false);
+  const float sab = flt(ab[0]) + flt(ab[1]);
+  const float scd = flt(cd[0]) + flt(cd[1]);
+  const u2v q = __builtin_amdgcn_permlane16_swap(bits(sab), bits(scd), false, false);
+  float v = flt(q[0]) + flt(q[1]);             // rows: a, c, b, d
+#define NMX_DPP4(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  v += NMX_DPP4(0xB1);
+  v += NMX_DPP4(0x4E);
+  v += NMX_DPP4(0x141);
+  v += NMX_DPP4(0x140);
+#undef NMX_DPP4
+  return v;
+}
+
 template <typename T, typename Op>
 NMX_DEV T nmx_block_reduce(T v, T ident, float* red, Op op) {
   v = nmx_wave_reduce(v, ident, op);
@@ -147,6 +168,8 @@ NMX_DEV float nmx_clean(float v) {
 // correctly rounded results) was a fifth of their instructions.  Absolute error ~2e-7 in log10 units, where the
 // parity policy allows 1e-5.
 NMX_DEV float nmx_log10_fast(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
+// log10(sqrt(x)) = log10(x) / 2 in one multiplication (band powers: the log of |X| from |X|^2)
+NMX_DEV float nmx_log10_half_fast(float x) { return __builtin_amdgcn_logf(x) * 0.15051499783199060f; }
 // sqrt through the hardware instruction (v_sqrt_f32, 1 ulp) for per-sample work: the library sqrtf is the instruction
 // plus a scaling / refinement sequence of ~12 instructions to a correctly rounded result (denormal inputs included) --
 // a quarter of the Hilbert-envelope kernel's VALU instructions for a relative 6e-8 nobody reads

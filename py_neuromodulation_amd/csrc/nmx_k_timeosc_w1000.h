@@ -69,6 +69,15 @@ struct NmxBandAcc {
       if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
   }
   NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
+    if (NB == 4 && vals_per_bin == 1) {
+      // the four band sums stay in lanes 0 / 16 / 32 / 48 (bands 0, 2, 1, 3): ONE multiplication and ONE store
+      // instruction for the four results, no broadcast through scalar registers
+      const float r = nmx_wave_sum4_rows(s[0], s[1], s[2], s[3]);
+      const int row = lane >> 4, b = ((row & 1) << 1) | (row >> 1);
+      const float inv = b == 0 ? O.inv_bins[0] : (b == 1 ? O.inv_bins[1] : (b == 2 ? O.inv_bins[2] : O.inv_bins[3]));
+      if ((lane & 15) == 0 && b < n_bands) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = r * inv;
+      return;
+    }
     float tot[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) tot[b] = s[b];
@@ -77,6 +86,10 @@ struct NmxBandAcc {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= n_bands) continue;
+      if (vals_per_bin == 1) {   // (compile-time at the call sites: the plan's 1 / bins, NaN for an empty band)
+        if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = tot[b] * O.inv_bins[b];
+        continue;
+      }
       const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
       if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot[b] * __builtin_amdgcn_rcpf((float)cnt) : NAN;
     }
@@ -124,7 +137,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
     const bool td = (features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0;
     // (always: the window sum it forms is also the NaN / infinity test of the window)
-    const bool fast = nmx_td_emit<1000, !LOW, (SPEC & NMX_TOW_FEATS)>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
+    const bool fast = nmx_td_emit<1000, (!LOW || SPEC != 0), (SPEC & NMX_TOW_FEATS)>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
     wsum = Rt.sum;
     if (fast) {
       if (stft_on) {   // park the window in LDS (group 3: lanes 0..57)
@@ -185,14 +198,34 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       const NmxOsc& O = A.fft;
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
-        const float2 X = k == 0 ? make_float2(wsum, 0.f) : xbin(k);
+        // (low-band forms: 0 <= k < 100, no mirrored bin)
+        const float2 X = k == 0 ? make_float2(wsum, 0.f) : (LOW ? nmx_rfft_bin(Z, twr, 500, k) : xbin(k));
         const float pw = X.x * X.x + X.y * X.y;
-        const float v = fft_log ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
+        const float v = fft_log ? nmx_log10_half_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
       }
       acc.emit(O, nb, 1, out_row, c, lane);
     }
     NMX_PROF(2)
+#ifndef NMX_HOST_EMU
+    if (welch_on && LOW && A.welch.k_lo >= 1 && A.welch.k_hi - A.welch.k_lo + 2 <= 64) {
+      // low-band forms, all bins in one pass: lane l forms X'[k_lo - 1 + l] ONCE and takes the two neighbours of the
+      // three-term hann convolution from the lanes next to it (DPP) instead of two more bins from LDS
+      const NmxOsc& O = A.welch;
+      acc.clear();
+      const int k = O.k_lo - 1 + lane;
+      float2 X0 = nmx_rfft_bin(Z, twr, 500, k < 1 ? 1 : (k > 101 ? 101 : k));
+      if (k < 1) X0 = make_float2(0.f, 0.f);   // X'[0] = 0: the constant went with the detrend
+      auto shr1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); };
+      auto shl1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); };
+      const float2 Xm = make_float2(shr1(X0.x), shr1(X0.y)), Xp = make_float2(shl1(X0.x), shl1(X0.y));
+      const float yr = 0.5f * X0.x - 0.25f * (Xm.x + Xp.x), yi = 0.5f * X0.y - 0.25f * (Xm.y + Xp.y);
+      float p = (yr * yr + yi * yi) * (2.f * O.scale);   // (1 <= k < 500: two-sided density)
+      if (welch_log) p = nmx_log10_fast(p);
+      if (k >= O.k_lo && k < O.k_hi) acc.add(O, nb, k, p);
+      acc.emit(O, nb, 1, out_row, c, lane);
+    } else
+#endif
     if (welch_on) {
       const NmxOsc& O = A.welch;
       acc.clear();
@@ -245,11 +278,11 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
         const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
         const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
         const float pa = ax * ax + ay * ay;
-        const float va = O.log_transform ? 0.5f * nmx_log10_fast(pa) + lscale : sqrtf(pa) * O.scale;
+        const float va = O.log_transform ? nmx_log10_half_fast(pa) + lscale : sqrtf(pa) * O.scale;
         acc.add(O, nb, k, va);
         if (pr < 2) {
           const float pb = bx * bx + by * by;
-          const float vb = O.log_transform ? 0.5f * nmx_log10_fast(pb) + lscale : sqrtf(pb) * O.scale;
+          const float vb = O.log_transform ? nmx_log10_half_fast(pb) + lscale : sqrtf(pb) * O.scale;
           acc.add(O, nb, k, vb);
         }
       }
@@ -324,10 +357,10 @@ NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, flo
       const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
       const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
       const float pa = ax * ax + ay * ay;
-      acc.add(O, nb, k, O.log_transform ? 0.5f * nmx_log10_fast(pa) + lscale : sqrtf(pa) * O.scale);
+      acc.add(O, nb, k, O.log_transform ? nmx_log10_half_fast(pa) + lscale : sqrtf(pa) * O.scale);
       if (two) {
         const float pb = bx * bx + by * by;
-        acc.add(O, nb, k, O.log_transform ? 0.5f * nmx_log10_fast(pb) + lscale : sqrtf(pb) * O.scale);
+        acc.add(O, nb, k, O.log_transform ? nmx_log10_half_fast(pb) + lscale : sqrtf(pb) * O.scale);
       }
     }
     NMX_WAVE_FENCE();

@@ -167,7 +167,7 @@ NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
       const float pw = re[b] * re[b] + im[b] * im[b];
-      const float v = OS.log_transform ? 0.5f * nmx_log10_fast(pw) + lscale : sqrtf(pw) * OS.scale;
+      const float v = OS.log_transform ? nmx_log10_half_fast(pw) + lscale : sqrtf(pw) * OS.scale;
       acc_s.add(OS, nb, OS.k_lo + b0 + b, v);
     }
   }
@@ -228,9 +228,9 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
         const float pw = re * re + im * im;
         if (q < n_fft) {
           if (k >= A.fft.k_lo && k < A.fft.k_hi)
-            acc_f.add(A.fft, nb, k, A.fft.log_transform ? 0.5f * nmx_log10_fast(pw) : sqrtf(pw));
+            acc_f.add(A.fft, nb, k, A.fft.log_transform ? nmx_log10_half_fast(pw) : sqrtf(pw));
         } else if (k >= OS.k_lo && k < OS.k_hi) {
-          acc_s.add(OS, nb, k, OS.log_transform ? 0.5f * nmx_log10_fast(pw) + OS.log10_scale : sqrtf(pw) * OS.scale);
+          acc_s.add(OS, nb, k, OS.log_transform ? nmx_log10_half_fast(pw) + OS.log10_scale : sqrtf(pw) * OS.scale);
         }
       }
     }
