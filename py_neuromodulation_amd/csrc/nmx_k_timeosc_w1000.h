@@ -69,12 +69,14 @@ struct NmxBandAcc {
       if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
   }
   NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
-    if (NB == 4 && vals_per_bin == 1) {
+    if (NB == 4) {
       // the four band sums stay in lanes 0 / 16 / 32 / 48 (bands 0, 2, 1, 3): ONE multiplication and ONE store
-      // instruction for the four results, no broadcast through scalar registers
+      // instruction for the four results, no broadcast through scalar registers; 1 / bins from the plan (NaN for an
+      // empty band: the reference's mean of nothing)
       const float r = nmx_wave_sum4_rows(s[0], s[1], s[2], s[3]);
       const int row = lane >> 4, b = ((row & 1) << 1) | (row >> 1);
-      const float inv = b == 0 ? O.inv_bins[0] : (b == 1 ? O.inv_bins[1] : (b == 2 ? O.inv_bins[2] : O.inv_bins[3]));
+      float inv = b == 0 ? O.inv_bins[0] : (b == 1 ? O.inv_bins[1] : (b == 2 ? O.inv_bins[2] : O.inv_bins[3]));
+      if (vals_per_bin != 1) inv *= 1.f / (float)vals_per_bin;
       if ((lane & 15) == 0 && b < n_bands) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = r * inv;
       return;
     }
@@ -208,8 +210,8 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     }
     NMX_PROF(2)
 #ifndef NMX_HOST_EMU
-    if (welch_on && LOW && A.welch.k_lo >= 1 && A.welch.k_hi - A.welch.k_lo + 2 <= 64) {
-      // low-band forms, all bins in one pass: lane l forms X'[k_lo - 1 + l] ONCE and takes the two neighbours of the
+    if (welch_on && A.welch.k_lo >= 1 && A.welch.k_hi - A.welch.k_lo + 2 <= 64 && A.welch.k_hi <= 100) {
+      // low bands, all bins in one pass: lane l forms X'[k_lo - 1 + l] ONCE and takes the two neighbours of the
       // three-term hann convolution from the lanes next to it (DPP) instead of two more bins from LDS
       const NmxOsc& O = A.welch;
       acc.clear();
