@@ -327,13 +327,36 @@ NMX_NOINLINE nmx_c2 nmx_w64_range_mask(nmx_c2 val, int m, int lo, int hi) {
   { result = nmx_wave_reduce(acc_array[0], 0.f, [](float a_, float b_) { return a_ + b_; }); }
 #endif
 
+#ifndef NMX_HOST_EMU
+// the notch's reflection table (see nmx_bank_w64_item, rtab): [16][64] words, built by the threads of a workgroup
+NMX_DEV void nmx_w64_reflect_table(const NmxBankArgs& A, unsigned* rtab, int tid, int nthreads) {
+  const int W = A.W, h = A.pad_half, ne = A.n_edge;
+  for (int i = tid; i < 1024; i += nthreads) {
+    const int r = i >> 6, l = i & 63;
+    unsigned word = 0;
+    for (int u = 0; u < 2; ++u) {
+      const int jp = 2 * (l + 64 * r) + u, j = jp - h;
+      unsigned e = 0xfffcu;   // beyond the staged signal / the reflection limit: loads 0, enters as is
+      if (jp < W + 2 * h) {
+        if (j < 0) { if (-j <= ne) e = (unsigned)(4 * -j) | 1u; }
+        else if (j < W) e = (unsigned)(4 * j);
+        else { const int rr = j - (W - 1); if (rr <= ne) e = (unsigned)(4 * (W - 1 - rr)) | 2u; }
+      }
+      word |= e << (16 * u);
+    }
+    rtab[i] = word;
+  }
+}
+#endif
+
 // PAD = 0: zero-padded window ("same" FIR bank);  PAD = 1: odd-reflected window (notch)
 // TAB = 1: the A/B tables of all filters sit in LDS at `tab` ([filter][A[n], B[n]]), staged once
 // per (persistent, multi-wave) workgroup; TAB = 0: read from global memory (L2).
 // HALF = 1 (PAD = 0, W <= 1024): only the output registers v[4 t + r], r < 2 (samples < 1024) exist -- the
 // others are never computed, reduced or stored.
 template <int PAD, int TAB, int MC, int HALF = 0, int HOIST = 1>
-NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab) {
+NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* smem, const float* tab,
+                               const unsigned* rtab = nullptr) {
   w = nmx_uniform_i(w);   // one item per wave: (w, c) and everything derived from them is scalar
   c = nmx_uniform_i(c);
   const NmxBankArgs& A = AA.b;
@@ -410,6 +433,39 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
       // reflected flanks (MNE _smart_pad, reflect_limited: at most n_edge samples); every lane computes its 32
       // indices branch-free and all loads are in flight before the first use (the staged form walked 18 of the 32
       // elements through nested branches with one dependent LDS read each: 60 % of the notch item's cycles).
+      if (rtab) {
+        // The persistent kernel's form: WHERE sample jp of the staged signal comes from and HOW it enters (as is, or
+        // reflected about the first / the last sample) depends on the plan and the lane only -- nmx_w64_reflect_table
+        // writes it once per workgroup into LDS, two 16-bit entries per word: byte offset | code (0: x, 1: 2 x[0] - x,
+        // 2: 2 x[W-1] - x; a sample beyond the staged signal is code 0 at an out-of-range offset, which loads 0).  Per
+        // sample: decode + load + one subtraction and two selects instead of ~20 index / range instructions.
+        const nmx_rsrc rs = nmx_make_rsrc(src, 4 * W);
+        unsigned wds[16];
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) wds[r] = rtab[64 * r + l];
+        float t[32];
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          t[2 * r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(wds[r] & 0xfffcu), 0, 0));
+          t[2 * r + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((wds[r] >> 16) & 0xfffcu), 0, 0));
+        }
+        float x0 = src[0], xl = src[W - 1];
+        if (A.clean_on_load) { x0 = nmx_clean(x0); xl = nmx_clean(xl); }
+        const float x02 = 2.f * x0, xl2 = 2.f * xl;
+        NMX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          float e2[2];
+          NMX_UNROLL
+          for (int u = 0; u < 2; ++u) {
+            const unsigned code = (wds[r] >> (16 * u)) & 3u;
+            float x = t[2 * r + u];
+            if (A.clean_on_load) x = nmx_clean_bl(x);
+            const float refl = (code == 1u ? x02 : xl2) - x;
+            e2[u] = code == 0u ? x : refl;
+          }
+          vv[r] = nmx_mk2(e2[0], e2[1]);
+        }
+      } else
       {
         const nmx_rsrc rs = nmx_make_rsrc(src, 4 * W);
         const int h = A.pad_half, ne = A.n_edge;

@@ -81,11 +81,18 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64q_, NMX_W64_
                              nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats, tab);
 }
 
-// Persistent form of the above: workgroups of four waves, three per CU, walk the items -- the tables are staged once
+// waves of the persistent notch workgroup: ONE workgroup of twelve waves per CU (3 waves / SIMD at 168 VGPRs) shares one
+// copy of the 20 KB of tables -- measured on one lease with the reflection table: 12 waves 0.96 ms, 6 (two workgroups per
+// CU) 1.15 - 1.20, 4 (only two workgroups fit: 8 waves) 1.22
+#ifndef NMX_NOTCH_QP_WAVES
+#define NMX_NOTCH_QP_WAVES 12
+#endif
+// Persistent form of the above: one workgroup per CU (filter tables, twiddles and the reflection table: 20 KB, one
+// exchange tile per wave) walks the items -- the tables are staged once
 // per workgroup instead of once per four items (the staging + its barrier + the workgroup launch were a quarter of
 // the four-item kernel's time).  The kernel-argument pointer is laundered once per iteration so that the plan is
 // re-read with s_load instead of being hoisted into (spilled) scalar registers (nmx_wave.hip).
-__global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_items,
+__global__ void __launch_bounds__(64 * NMX_NOTCH_QP_WAVES, 3) NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_items,
                                                                                        int x_floats) {
   typedef const NmxBankW64Args __attribute__((address_space(4)))* nmx_karg_p;
   nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
@@ -93,17 +100,19 @@ __global__ void __launch_bounds__(256, 3) NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64
   const int n = NMX_W64_N, tab_floats = 2 * n;
   {
     const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
-    for (int i = threadIdx.x; i < tab_floats; i += 256) tab[i] = i < n ? A.Hs[0][i] : A.Hd[0][i - n];
-    for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += 256) tab[tab_floats + i] = A.twl[i];
+    for (int i = threadIdx.x; i < tab_floats; i += 64 * NMX_NOTCH_QP_WAVES) tab[i] = i < n ? A.Hs[0][i] : A.Hd[0][i - n];
+    for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += 64 * NMX_NOTCH_QP_WAVES) tab[tab_floats + i] = A.twl[i];
   }
+  unsigned* rtab = (unsigned*)(nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS);   // [16][64] (4 KB)
+  nmx_w64_reflect_table(((const NmxBankW64Args*)Ap)->b, rtab, (int)threadIdx.x, 64 * NMX_NOTCH_QP_WAVES);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
+  float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + 1024 + wave * x_floats;
 #pragma nounroll
-  for (int item = blockIdx.x * 4 + wave; item < n_items; item += (int)gridDim.x * 4) {
+  for (int item = blockIdx.x * NMX_NOTCH_QP_WAVES + wave; item < n_items; item += (int)gridDim.x * NMX_NOTCH_QP_WAVES) {
     asm volatile("" : "+s"(Ap));
     const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
-    nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+    nmx_bank_w64_item<1, 1, 0>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, rtab);
     NMX_WAVE_FENCE();
   }
 }
@@ -264,7 +273,8 @@ extern "C" int NMX_CAT(nmx_w64q_launch_notch_, NMX_W64_NAME)(const NmxBankW64Arg
     if (nmx_first_on_device(seen_p))
       (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME), dim3(3 * 256), dim3(256), lds, s, *A, n_items, x_floats);
+    const size_t ldsp = (size_t)(2 * NMX_W64_N + NMX_W64_TWL_FLOATS + 1024 + NMX_NOTCH_QP_WAVES * x_floats) * 4;
+    hipLaunchKernelGGL(NMX_CAT(nmx_kern_notch_w64qp_, NMX_W64_NAME), dim3((12 / NMX_NOTCH_QP_WAVES) * 256), dim3(64 * NMX_NOTCH_QP_WAVES), ldsp, s, *A, n_items, x_floats);
     NMX_KNAME("nmx_kern_notch_w64qp_", "");
     return 1;
   }
