@@ -151,6 +151,11 @@ NMX_DEV void nmx_block_sum_n(float* v, float* red) {
 }
 #endif
 
+#ifndef NMX_HOST_EMU
+// the bare instructions: a NaN operand is skipped (no canonicalising v_max(x, x) in front, as __builtin_fmaxf gets)
+NMX_DEV float nmx_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+NMX_DEV float nmx_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#endif
 NMX_DEV float nmx_nanmax(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
 NMX_DEV float nmx_nanmin(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
 
