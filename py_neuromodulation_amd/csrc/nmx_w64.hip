@@ -47,21 +47,31 @@ __global__ void __launch_bounds__(64, 2) NMX_CAT(nmx_kern_notch_w64_, NMX_W64_NA
 // Pipelined persistent kernel (nmx_k_bank_w64p.h): the A / B tables are staged INTERLEAVED ((A_k, B_k) pairs: one
 // 8-byte read per point), everything else as below.
 template <int HALF>
-__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)(const NmxBankW64Args A, int n_items,
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64pp_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_items,
                                                                                     int x_floats) {
+  // (kernel-argument pointer laundered once per item: the plan is re-read with s_load, not hoisted into scalar
+  // registers that spill to lanes of a VGPR)
+  typedef const NmxBankW64Args __attribute__((address_space(4)))* nmx_karg_p;
+  nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
   float* tab = nmx_smem_w64;
-  const int n = NMX_W64_N, tab_floats = A.b.n_filters * 2 * n;
-  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
-    const int fi = i / (2 * n), j = i - fi * 2 * n;
-    tab[i] = (j & 1) ? A.Hd[fi][j >> 1] : A.Hs[fi][j >> 1];
+  const int n = NMX_W64_N, tab_floats = ((const NmxBankW64Args*)Ap)->b.n_filters * 2 * n;
+  {
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) {
+      const int fi = i / (2 * n), j = i - fi * 2 * n;
+      tab[i] = (j & 1) ? A.Hd[fi][j >> 1] : A.Hs[fi][j >> 1];
+    }
+    for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
   }
-  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + wave * x_floats;
 #pragma nounroll
-  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
+  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw) {
+    asm volatile("" : "+s"(Ap));
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
     nmx_bank_w64_item_pipe<HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab);
+  }
 }
 
 // Notch, four items per workgroup: the filter's A / B tables and the twiddles are staged in LDS once per
@@ -120,19 +130,30 @@ __global__ void __launch_bounds__(64 * NMX_NOTCH_QP_WAVES, 3) NMX_CAT(nmx_kern_n
 // M = 4096 (nmx_k_bank_w64x2.h): persistent workgroups of `nw` waves; LDS = tables of the first n_tab filters,
 // pass B / C twiddles, w^k, one exchange tile per wave
 template <int HALF>
-__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)(const NmxBankW64Args A, int n_items,
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64x2_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_items,
                                                                                     int x_floats, int n_tab) {
+  // (the kernel-argument pointer is laundered once per item: the plan -- eight filters' worth of descriptors -- is then
+  // re-read with s_load instead of being hoisted into scalar registers that spill to v_writelane / v_readlane, 108 of
+  // them in the first form of this loop)
+  typedef const NmxBankW64Args __attribute__((address_space(4)))* nmx_karg_p;
+  nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
   float* tab = nmx_smem_w64;
   const int tab_floats = n_tab * 4096;
-  for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) tab[i] = A.Hs[i >> 12][i & 4095];
-  for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) tab[tab_floats + NMX_W64_TWL_FLOATS + i] = A.tw2[i];
+  {
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    for (int i = threadIdx.x; i < tab_floats; i += blockDim.x) tab[i] = A.Hs[i >> 12][i & 4095];
+    for (int i = threadIdx.x; i < NMX_W64_TWL_FLOATS; i += blockDim.x) tab[tab_floats + i] = A.twl[i];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) tab[tab_floats + NMX_W64_TWL_FLOATS + i] = A.tw2[i];
+  }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   float* mine = nmx_smem_w64 + tab_floats + NMX_W64_TWL_FLOATS + 2048 + wave * x_floats;
 #pragma nounroll
-  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw)
+  for (int item = blockIdx.x * nw + wave; item < n_items; item += gridDim.x * nw) {
+    asm volatile("" : "+s"(Ap));
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
     nmx_bank_w64x2_item<HALF>(A, item / A.b.n_channels, item % A.b.n_channels, mine, tab, n_tab);
+  }
 }
 
 extern "C" int NMX_CAT(nmx_w64x2_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
