@@ -113,6 +113,8 @@ struct NmxBandAcc {
 // LineLength) and the time / oscillatory features of default_settings.yaml (+ Raw + Welch), log10 band powers
 #define NMX_TOW_SPEC_C2 (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_FFT | NMX_TOW_SPEC_LOG_FFT)
 #define NMX_TOW_SPEC_DEFAULT (NMXD_F_HJORTH | NMXD_F_RAW | NMXD_F_LINELENGTH | NMXD_F_FFT | NMXD_F_WELCH | NMX_TOW_SPEC_LOG_FFT | NMX_TOW_SPEC_LOG_WELCH)
+// every time / oscillatory feature of the hot path, log10 band powers (bench.py's headline set)
+#define NMX_TOW_SPEC_ALL (NMX_TOW_SPEC_DEFAULT | NMXD_F_STFT)
 static inline unsigned nmx_tow_spec(const NmxTimeOscArgs& A) {
   return (A.features & NMX_TOW_FEATS) | (A.fft.enabled && A.fft.log_transform ? NMX_TOW_SPEC_LOG_FFT : 0u) |
          (A.welch.enabled && A.welch.log_transform ? NMX_TOW_SPEC_LOG_WELCH : 0u);

@@ -83,7 +83,7 @@ extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long 
 }
 
 // time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
-template <int NB>
+template <int NB, unsigned SPEC = 0>
 __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
   const int item = blockIdx.x;
   const int w = nmx_uniform_i(item / A.n_channels), c = nmx_uniform_i(item % A.n_channels);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArg
   T.load(A.w500_tab, (int)(threadIdx.x & 63));
   NmxTdRegs R;
   nmx_td_load<1000>(A, w, c, R);
-  nmx_timeosc_w1000_body<NB>(A, w, c, R, T, nmx_smem_wave);
+  nmx_timeosc_w1000_body<NB, false, NmxW500TwReg, false, SPEC>(A, w, c, R, T, nmx_smem_wave);
 }
 
 // low bands, no STFT, ONE item per workgroup at 5 waves per SIMD (96 VGPRs: compact twiddles, no prefetch registers):
@@ -223,7 +223,12 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     return 1;
   }
   const size_t lds = (size_t)(A->stft.enabled ? NMX_TOW_LDS_FLOATS : NMX_TOW_LDS_FLOATS_NOSTFT) * 4;
-  if (A->n_bands <= 4) {
+  static int spec_full = -1;
+  if (spec_full < 0) { const char* v = getenv("NMX_TOW_SPEC"); spec_full = !(v && v[0] == '0'); }
+  if (A->n_bands <= 4 && spec_full && nmx_tow_spec(*A) == NMX_TOW_SPEC_ALL) {   // the headline set: feature tests folded
+    hipLaunchKernelGGL((nmx_kern_timeosc_w1000<4, NMX_TOW_SPEC_ALL>), dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel("nmx_kern_timeosc_w1000<4, 196923u>");
+  } else if (A->n_bands <= 4) {
     hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), lds, s, *A);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<4>");
   } else {
