@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, part d: FIR kernels -- notch (reflected window from global memory, persistent workgroups), channel-pair bank
+# FIR kernels alone and inside the step: notch alone, bank + sharp-wave filters alone, their parity tests, the step with and without overlap
 # (tail variance: registers in front of the tail skipped, four sums per reduction)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
