@@ -1,6 +1,5 @@
 #!/bin/bash
 # FIR kernels alone and inside the step: notch alone, bank + sharp-wave filters alone, their parity tests, the step with and without overlap
-# (tail variance: registers in front of the tail skipped, four sums per reduction)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "notch alone: $(timeout 300 python tools/run_notch_only.py 2>&1 | tail -1)"
