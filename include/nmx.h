@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 6
+#define NMX_ABI_VERSION 7
 
 /* error codes */
 #define NMX_OK 0
@@ -217,6 +217,16 @@ int nmx_plan_n_outputs(const nmx_plan* plan, int64_t* n_outputs);
 int nmx_process_batch(nmx_plan* plan, const float* x, int64_t ldx, int64_t n_samples,
                       const int64_t* starts, int64_t n_windows, float* out, uint8_t* nan_mask,
                       int memspace, void* hip_stream);
+
+/* nmx_process_batch that ALSO hands back the pre-processed windows the features were computed from:
+ * pre[n_windows][n_channels][window] float32 (host or device like `out`) -- the `data` argument of
+ * NMFeature.calc_feature (features/feature_processor.py:80-82).  The Python host runs user-registered features
+ * (nm.add_custom_feature, feature_processor.py:52-53,90-108) on them and appends their columns after the built-in
+ * ones.  State (burst ring, Kalman, raw normaliser) advances exactly as in nmx_process_batch: the windows come
+ * from the SAME pre-processing pass, not from a second one. */
+int nmx_process_batch_tap(nmx_plan* plan, const float* x, int64_t ldx, int64_t n_samples,
+                          const int64_t* starts, int64_t n_windows, float* out, uint8_t* nan_mask,
+                          int memspace, void* hip_stream, float* pre);
 
 /* One window, the reference's call shape: x[C_in][W] float64 host -> out[n_outputs] host. */
 int nmx_process_window(nmx_plan* plan, const double* x, int64_t ldx, float* out,

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 6
+NMX_ABI_VERSION = 7
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -79,7 +79,7 @@ class NmxError(RuntimeError):
 
 _EXPORTS = [
     "nmx_abi_version", "nmx_device_count", "nmx_last_error", "nmx_plan_create",
-    "nmx_plan_destroy", "nmx_plan_n_outputs", "nmx_process_batch", "nmx_process_window",
+    "nmx_plan_destroy", "nmx_plan_n_outputs", "nmx_process_batch", "nmx_process_batch_tap", "nmx_process_window",
     "nmx_preprocess_window", "nmx_filter_window", "nmx_state_reset", "nmx_state_size",
     "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms", "nmx_last_kernels",
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
@@ -121,6 +121,8 @@ class NmxLibrary:
         L.nmx_plan_n_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.nmx_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.nmx_process_batch_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.nmx_process_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.nmx_preprocess_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.nmx_filter_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]

@@ -82,14 +82,16 @@ __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
 __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
 }
+// rows on grid.x (2^31 - 1 blocks), column blocks on grid.y: grid.y / .z stop at 65 535, and a long offline table or a
+// long history has more rows than that
 __global__ void __launch_bounds__(256) nmx_kern_power_prep(const NmxPowerPrepArgs P) {
-  nmx_power_prep_at(P, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x));
+  nmx_power_prep_at(P, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
 }
 __global__ void __launch_bounds__(64) nmx_kern_power(const NmxPowerArgs A) {
-  nmx_power_cell(A, (int)blockIdx.y, (int)(blockIdx.x * 64 + threadIdx.x));
+  nmx_power_cell(A, (int)blockIdx.x, (int)(blockIdx.y * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_power_ring(const NmxPowerPrepArgs P) {
-  nmx_power_ring_at(P, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x));
+  nmx_power_ring_at(P, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
   __shared__ float red[256];
@@ -102,6 +104,10 @@ __global__ void __launch_bounds__(256) nmx_kern_reref_struct(const NmxRerefStruc
 __global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
   const int item = blockIdx.x;
   nmx_nanmask_item(A, item / A.C_in, item % A.C_in, nmx_smem);
+}
+__global__ void __launch_bounds__(256) nmx_kern_tap(const NmxTapArgs A) {
+  const int item = blockIdx.x;
+  nmx_tap_item(A, item / A.C, item % A.C);
 }
 
 // ---- which kernels ran (per stage of the launch sequence; stage indices = nmx_last_timing_ms) ----
@@ -125,7 +131,7 @@ struct be_timer_t {
 };
 
 static thread_local std::string g_be_err;
-static int g_be_rc = 0;
+static thread_local int g_be_rc = 0;   // per host thread: the plans of a multi-device stream run on one thread each
 static int nmx_fail(int code, const std::string& msg);
 static int be_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
@@ -280,11 +286,13 @@ extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, s
 //   notch (odd-reflected window), >= 1024 items: four items / workgroup nmx_kern_notch_w64q
 //   a window or two (nmx_process_window): one wave per workgroup        nmx_kern_bank_w64 / nmx_kern_notch_w64
 static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds, be_stream_t s) {
-  static int n_cu = -1;
-  if (n_cu < 0) {
+  static thread_local int n_cu = -1, n_cu_dev = -1;   // per host thread and device (multi-device streams)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (n_cu < 0 || n_cu_dev != dev) {
     hipDeviceProp_t prop;
-    int dev = 0;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    n_cu_dev = dev;
   }
   if (A.tw2) {
     if (!nmx_w64x2_launch_rd64(&A, n_items, n_cu, s)) g_be_rc = nmx_fail(NMX_E_INVALID, "M = 4096 FIR path: LDS budget");
@@ -379,11 +387,11 @@ static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
 }
 static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be_stream_t s) {
-  const unsigned gx = (unsigned)((P.n_cols + 255) / 256);
-  hipLaunchKernelGGL(nmx_kern_power_prep, dim3(gx, (unsigned)(P.have + P.n_rows)), dim3(256), 0, s, P);
+  const unsigned gy = (unsigned)((P.n_cols + 255) / 256);
+  hipLaunchKernelGGL(nmx_kern_power_prep, dim3((unsigned)(P.have + P.n_rows), gy), dim3(256), 0, s, P);
   // one wave per 64 columns of one hop: the ~30 likelihood evaluations of a fit diverge little inside a wave
-  hipLaunchKernelGGL(nmx_kern_power, dim3((unsigned)((A.n_cols + 63) / 64), (unsigned)A.n_rows), dim3(64), 0, s, A);
-  hipLaunchKernelGGL(nmx_kern_power_ring, dim3(gx, (unsigned)P.n_rows), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(nmx_kern_power, dim3((unsigned)A.n_rows, (unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
+  hipLaunchKernelGGL(nmx_kern_power_ring, dim3((unsigned)P.n_rows, gy), dim3(256), 0, s, P);
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
@@ -395,6 +403,9 @@ static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t s) {
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);
+}
+static void be_launch_tap(const NmxTapArgs& A, int n_items, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_tap, dim3(n_items), dim3(256), 0, s, A);
 }
 
 #include "nmx_engine.inc"

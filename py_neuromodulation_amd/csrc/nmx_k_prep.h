@@ -8,6 +8,9 @@
 //     selection data[feature_idx] is folded into R by the host.
 //  nmx_nanmask_item: mask[w][j] = any(isnan(x[j][start_w : start_w + W]))
 //     (stream/data_processor.py:253), one wave per (window, input row).
+//  nmx_tap_item: y[w][c][0..W) = the pre-processed window the features read (the argument of
+//     NMFeature.calc_feature, features/feature_processor.py:80-82), gathered from whatever layout the last
+//     pre-processing stage left it in -- for user-registered host features (feature_processor.py:52-53).
 #pragma once
 
 #include "nmx_device.h"
@@ -193,4 +196,22 @@ NMX_DEV void nmx_nanmask_item(const NmxNanMaskArgs& A, int w, int j, float* smem
   }
   any = nmx_block_or(any, smem);
   if (NMX_TID == 0) A.mask[(long long)w * A.C_in + j] = (unsigned char)(any ? 1 : 0);
+}
+
+struct NmxTapArgs {
+  const float* x;           // last pre-processing stage's output (or the recording itself)
+  long long ch_stride, win_stride;
+  const long long* starts;  // per-window start sample or NULL
+  float* y;                 // [n_windows][C][W]
+  int C, W;
+  int clean;                // nan_to_num while copying (no stage has cleaned the samples yet)
+};
+
+NMX_DEV void nmx_tap_item(const NmxTapArgs& A, int w, int c) {
+  const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? A.starts[w] : 0);
+  float* dst = A.y + ((long long)w * A.C + c) * A.W;
+  for (int i = NMX_TID; i < A.W; i += NMX_NT) {
+    const float v = src[i];
+    dst[i] = A.clean ? nmx_clean(v) : v;
+  }
 }

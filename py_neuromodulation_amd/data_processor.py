@@ -11,6 +11,12 @@ a NaN channel becomes NaN (:297-306, substring match, reproduced as is).
 Everything up to the features is ONE launch sequence on the GPU: the channel pick and the
 re-reference matrix are folded into one [C, C_all] matrix applied on the device, notch runs per
 window on the device, features read the result from HBM/LDS.
+
+User-registered features (``add_custom_feature``, features/feature_processor.py:52-53,90-108) are
+instantiated after the built-in ones and called on the host, hop by hop, with the pre-processed window
+the device features read (``nmx_process_batch_tap``; the float64 window itself when nothing is enabled in
+``settings.preprocessing`` and every channel is picked); their keys follow the built-in columns in
+registration order and go through the same normaliser / NaN policy.
 """
 
 from __future__ import annotations
@@ -41,12 +47,80 @@ class _LazyNanCols:
         return cols
 
 
+class UserColumns:
+    """The user-registered features of one stream (features/feature_processor.py:52-53): instances built after the
+    built-in features with the same ``(settings, ch_names, sfreq)``, called hop by hop on the host with the
+    pre-processed window (``estimate_features``, :80-82).  ``keys`` is the orchestrator's column list: the first call
+    appends the plugin keys to it (a key that repeats an earlier one overwrites that column, ``dict.update``).
+    The plugin columns go through their own device normaliser (per-column statistics: splitting the table changes
+    nothing) in float32 like the built-in columns."""
+
+    def __init__(self, settings, ch_names, sfreq, keys: list, device: int = 0, lib=None) -> None:
+        self.settings, self.ch_names, self.sfreq, self.keys = settings, list(ch_names), sfreq, keys
+        self.device, self.lib = int(device), lib
+        self.user_keys: list[str] | None = None
+        self.cols: np.ndarray | None = None
+        self.norm = None
+        self.n_builtin = len(keys)
+        self._instantiate()
+
+    def _instantiate(self) -> None:
+        from . import user_features as registered
+
+        self.features = {name: cls(self.settings, self.ch_names, self.sfreq) for name, cls in registered.items()}
+
+    def reset(self) -> None:
+        """Fresh instances and history, like the reference's new FeatureProcessors per DataProcessor."""
+        self._instantiate()
+        if self.norm is not None:
+            self.norm.reset()
+
+    def rows(self, windows) -> np.ndarray:
+        """windows: iterable of float64 [C, W] pre-processed windows in hop order -> float64 [n, n_user]."""
+        rows = []
+        for w in windows:
+            d: dict = {}
+            for f in self.features.values():
+                d.update(f.calc_feature(w))
+            if self.user_keys is None:
+                self.user_keys = list(d)
+                col = {k: i for i, k in enumerate(self.keys)}
+                n0 = len(self.keys)
+                new = [k for k in self.user_keys if k not in col]
+                self.keys.extend(new)
+                col.update({k: n0 + i for i, k in enumerate(new)})
+                self.cols = np.array([col[k] for k in self.user_keys], dtype=np.int64)
+                st = self.settings
+                if st.postprocessing.feature_normalization:
+                    mask = None
+                    if not st.feature_normalization_settings.normalize_psd:
+                        mask = np.array(["psd" not in k for k in self.user_keys], dtype=np.uint8)
+                    self.norm = DeviceFeatureNormalizer(st, len(self.user_keys), colmask=mask, device=self.device,
+                                                        lib=self.lib)
+            if list(d) != self.user_keys:
+                raise ValueError("a user feature changed its keys between hops: "
+                                 f"{sorted(set(d) ^ set(self.user_keys))[:4]}")
+            rows.append(np.fromiter(d.values(), dtype=np.float64, count=len(d)))
+        out = np.stack(rows) if rows else np.empty((0, len(self.user_keys or [])))
+        if self.norm is not None and len(out):
+            out = self.norm.process_batch(out).astype(np.float64)
+        return out
+
+    def merge(self, builtin: np.ndarray, user: np.ndarray) -> np.ndarray:
+        out = np.empty((builtin.shape[0], len(self.keys)), np.float64)
+        out[:, :builtin.shape[1]] = builtin
+        if user.shape[0]:
+            out[:, self.cols] = user     # after the built-in values: dict.update overwrites a repeated key
+        return out
+
+
 class DataProcessor:
     def __init__(self, sfreq: float, settings, channels, coord_names=None, coord_list=None,
                  line_noise: float | None = None, path_grids=None, verbose: bool = True,
                  device: int = 0, window: int | None = None, lib=None,
                  channel_subset=None, dry_run: bool = False,
-                 resample_features_at_new_rate: bool = False, local_inputs: bool = False) -> None:
+                 resample_features_at_new_rate: bool = False, local_inputs: bool = False,
+                 staging_slot: int = 0) -> None:
         self.settings = NMSettings.load(settings)
         self.channels = chmod.load_channels(channels)
         self.sfreq_features = self.settings.sampling_rate_features_hz
@@ -150,19 +224,27 @@ class DataProcessor:
         if resample_to is None:
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, window=window, lib=lib, dry_run=dry_run,
-                                        pre_taps=pre_taps, raw_norm=raw_norm)
+                                        pre_taps=pre_taps, raw_norm=raw_norm, staging_slot=staging_slot)
         elif resample_features_at_new_rate:   # `window` counts RAW samples (the generator cuts raw data)
             self.engine = HotPathEngine(st, names, resample_to, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, lib=lib, dry_run=dry_run,
                                         resample_from=self.sfreq_raw, raw_window=window, pre_taps=pre_taps,
-                                        raw_norm=raw_norm)
+                                        raw_norm=raw_norm, staging_slot=staging_slot)
             self.sfreq_raw = resample_to
         else:   # the reference: windows resampled, everything designed with the raw rate
             self.engine = HotPathEngine(st, names, self.sfreq_raw, ref_matrix=full, notch_taps=notch_taps,
                                         device=device, lib=lib, dry_run=dry_run,
                                         resample_from=self.sfreq_raw, resample_to=resample_to,
-                                        raw_window=window, pre_taps=pre_taps, raw_norm=raw_norm)
-        self.keys = self.engine.keys
+                                        raw_window=window, pre_taps=pre_taps, raw_norm=raw_norm, staging_slot=staging_slot)
+        self.keys = list(self.engine.keys)
+        # user features: instantiated after the built-ins with the same arguments (feature_processor.py:45-53); a
+        # channel shard leaves them to its coordinator (they see ALL channels: sharding.MultiDeviceProcessor)
+        from . import user_features as _registered
+
+        self._user = None
+        if _registered and not dry_run and channel_subset is None:
+            self._user = UserColumns(st, names, self.sfreq_raw, self.keys, device=device, lib=lib)
+        self._user_chunk = 64                          # hops per tapped batch (bounds the [n, C, W] hand-back)
         self.feature_normalizer = None
         self.non_psd_indices = None
         self.device_normalizer = None
@@ -183,7 +265,7 @@ class DataProcessor:
                 # inside the engine's launch sequence: rows come back normalised (no second round trip)
                 self.engine.attach_normalizer(self.device_normalizer)
                 self._norm_in_engine = True
-            elif not dry_run:   # "power": no device implementation and no host fall-back (raises, naming the setting)
+            elif not dry_run:   # an unknown method name (every method of normalization.py:57-70 runs on the device): raises, naming it
                 self.feature_normalizer = FeatureNormalizer(st)
         # NaN policy: columns whose key contains the channel's new_name (substring, as the reference);
         # built on first use per channel (256 channels x 8 000 keys of substring tests cost 50 ms up front,
@@ -198,8 +280,8 @@ class DataProcessor:
         self.engine.reset_state()
         if self.device_normalizer is not None:
             self.device_normalizer.reset()
-        if self.feature_normalizer is not None:
-            self.feature_normalizer = FeatureNormalizer(self.settings)
+        if self._user is not None:
+            self._user.reset()
         self.cnt_samples = 0
 
     # ------------------------------------------------------------------------------------
@@ -221,8 +303,65 @@ class DataProcessor:
                 row[self._nan_cols[ci]] = np.nan
         return row
 
+    # -- user-registered features (features/feature_processor.py:52-53,80-82) ----------------------
+    @property
+    def user_features(self) -> dict:
+        return self._user.features if self._user is not None else {}
+
+    @property
+    def user_keys(self):
+        return self._user.user_keys if self._user is not None else None
+
+    def _user_rows(self, windows) -> np.ndarray:
+        first = self._user.user_keys is None
+        out = self._user.rows(windows)
+        if first and self._user.user_keys is not None:
+            self._nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
+        return out
+
+    def _host_windows(self, data: np.ndarray, starts) -> "list[np.ndarray]":
+        W = self.engine.W_in
+        return [np.nan_to_num(np.asarray(data[:, int(s):int(s) + W], dtype=np.float64)) for s in starts]
+
+    def _with_user_columns(self, rows: np.ndarray, user: np.ndarray) -> np.ndarray:
+        return self._user.merge(rows, user)
+
+    def process_batch_tapped(self, data: np.ndarray, starts: np.ndarray):
+        """One batch through the engine AND the windows its features read: (float32 rows -- normalised when the
+        normaliser is attached --, NaN mask, float64 [n, C, W])."""
+        eng = self.engine
+        if eng.preprocessing_is_identity:
+            o, m = eng.process_batch(data, starts, want_nan_mask=True)
+            return o, m, np.stack(self._host_windows(data, starts))
+        o, m, pre = eng.process_batch(data, starts, want_nan_mask=True, tap=True)
+        return o, m, pre.astype(np.float64)
+
+    def _process_batch_user(self, data: np.ndarray, starts: np.ndarray):
+        """Engine rows, NaN mask and the user-feature rows of the same hops; the hops go through the engine in chunks
+        of ``_user_chunk`` so that the tapped windows stay small."""
+        starts = np.asarray(starts, dtype=np.int64)
+        outs, masks, users = [], [], []
+        for i in range(0, len(starts), self._user_chunk):
+            o, m, wins = self.process_batch_tapped(data, starts[i:i + self._user_chunk])
+            outs.append(o)
+            masks.append(m)
+            users.append(self._user_rows(wins))
+        return np.concatenate(outs), np.concatenate(masks), np.concatenate(users)
+
     def process(self, data: np.ndarray) -> dict:
         start_time = time()
+        if self._user is not None:
+            data = np.asarray(data)
+            out, mask, user = self._process_batch_user(data, np.zeros(1, np.int64))
+            rows = self._finish_rows(out, mask, self._norm_in_engine)
+            row = self._with_user_columns(rows, user)[0]
+            if mask[0].any():
+                row = self._apply_nan_policy(row[None], mask)[0]
+            if self.verbose:
+                from . import logger
+
+                logger.info("Last batch took: %.3f seconds to process", time() - start_time)
+            return dict(zip(self.keys, row.tolist()))
         out, mask = self.engine.process_window(data, want_nan_mask=True)
         row = self._postprocess_row(out.astype(np.float64), mask)
         if self.verbose:
@@ -234,8 +373,17 @@ class DataProcessor:
     def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
         """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
         applied hop by hop because the normaliser is sequential)."""
+        if self._user is not None:
+            out, mask, user = self._process_batch_user(data, starts)
+            rows = self._with_user_columns(self._finish_rows(out, mask, self._norm_in_engine), user)
+            return self._apply_nan_policy(rows, mask) if mask.any() else rows
         out, mask = self.engine.process_batch(data, starts, want_nan_mask=True, staged_output=True)
         return self.postprocess_batch(out, mask, normalised=self._norm_in_engine)
+
+    def _finish_rows(self, out: np.ndarray, mask: np.ndarray, normalised: bool) -> np.ndarray:
+        """Built-in columns: normalisation (unless it ran inside the engine) and the cast to float64; the NaN policy
+        is applied by the caller once the user columns are in place."""
+        return self.postprocess_batch(out, np.zeros_like(mask), normalised=normalised)
 
     def postprocess_batch(self, out: np.ndarray, mask: np.ndarray, normalised: bool = False) -> np.ndarray:
         """Normalisation + NaN policy for engine rows ``out[n, F]`` (hop order); ``normalised``: the

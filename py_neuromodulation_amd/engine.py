@@ -75,13 +75,14 @@ def parallel_cast(dst: np.ndarray, src: np.ndarray) -> None:
 _STAGING: dict = {}
 
 
-def _staging(lib, device: int = 0) -> "_Pinned":
+def _staging(lib, device: int = 0, slot: int = 0) -> "_Pinned":
     """ONE staging pool per loaded library, shared by every engine (page-locking ~170 MB costs tens of
     milliseconds -- Stream.run builds a fresh engine per run, like the reference builds a fresh
-    DataProcessor).  Engines are not re-entrant (include/nmx.h), neither is the pool -- one pool PER DEVICE, so
-    that the engines of a multi-device stream (one host thread each) never share a staging array.  Pools are
+    DataProcessor).  Engines are not re-entrant (include/nmx.h), neither is the pool -- one pool per device AND
+    ``slot``: the engines of a multi-device stream run on one host thread each and take the slot of their part index,
+    so two parts never share a staging array even when they name the same device (``devices=[0, 0]``).  Pools are
     reference counted and cached (see ``_release_staging`` / ``release_staging``)."""
-    key = (str(lib.path), int(device))
+    key = (str(lib.path), int(device), int(slot))
     if key not in _STAGING:
         _STAGING[key] = _Pinned(lib, key)
     _STAGING[key].users += 1
@@ -155,7 +156,7 @@ class HotPathEngine:
                  window: int | None = None, dry_run: bool = False,
                  resample_from: float | None = None, raw_window: int | None = None,
                  pre_taps: Sequence[np.ndarray] | None = None,
-                 raw_norm: tuple | None = None, resample_to: float | None = None) -> None:
+                 raw_norm: tuple | None = None, resample_to: float | None = None, staging_slot: int = 0) -> None:
         """``sfreq`` is the rate every feature and filter is DESIGNED with (what the reference passes to the
         feature constructors).  ``resample_from`` = sampling rate of the incoming windows when they are
         resampled (raw_resampling, processing/resample.py:19-60): incoming windows then hold ``raw_window``
@@ -204,7 +205,7 @@ class HotPathEngine:
         self._pinned = None
         if not dry_run:
             self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
-            self._pinned = _staging(self.lib, device)
+            self._pinned = _staging(self.lib, device, staging_slot)
 
     # ------------------------------------------------------------------------------------
     def _dptr(self, arr: np.ndarray):
@@ -549,9 +550,21 @@ class HotPathEngine:
         weakref.finalize(buf, lib.lib.nmx_host_free, p.value)   # numpy keeps `buf` alive as the base of every view
         return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
+    @property
+    def preprocessing_is_identity(self) -> bool:
+        """No stage between the incoming rows and the features (no re-reference / channel pick, FIR stage,
+        resampler, raw normaliser): the features see nan_to_num(window) itself."""
+        d = self.desc
+        return not (bool(d.ref_matrix) or d.n_notch_taps or d.n_pre_filters or d.raw_norm_method
+                    or self.resample_ratio)
+
     def process_batch(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False,
-                      staged_output: bool = False, out: np.ndarray | None = None):
+                      staged_output: bool = False, out: np.ndarray | None = None, tap: bool = False):
         """data[C_in, T] host array, starts[n] window start samples -> float32[n, n_outputs].
+
+        ``tap=True`` appends float32[n, C, W] to the result: the pre-processed windows the features were computed
+        from (nmx_process_batch_tap) -- the ``data`` argument of ``NMFeature.calc_feature`` for user-registered
+        host features (features/feature_processor.py:52-53,80-82).
 
         A recording that is not contiguous float32 is cast into a page-locked staging array (first axis
         split over a few threads): the host -> device copies then run at the PCIe rate next to the kernels;
@@ -579,6 +592,12 @@ class HotPathEngine:
         else:
             out = np.empty((n, self.n_outputs), np.float32)
         mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        if tap:
+            pre = np.empty((n, self.C, self.W), np.float32)
+            self.lib.check(self.lib.lib.nmx_process_batch_tap(
+                self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
+                out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None, pre.ctypes.data))
+            return (out, mask.astype(bool), pre) if want_nan_mask else (out, pre)
         self.lib.check(self.lib.lib.nmx_process_batch(
             self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
             out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))

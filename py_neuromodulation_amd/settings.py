@@ -19,6 +19,7 @@ from __future__ import annotations
 import copy
 import json
 import math
+import weakref
 from pathlib import Path
 from typing import Any
 
@@ -136,6 +137,20 @@ class BoolSelector(_Node):
         return iter(self.__dict__.keys())
 
 
+# names registered through add_custom_feature (features/feature_processor.py:90-108): flags of the feature selector
+# that are NOT declared fields of the reference's FeatureSelector -- its get_enabled() walks model_fields only
+# (utils/types.py:135-140), so a user feature never shows up there; FeatureProcessors instantiates every registered
+# user feature unconditionally (feature_processor.py:52-53)
+_USER_FEATURE_FIELDS: set[str] = set()
+
+
+class FeatureSelector(BoolSelector):
+    """stream/settings.py:41-55 + the extra attributes add_custom_feature sets on live settings objects."""
+
+    def get_enabled(self) -> list[str]:
+        return [k for k in super().get_enabled() if k not in _USER_FEATURE_FIELDS]
+
+
 # ---- defaults of the fields the hot path reads (values: default_settings.yaml) ----------
 
 _FEATURES = ["raw_hjorth", "return_raw", "bandpass_filter", "stft", "fft", "welch",
@@ -239,13 +254,15 @@ def _build(key: str, v: Any) -> Any:
     if key == "features" and isinstance(v, dict) and set(v) <= {"mean", "median", "std", "max"}:
         return BoolSelector(**{k: bool(v.get(k, False)) for k in ("mean", "median", "std", "max")})
     if isinstance(v, dict):
-        cls = BoolSelector if key in _SELECTOR_KEYS else _Node
+        cls = FeatureSelector if key == "features" else BoolSelector if key in _SELECTOR_KEYS else _Node
         return cls(**{k: _build(k, x) for k, x in v.items()})
     return copy.deepcopy(v)
 
 
 class NMSettings(_Node):
     """Hot-path subset of the reference's ``NMSettings`` (stream/settings.py:72-299)."""
+
+    _instances: "weakref.WeakSet[NMSettings]"   # live objects: add_custom_feature flips the flag on each (settings.py:129-150)
 
     def __init__(self, **model_dict: Any) -> None:
         merged = _merge(_default_dict(), model_dict)
@@ -254,6 +271,26 @@ class NMSettings(_Node):
             self.bursts_settings.frequency_bands = [
                 f.replace(" ", "_") for f in self.bursts_settings.frequency_bands]
         self._check()
+        for name in _USER_FEATURE_FIELDS:   # stream/settings.py:129-133
+            setattr(self.features, name, True)
+        NMSettings._instances.add(self)
+
+    __hash__ = object.__hash__   # identity: the WeakSet of live instances
+
+    @classmethod
+    def _add_feature(cls, feature: str) -> None:
+        """stream/settings.py:140-143."""
+        _USER_FEATURE_FIELDS.add(feature)
+        for inst in list(cls._instances):
+            setattr(inst.features, feature, True)
+
+    @classmethod
+    def _remove_feature(cls, feature: str) -> None:
+        """stream/settings.py:145-148."""
+        _USER_FEATURE_FIELDS.discard(feature)
+        for inst in list(cls._instances):
+            if feature in inst.features:
+                delattr(inst.features, feature)
 
     # -- validation (stream/settings.py:152-201 + per-feature validators) ----------------
     def _check(self) -> None:
@@ -382,3 +419,6 @@ class NMSettings(_Node):
                 json.dump(self.to_dict(), f, indent=4)
             else:
                 f.write(text if text is not None else self.to_yaml_text())
+
+
+NMSettings._instances = weakref.WeakSet()

@@ -22,7 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import channels as chmod
-from .data_processor import DataProcessor
+from .data_processor import DataProcessor, UserColumns, _LazyNanCols
 from .generator import window_schedule
 from .settings import NMSettings
 
@@ -71,6 +71,12 @@ class ShardedStream:
             self.owned_rows = [self.feature_idx[i] for i in self.shard]
 
     def _processor(self, window, dry_run=False):
+        from . import user_features as _registered
+
+        if _registered:   # a plugin sees the window over ALL channels: only a single-process stream can call it
+            raise NotImplementedError(
+                f"user-registered features {list(_registered)} need every channel in one process: use "
+                "Stream(devices=[...]) (sharding.MultiDeviceProcessor) instead of one rank per GPU")
         return DataProcessor(self.sfreq, self.settings, self.channels, line_noise=self.line_noise, verbose=False,
                              device=self.device, window=window, lib=self._lib, channel_subset=self.shard,
                              local_inputs=self.local_input, dry_run=dry_run)
@@ -184,7 +190,7 @@ class MultiDeviceProcessor:
             shard = channel_shard(len(names), len(devices), i)
             if not len(shard):
                 continue   # more devices than channels
-            dp = DataProcessor(sfreq, self.settings, self.channels, device=dev, channel_subset=shard, **kw)
+            dp = DataProcessor(sfreq, self.settings, self.channels, device=dev, channel_subset=shard, staging_slot=i, **kw)
             self.parts.append(dp)
             self._cols.append(np.array([col[k] for k in dp.keys], dtype=np.int64))
         self.devices = devices[:len(self.parts)]
@@ -192,14 +198,33 @@ class MultiDeviceProcessor:
         self.settings_token = None
         self._norm_in_engine = all(p._norm_in_engine for p in self.parts)
         self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+        # user-registered features see ALL channels (features/feature_processor.py:52-53): the parts hand back the
+        # pre-processed windows of their channel blocks, the coordinator runs the plugins on the joined window
+        from . import user_features as _registered
+
+        self._user = None
+        if _registered:
+            self._user = UserColumns(self.settings, self.ch_names_used, self.sfreq_raw, self.keys,
+                                     device=self.devices[0], lib=lib)
+        self._user_chunk = 64
 
     @property
     def engine(self):
         return self.parts[0].engine   # window length / input shape are the same on every device
 
+    @property
+    def user_features(self) -> dict:
+        return self._user.features if self._user is not None else {}
+
+    @property
+    def user_keys(self):
+        return self._user.user_keys if self._user is not None else None
+
     def reset(self) -> None:
         for p in self.parts:
             p.reset()
+        if self._user is not None:
+            self._user.reset()
 
     def _merge(self, rows) -> np.ndarray:
         out = np.full((rows[0].shape[0], len(self.keys)), np.nan)
@@ -208,10 +233,31 @@ class MultiDeviceProcessor:
         return out
 
     def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
-        rows = list(self._pool.map(lambda p: p.process_batch(data, starts), self.parts))
-        return self._merge(rows)
+        if self._user is None:
+            rows = list(self._pool.map(lambda p: p.process_batch(data, starts), self.parts))
+            return self._merge(rows)
+        starts = np.asarray(starts, dtype=np.int64)
+        tables = []
+        for i in range(0, len(starts), self._user_chunk):
+            st_ = starts[i:i + self._user_chunk]
+            got = list(self._pool.map(lambda p: p.process_batch_tapped(data, st_), self.parts))
+            # contiguous channel blocks in device order: the joined window is the single-device one
+            user = self._user.rows(np.concatenate([w for _, _, w in got], axis=1))
+            builtin = [p.postprocess_batch(o, m, normalised=p._norm_in_engine) for p, (o, m, _) in zip(self.parts, got)]
+            table = self._merge(builtin)
+            table[:, self._user.cols] = user
+            mask = got[0][1]   # replicated input: every part saw every incoming row
+            if mask.any():     # the plugin keys follow the substring NaN policy too (stream/data_processor.py:297-306)
+                nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
+                for ci in np.where(mask.any(axis=0))[0]:
+                    table[np.ix_(mask[:, ci], nan_cols[ci])] = np.nan
+            tables.append(table)
+        return np.concatenate(tables) if tables else np.empty((0, len(self.keys)))
 
     def process(self, data: np.ndarray) -> dict:
+        if self._user is not None:
+            row = self.process_batch(np.asarray(data), np.zeros(1, np.int64))[0]
+            return dict(zip(self.keys, row.tolist()))
         parts = list(self._pool.map(lambda p: p.process(data), self.parts))
         merged = {}
         for d in parts:

@@ -67,8 +67,11 @@ class Stream:
     def _processor_token(self):
         """Everything a DataProcessor is built from: the settings / channel table AND the stream attributes the
         reference reads afresh on every run (stream/stream.py:233-242 builds a new DataProcessor per run)."""
+        from . import user_features
+
         return (self._settings_token(), repr(self.line_noise), repr(self.sfreq), bool(self._resample_new_rate),
-                int(self.device), tuple(self.devices or ()), id(self._lib))
+                int(self.device), tuple(self.devices or ()), id(self._lib),
+                tuple((k, id(v)) for k, v in user_features.items()))
 
     def _make_processor(self, window):
         if self.devices is not None and len(self.devices) > 1:
@@ -149,10 +152,9 @@ class Stream:
                     procs[w] = dp
                 else:
                     procs[w] = self._make_processor(w)
-            self.data_processor = procs[groups[0]]
-            keys = list(self.data_processor.keys)
+            self.data_processor = dp0 = procs[groups[0]]
             if len(groups) == 1:
-                rows = self.data_processor.process_batch(data, starts)
+                rows = dp0.process_batch(data, starts)
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
                 # cannot run inside the per-length engines: detach, normalise the merged rows afterwards
@@ -160,13 +162,28 @@ class Stream:
                     if p._norm_in_engine:
                         p.engine.attach_normalizer(None)
                         p._norm_in_engine = False
-                raw = np.empty((len(starts), len(keys)), dtype=np.float32)
+                raw = np.empty((len(starts), len(dp0.engine.keys)), dtype=np.float32)
                 masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
+                wins = [None] * len(starts)   # user features: the pre-processed window of every hop, hop order
                 for w, p in procs.items():
                     sel = np.where(lens == w)[0]
-                    o, m = p.engine.process_batch(data, starts[sel], want_nan_mask=True)
+                    if dp0.user_features and not p.engine.preprocessing_is_identity:
+                        o, m, pre = p.engine.process_batch(data, starts[sel], want_nan_mask=True, tap=True)
+                        for j, i in enumerate(sel):
+                            wins[i] = pre[j].astype(np.float64)
+                    else:
+                        o, m = p.engine.process_batch(data, starts[sel], want_nan_mask=True)
+                        if dp0.user_features:
+                            for i, wv in zip(sel, p._host_windows(data, starts[sel])):
+                                wins[i] = wv
                     raw[sel], masks[sel] = o, m
-                rows = self.data_processor.postprocess_batch(raw, masks)
+                if dp0.user_features:
+                    user = dp0._user_rows(wins)   # one set of instances sees every hop in order, like the reference
+                    rows = dp0._with_user_columns(dp0._finish_rows(raw, masks, False), user)
+                    rows = dp0._apply_nan_policy(rows, masks) if masks.any() else rows
+                else:
+                    rows = dp0.postprocess_batch(raw, masks)
+            keys = list(dp0.keys)   # after the first hop: user-feature keys are known once calc_feature has run
         df = pd.DataFrame(rows, columns=keys)
         df["time"] = times
         tgt = self.channels[self.channels["target"] == 1]

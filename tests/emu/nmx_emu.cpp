@@ -151,5 +151,8 @@ static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t)
   float sm[64];
   for (int it = 0; it < n_items; ++it) nmx_nanmask_item(A, it / A.C_in, it % A.C_in, sm);
 }
+static void be_launch_tap(const NmxTapArgs& A, int n_items, be_stream_t) {
+  for (int it = 0; it < n_items; ++it) nmx_tap_item(A, it / A.C, it % A.C);
+}
 
 #include "../../py_neuromodulation_amd/csrc/nmx_engine.inc"

@@ -608,6 +608,55 @@ def case_output_files():
     print("output_files", names, rows_per_file)
 
 
+def case_user_features():
+    """User-registered NMFeature plugins (features/feature_processor.py:52-53,90-108; the plugin of
+    examples/plot_2_example_add_feature.py is tests/user_plugins.ChannelMean): the reference's own Stream.run with
+    the plugins registered -- columns after the built-in ones, normalised with them, NaN policy by substring."""
+    sys.path.insert(0, str(HERE.parent))
+    import user_plugins as up
+
+    out = {}
+    # (1) the example's shape: 5 channels x 10 s of uniform noise at 1 kHz, 10 Hz features, default settings
+    #     (notch + re-reference + z-score; sharp waves / bursts / fft / welch / hjorth ... enabled)
+    nm.add_custom_feature("channel_mean", up.ChannelMean)
+    try:
+        rng = np.random.default_rng(2024)
+        data = rng.random((5, 10000))
+        s = nm.NMSettings.get_default()
+        st = nm.Stream(sfreq=1000, data=data, settings=s, sampling_rate_features_hz=10, verbose=False)
+        with tempfile.TemporaryDirectory() as td:
+            df = st.run(out_dir=td, save_csv=False)
+        out.update({"ex_data": data, "ex_settings_json": dump(st.settings), "ex_columns": np.array(list(df.columns)),
+                    "ex_values": df.to_numpy(dtype=np.float64),
+                    "ex_channels_json": json.dumps(st.channels.to_dict("list"))})
+        print("user_features example", df.shape)
+        # (2) two plugins (the second one is stateful and emits a "psd" key that the normaliser must skip), re-reference
+        #     only, z-score on, a NaN stretch in one channel
+        nm.add_custom_feature("hop_stats", up.HopStats)
+        data = synth(4, 4000, 1000, seed=77)
+        data[2, 2100:2130] = np.nan
+        s = _small_settings()
+        s.postprocessing.feature_normalization = True
+        s.feature_normalization_settings.normalization_time_s = 1
+        st, df = _run_stream(data, 1000, s)
+        out.update({"two_data": data, "two_settings_json": dump(st.settings), "two_columns": np.array(list(df.columns)),
+                    "two_values": df.to_numpy(dtype=np.float64),
+                    "two_channels_json": json.dumps(st.channels.to_dict("list"))})
+        print("user_features two plugins", df.shape)
+        # (3) no pre-processing, no normaliser: the plugins see the float64 window itself
+        s = _small_settings()
+        s.preprocessing = []
+        st, df = _run_stream(data, 1000, s)
+        out.update({"raw_settings_json": dump(st.settings), "raw_columns": np.array(list(df.columns)),
+                    "raw_values": df.to_numpy(dtype=np.float64)})
+        print("user_features no preprocessing", df.shape)
+    finally:
+        for name in ("channel_mean", "hop_stats"):
+            if name in nm.user_features:
+                nm.remove_custom_feature(name)
+    np.savez_compressed(HERE / "user_features.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -630,3 +679,4 @@ if __name__ == "__main__":
     case_notch()
     case_resample_quirk()
     case_output_files()
+    case_user_features()

@@ -1881,3 +1881,101 @@ def case_random_window_by_window(lib, seed, wide=False):
         # features: identical.  After the normaliser: within one fp32 ulp -- its float64 sums are rebuilt from the history
         # at the start of every library call and slide inside a call, so the two call shapes add in a different order
         np.testing.assert_array_max_ulp(a32[ok], b32[ok], maxulp=1)
+
+
+# ---- user-registered NMFeature plugins (features/feature_processor.py:52-53,90-108) -------------------------
+def case_user_features(lib, tags=("raw", "two", "ex")):
+    """The reference's own Stream.run with plugins registered through add_custom_feature wrote
+    tests/golden/user_features.npz; the fused orchestrator must return the same table: the plugin columns after
+    the built-in ones in registration order, normalised with them ("psd" keys skipped), NaN policy by substring.
+
+    raw: no pre-processing, no normaliser -- the plugins see the float64 window itself: 1e-12.
+    two / ex: re-reference (+ notch for ex) and a z-score.  A z-score amplifies fp32 rounding by value / spread, so
+      the composition is checked stage by stage like case_pipeline_readme_default_zscore: (1) the un-normalised
+      plugin columns of the same run against the plugins applied to the ORACLE's float64 pre-processed windows
+      (1e-5 relative + 2e-6 x the window's amplitude: a mean is conditioned by the amplitude of what it averages),
+      (2) the normalised table against the float64 oracle normaliser on the engine's own rows, (3) the reference's
+      normalised table as a sanity bound."""
+    import json
+
+    import py_neuromodulation_amd as nmx
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.stream import Stream
+    from tests import user_plugins as up
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("user_features")
+    cases = {"ex": ({"channel_mean": up.ChannelMean}, "ex_data", "ex_channels_json", 10),
+             "two": ({"channel_mean": up.ChannelMean, "hop_stats": up.HopStats}, "two_data", "two_channels_json", None),
+             "raw": ({"channel_mean": up.ChannelMean, "hop_stats": up.HopStats}, "two_data", "two_channels_json", None)}
+    for tag in tags:
+        plugins, data_key, ch_key, feat_hz = cases[tag]
+        for name, cls in plugins.items():
+            nmx.add_custom_feature(name, cls)
+        try:
+            s = settings_from_json(g[f"{tag}_settings_json"])
+            data = g[data_key]
+            ch = json.loads(str(g[ch_key]))
+            cols = [str(c) for c in g[f"{tag}_columns"]]
+            want = g[f"{tag}_values"]
+
+            def run(settings, x=None):
+                st = Stream(sfreq=1000.0, channels=ch, settings=settings, line_noise=50, lib=lib)
+                return st, st.run(data if x is None else x, save_csv=False)
+
+            st, df = run(s)
+            assert list(df.columns) == cols, f"{tag}: columns / order differ from the reference"
+            got = df.to_numpy(dtype=np.float64)
+            assert got.shape == want.shape
+            assert np.array_equal(np.isnan(got), np.isnan(want)), f"{tag}: NaN policy"
+            np.testing.assert_array_equal(got[:, -1], want[:, -1])   # time
+            n_builtin = len(st.data_processor.engine.keys)
+            user_cols = cols[n_builtin:-1]
+            assert user_cols == list(st.data_processor.user_keys)
+            starts, ends, _ = orc.window_schedule(data.shape[1], 1000.0, s.sampling_rate_features_hz,
+                                                  s.segment_length_features_ms)
+            if tag == "raw":
+                pv = parity.PipelineVerifiers(s, ch, 1000.0, data, starts, 1000, line_noise=50)
+                for r in range(len(got)):
+                    n_bad, rep, _ = parity.compare(cols[:n_builtin], got[r, :n_builtin], want[r, :n_builtin], s, 1000.0,
+                                                   500.0, 1000, verifier=pv.row(r))
+                    assert n_bad == 0, f"raw row {r}\n{rep}"
+                np.testing.assert_allclose(got[:, n_builtin:-1], want[:, n_builtin:-1], rtol=1e-12, atol=0, equal_nan=True)
+                continue
+            # (1) un-normalised plugin columns vs the plugins on the oracle's float64 pre-processed windows
+            s_raw = type(s)(**s.to_dict())
+            s_raw.postprocessing.feature_normalization = False
+            # (features are computed from nan_to_num(window) and normalised BEFORE the NaN policy blanks them,
+            # stream/data_processor.py:255,263-306: the history of the normaliser holds the values of the cleaned data)
+            st_raw, df_raw = run(s_raw, np.nan_to_num(data))
+            raw = df_raw.to_numpy(dtype=np.float64)[:, :-1]
+            dp = orc.DataProcessor(1000.0, s_raw, ch, 50)
+            insts = [cls(s_raw, dp.ch_names_used, dp.sfreq) for cls in plugins.values()]
+            for r, (a, b) in enumerate(zip(starts, ends)):
+                w = dp.preprocess(np.nan_to_num(data[:, a:b])[dp.feature_idx])
+                d: dict = {}
+                for f in insts:
+                    d.update(f.calc_feature(w))
+                assert list(d) == user_cols
+                amp = float(np.abs(w).max())
+                ok = ~np.isnan(raw[r, n_builtin:])   # NaN policy already compared above
+                np.testing.assert_allclose(raw[r, n_builtin:][ok], np.array(list(d.values()))[ok], rtol=1e-5,
+                                           atol=2e-6 * amp, err_msg=f"{tag} row {r}")
+            # (2) the normaliser on the engine's own rows ("psd" keys pass through, stream/data_processor.py:263-290)
+            keys = cols[:-1]
+            non_psd = [i for i, k in enumerate(keys) if "psd" not in k]
+            norm = orc.FeatureNormalizer(s)
+            # the plugin columns enter the device normaliser as float32, like the built-in ones: same inputs on both sides
+            raw[:, n_builtin:] = raw[:, n_builtin:].astype(np.float32)
+            want_n = raw.copy()
+            for r in range(len(raw)):
+                want_n[r, non_psd] = norm.process(raw[r, non_psd].copy())
+            fin = ~np.isnan(got[:, :-1])
+            np.testing.assert_allclose(got[:, :-1][fin], want_n[fin], rtol=1e-5, atol=2e-6, err_msg=tag)
+            # (3) the reference's normalised table
+            err = np.abs(got[1:, :-1] - want[1:, :-1])
+            assert np.nanmedian(err) < 1e-4, tag
+            assert np.nanmedian(err[:, n_builtin:]) < 1e-4, tag
+        finally:
+            for name in plugins:
+                nmx.remove_custom_feature(name)

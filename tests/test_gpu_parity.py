@@ -764,6 +764,10 @@ def test_random_settings_window_by_window_equals_batch(gpu_lib, seed):
     pc.case_random_window_by_window(gpu_lib, seed)
 
 
+def test_user_registered_features(gpu_lib):
+    pc.case_user_features(gpu_lib)
+
+
 def test_stream_output_files(gpu_lib, tmp_path):
     pc.case_stream_output_files(gpu_lib, tmp_path)
 

@@ -208,3 +208,7 @@ def test_burst_fill_walk_equals_workgroup_walk(emu_lib, monkeypatch):
     assert not np.isnan(want).any()
     for plan in ([n], [5, 1, n - 6], [30, 50]):
         np.testing.assert_array_equal(run(True, plan), want)
+
+
+def test_user_registered_features(emu_lib):
+    pc.case_user_features(emu_lib)

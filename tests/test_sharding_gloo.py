@@ -218,3 +218,82 @@ def _run_two_ranks(tmp_path, backend, port, nproc=2):
             continue
         n_bad, rep, _ = parity.compare([k for k, o in zip(keys, ok) if o], a2[r, :-1][ok], b2[r, :-1][ok], s, 1000.0, 200.0, 1000)
         assert n_bad == 0, f"row {r}\n{rep}"
+
+
+def test_multi_device_stream_runs_user_registered_features():
+    """Plugins registered with add_custom_feature see the window over ALL channels (features/feature_processor.py:52-53):
+    the parts of a multi-device stream hand back the pre-processed windows of their channel blocks, the coordinator
+    joins them -- same table as the one-plan stream, plugin columns, z-score and NaN policy included; one rank per
+    GPU (ShardedStream) cannot call them and says so."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+
+    import py_neuromodulation_amd as nmx
+    from py_neuromodulation_amd import NMSettings, _lib
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.sharding import ShardedStream
+    from py_neuromodulation_amd.stream import Stream
+    from tests import user_plugins as up
+
+    lib = _lib.NmxLibrary(ge.build_emu())
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((5, 2300)) * 20 + rng.uniform(-100, 100, (5, 1))
+    data[3, 1700:1704] = np.nan
+    nmx.add_custom_feature("channel_mean", up.ChannelMean)
+    nmx.add_custom_feature("hop_stats", up.HopStats)
+    os.environ["NMX_CAR_FAST"] = "0"
+    try:
+        s = NMSettings.get_default()
+        s.preprocessing = ["notch_filter", "re_referencing"]
+        one_st = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib)
+        one = one_st.run(save_csv=False)
+        st = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib, devices=[0, 0, 0])
+        many = st.run(save_csv=False)
+        assert list(many.columns) == list(one.columns)
+        assert [c for c in one.columns if c.startswith("channel_mean_")] == [f"channel_mean_{n}" for n in one_st.data_processor.ch_names_used]
+        a, b = many.to_numpy(float), one.to_numpy(float)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any()
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, equal_nan=True)
+        # window by window (DataProcessor.process, the reference's call shape) == the batch, stateful plugin included
+        dp = Stream(1000.0, data=data, settings=s, line_noise=50, lib=lib).data_processor
+        for r in range(3):
+            row = dp.process(data[:, r * 100:r * 100 + 1000])
+            assert list(row) == list(one.columns)[:-1]
+            np.testing.assert_allclose(np.array(list(row.values())), b[r, :-1], rtol=1e-6, atol=1e-6, equal_nan=True)
+        with pytest.raises(NotImplementedError, match="user-registered features"):
+            ShardedStream(1000.0, chmod.get_default_channels_from_data(data), s, rank=0, world_size=2, lib=lib).run(data)
+    finally:
+        del os.environ["NMX_CAR_FAST"]
+        nmx.remove_custom_feature("channel_mean")
+        nmx.remove_custom_feature("hop_stats")
+    # nothing registered any more: the plain table again
+    plain = Stream(1000.0, data=data, settings=NMSettings.get_default(), line_noise=50, lib=lib).run(save_csv=False)
+    assert not [c for c in plain.columns if "channel_mean" in c or "hops_seen" in c]
+
+
+def test_multi_device_parts_on_one_device_do_not_share_staging():
+    """two parts that name the same device shared one page-locked staging pool and wrote it from two host
+    threads.  Every part takes its own pool slot; a batch beyond the 2^18-cell staging threshold must equal the
+    one-plan stream."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+
+    from py_neuromodulation_amd import NMSettings, _lib
+    from py_neuromodulation_amd.stream import Stream
+
+    lib = _lib.NmxLibrary(ge.build_emu())
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    for f in ("fft", "welch", "stft", "raw_hjorth", "linelength"):
+        setattr(s.features, f, True)
+    s.preprocessing = []
+    s.postprocessing.feature_normalization = False
+    s.sampling_rate_features_hz = 100
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((6, 1000 + 10 * 6000)) * 10
+    one = Stream(1000.0, data=data, settings=s, lib=lib).run(save_csv=False).to_numpy(float)
+    st = Stream(1000.0, data=data, settings=s, lib=lib, devices=[0, 0])
+    assert st.data_processor.parts[0].engine._pinned is not st.data_processor.parts[1].engine._pinned
+    many = st.run(save_csv=False).to_numpy(float)
+    assert one.shape[0] * (one.shape[1] - 1) // 2 >= 1 << 18   # each part's output crosses the staging threshold
+    np.testing.assert_array_equal(many, one)
