@@ -143,6 +143,12 @@ struct NmxOsc {
   NmxCols cols, psd_cols;
   NmxFft fft;    // complex length n/2 (or n when complex_full)
   const float* win;  // [n] window (Welch: hann, STFT: hamming), NULL for FFT
+  // STFT: the segments are transformed CENTRED (x - mean of the window: fp32 rounding relative to the signal, not to
+  // its offset) and the constant's share comes back analytically: X_seg[k] += mean * wdc[sel][k], wdc[0][k] = DFT of
+  // the window (a full segment: interior or even-extended edge), wdc[1][k] = DFT of its first n - nadd samples (the
+  // zero-padded last segment of scipy's padded=True); float64 on the host, [2][nfreq] complex
+  const float2* wdc;
+  int nadd;          // STFT: zeros appended to the extended signal (the tail of the last segment)
 };
 
 struct NmxTimeOscArgs {

@@ -207,17 +207,23 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
   if (A.fft.enabled) {
     const NmxOsc& O = A.fft;
     const int N = O.n, off = W - N;
+    // the transform runs on x - mean: a constant only reaches bin 0 (X[0] = sum x), and without the offset the fp32
+    // rounding of the transform is relative to the signal, not to its DC level
+    float sm = 0.f;
+    for (int i = NMX_TID; i < N; i += NMX_NT) sm += xs[off + i];
+    const float xsum = nmx_block_sum(sm, red), mean = xsum / (float)N;
     NMX_SYNC();
     if (O.complex_full) {
-      for (int i = NMX_TID; i < N; i += NMX_NT) bufB[i] = make_float2(xs[off + i], 0.f);
+      for (int i = NMX_TID; i < N; i += NMX_NT) bufB[i] = make_float2(xs[off + i] - mean, 0.f);
     } else {
       for (int i = NMX_TID; i < N / 2; i += NMX_NT)
-        bufB[i] = make_float2(xs[off + 2 * i], xs[off + 2 * i + 1]);
+        bufB[i] = make_float2(xs[off + 2 * i] - mean, xs[off + 2 * i + 1] - mean);
     }
     NMX_SYNC();
     const float2* Z = nmx_osc_fft(O, bufA, bufB);
     for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
-      const float2 X = nmx_osc_bin(O, Z, k);
+      float2 X = nmx_osc_bin(O, Z, k);
+      if (k == 0) X = make_float2(xsum, 0.f);
       float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y);
       if (O.log_transform) v = nmx_log10_fast(v);
       spec[k - O.k_lo] = v;
@@ -275,11 +281,22 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
   if (A.stft.enabled) {
     const NmxOsc& O = A.stft;
     const int N = O.n, h = O.half;
+    // CENTRED segments (x - mean of the window; the zero padding stays zero); the constant's share of a segment's
+    // spectrum is added back from the plan's float64 table (NmxOsc::wdc): fp32 rounding relative to the signal
+    float smw = 0.f;
+    for (int i = NMX_TID; i < W; i += NMX_NT) smw += xs[i];
+    const float mean = nmx_block_sum(smw, red) / (float)W;
+    NMX_SYNC();
     auto xe = [&](int e) -> float {  // even extension by h, zero padding beyond
-      if (e < h) return xs[h - e];
-      if (e < h + W) return xs[e - h];
-      if (e < 2 * h + W) return xs[W - 2 - (e - h - W)];
+      if (e < h) return xs[h - e] - mean;
+      if (e < h + W) return xs[e - h] - mean;
+      if (e < 2 * h + W) return xs[W - 2 - (e - h - W)] - mean;
       return 0.f;
+    };
+    const int seg_padded = O.nadd ? O.nseg - 1 : -1;
+    auto with_dc = [&](float2 X, int sgi, int k) -> float2 {
+      const float2 t = O.wdc[(sgi == seg_padded ? O.nfreq : 0) + k];
+      return make_float2(X.x + mean * t.x, X.y + mean * t.y);
     };
     int sg_first = 0;
 #ifndef NMX_HOST_EMU
@@ -298,7 +315,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
         NMX_WAVE_FENCE();
         const float2* Z = nmx_fft4_wave<-1, 250, 5, 5, 5, 2>(wB, wA, wB, O.fft.tw);
         for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
-          const float2 X = nmx_rfft_bin(Z, O.fft.twr, 250, k);
+          const float2 X = with_dc(nmx_rfft_bin(Z, O.fft.twr, 250, k), sgi, k);
           float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y) * O.scale;
           if (O.log_transform) v = nmx_log10_fast(v);
           spec[(k - O.k_lo) * O.nseg + sgi] = v;
@@ -329,6 +346,8 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
           re += v * cs;
           im += v * sn;
         }
+        const float2 Xd = with_dc(make_float2(re, im), sgi, k);
+        re = Xd.x; im = Xd.y;
         float v = nmx_sqrt_fast(re * re + im * im) * O.scale;
         if (O.log_transform) v = nmx_log10_fast(v);
         spec[(k - O.k_lo) * O.nseg + sgi] = v;
@@ -347,7 +366,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       NMX_SYNC();
       const float2* Z = nmx_osc_fft(O, bufA, bufB);
       for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
-        const float2 X = nmx_osc_bin(O, Z, k);
+        const float2 X = with_dc(nmx_osc_bin(O, Z, k), sgi, k);
         float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y) * O.scale;
         if (O.log_transform) v = nmx_log10_fast(v);
         spec[(k - O.k_lo) * O.nseg + sgi] = v;

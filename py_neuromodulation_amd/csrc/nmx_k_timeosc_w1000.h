@@ -144,10 +144,11 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     const bool fast = nmx_td_emit<1000, (!LOW || SPEC != 0), (SPEC & NMX_TOW_FEATS)>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
     wsum = Rt.sum;
     if (fast) {
-      if (stft_on) {   // park the window in LDS (group 3: lanes 0..57)
+      if (stft_on) {   // park the CENTRED window in LDS (group 3: lanes 0..57); see the STFT block below
+        const float mean = wsum * (1.f / 1000.f);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = Rt.x[k];
+          if (k < 3 || lane < 58) ((nmx_f4*)xs)[lane + 64 * k] = Rt.x[k] - mean;
       }
     } else {
       // a NaN or an infinity in the window: cleaning loads and the scalar formulation (nmx_k_scan.h)
@@ -156,7 +157,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       R.sum = 0.f;
       if (td) {
         nmx_scan_emit(A, w, c, R);
-      } else if (spec1000) {
+      } else if (spec1000 || stft_on) {
         float p0 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) p0 += (R.x[k][0] + R.x[k][1]) + (R.x[k][2] + R.x[k][3]);   // out-of-range samples are 0
@@ -167,7 +168,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < 3 || lane < 58) {
-          if (stft_on) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};
+          if (stft_on) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
           if (spec1000) ((nmx_f4*)fb)[lane + 64 * k] = nmx_f4{R.x[k][0] - mean, R.x[k][1] - mean, R.x[k][2] - mean, R.x[k][3] - mean};
         }
     }
@@ -252,8 +253,14 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
            pf_acc[0], pf_acc[1], pf_acc[2], pf_acc[3]);
 #endif
   // ---- STFT: segments 0..4 at extended positions 250 s .. 250 s + 499 (even extension by 250) -------
+  // The segments are cut from the CENTRED window (xs holds x - mean): a hamming-weighted +-500 offset in every fp32
+  // product and butterfly put the rounding of these bins at 1e-7 of the OFFSET (2 % of the entries of the headline
+  // workload missed 1e-5 relative, the FFT / Welch features on their centred transform none).  What the constant
+  // contributes to a segment's spectrum is known exactly: mean * DFT(window), NmxOsc::wdc -- for the periodic hamming
+  // window 0.54 n at bin 0, -0.23 n at bin 1, nothing elsewhere -- and is added to the bins that read it.
   if (stft_on) {
     const NmxOsc& O = A.stft;
+    const float mean = wsum * (1.f / 1000.f);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)O.win, 0, 2000, 0x00020000);
     float hw[8];
 #pragma unroll
@@ -279,8 +286,13 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
         const nmx_c2 zk = Z[k == 500 ? 0 : k], zn = Z[k == 0 ? 0 : 500 - k];
         // A = (zk + conj zn) / 2,  B = -i (zk - conj zn) / 2
-        const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
-        const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+        float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
+        float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+        if (k < 2) {   // (all five segments are full: wdc[0]; real for the symmetric window up to the table's rounding)
+          const float2 t = O.wdc[k];
+          ax += mean * t.x; ay += mean * t.y;
+          bx += mean * t.x; by += mean * t.y;
+        }
         const float pa = ax * ax + ay * ay;
         const float va = O.log_transform ? nmx_log10_half_fast(pa) + lscale : sqrtf(pa) * O.scale;
         acc.add(O, nb, k, va);
@@ -323,13 +335,24 @@ NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, flo
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? nmx_uniform_ll(A.starts[w]) : 0ll);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4 * W, 0x00020000);
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  nmx_f4 xv[8];
+  float psum = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    xv[k] = nmx_f4{0.f, 0.f, 0.f, 0.f};
     if (256 * k >= W) break;
     const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane + 1024 * k, 0, 0);
     nmx_f4 v = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
     if (A.clean_on_load) { v.x = nmx_clean_bl(v.x); v.y = nmx_clean_bl(v.y); v.z = nmx_clean_bl(v.z); v.w = nmx_clean_bl(v.w); }
-    if (4 * (lane + 64 * k) < W) ((nmx_f4*)xs)[lane + 64 * k] = v;
+    xv[k] = v;
+    psum += (v.x + v.y) + (v.z + v.w);   // (samples beyond the row are 0: hardware range check)
+  }
+  // centred window (see nmx_timeosc_w1000_body: STFT)
+  const float mean = nmx_wave_reduce(psum, 0.f, [](float a_, float b_) { return a_ + b_; }) / (float)W;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (256 * k >= W) break;
+    if (4 * (lane + 64 * k) < W) ((nmx_f4*)xs)[lane + 64 * k] = xv[k] - mean;
   }
   NmxW500TwReg T;
   T.load(A.w500_tab, lane);
@@ -358,8 +381,14 @@ NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, flo
     const nmx_c2* Z = O.k_hi <= 100 ? nmx_w500_fft_fwd_low(fb, fa, fb, T, lane, O.k_hi) : nmx_w500_fft<-1>(fb, fa, fb, T, lane);
     for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
       const nmx_c2 zk = Z[k == 500 ? 0 : k], zn = Z[k == 0 ? 0 : 500 - k];
-      const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
-      const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+      float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y);
+      float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+      {   // the constant's share (the last segment may end in scipy's zero padding: second table)
+        const float2 ta = O.wdc[((O.nadd && sa == O.nseg - 1) ? O.nfreq : 0) + k];
+        const float2 tb = O.wdc[((O.nadd && sa + 1 == O.nseg - 1) ? O.nfreq : 0) + k];
+        ax += mean * ta.x; ay += mean * ta.y;
+        bx += mean * tb.x; by += mean * tb.y;
+      }
       const float pa = ax * ax + ay * ay;
       acc.add(O, nb, k, O.log_transform ? nmx_log10_half_fast(pa) + lscale : sqrtf(pa) * O.scale);
       if (two) {
