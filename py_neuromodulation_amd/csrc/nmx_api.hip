@@ -277,11 +277,13 @@ extern "C" int nmx_w64q_launch_notch_rd64(const NmxBankW64Args*, int, hipStream_
 extern "C" int nmx_w64x2_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64c_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" int nmx_w64d_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
+extern "C" int nmx_w64e_launch_rd64(const NmxBankW64Args*, int, int, hipStream_t);
 extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, size_t lds, const unsigned char* todo,
                                            hipStream_t s);
 // One-wave FIR kernels (nmx_w64.hip), one kernel per shape class:
 //   M = 4096 (windows + filter half-length in (2048, 4096])            nmx_kern_bank_w64x2
 //   channel pairs, M = 1536 / 1024 (every filter that fits)            nmx_kern_bank_w64c / w64d
+//   channel pairs, M = 2048 (longer filters; the notch)                nmx_kern_bank_w64e<0 / 1>
 //   M = 2048, >= 4096 items: persistent 8-wave workgroups, pipelined   nmx_kern_bank_w64pp
 //   notch (odd-reflected window), >= 1024 items: four items / workgroup nmx_kern_notch_w64q
 //   a window or two (nmx_process_window): one wave per workgroup        nmx_kern_bank_w64 / nmx_kern_notch_w64
@@ -298,7 +300,9 @@ static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
     if (!nmx_w64x2_launch_rd64(&A, n_items, n_cu, s)) g_be_rc = nmx_fail(NMX_E_INVALID, "M = 4096 FIR path: LDS budget");
     return;
   }
-  if (A.hc && (A.pair_m == 1024 ? nmx_w64d_launch_rd64(&A, n_items, n_cu, s) : nmx_w64c_launch_rd64(&A, n_items, n_cu, s))) return;
+  if (A.hc && A.pair_m == 2048) {
+    if (nmx_w64e_launch_rd64(&A, n_items, n_cu, s)) return;   // else: the one-channel M = 2048 kernels below
+  } else if (A.hc && (A.pair_m == 1024 ? nmx_w64d_launch_rd64(&A, n_items, n_cu, s) : nmx_w64c_launch_rd64(&A, n_items, n_cu, s))) return;
   if (n_items >= 4096 && nmx_w64p_launch_rd64(&A, n_items, n_cu, s)) return;
   if (A.b.pad_mode != 0 && n_items >= 1024 && nmx_w64q_launch_notch_rd64(&A, n_items, s)) return;
   nmx_w64_launch_rd64(&A, n_items, lds, s);

@@ -248,6 +248,69 @@ NMX_DEV void nmx_w64c_lane_setup(NmxW64cLane& Ln, const float* tile, const float
   for (int q = 0; q < 8; ++q) Ln.twb[q] = tb[8 * q];
 }
 
+// ---- epilogue of one filter of a channel-pair item (shared with the M = 2048 pair kernel, nmx_k_bank_w64e.h):
+// v[j] = (y_c, y_{c+1})[l + 64 j], j < 16.  Band-pass activity = variance of the tail [W - seglen, W) of both channels at
+// once (re / im); filtered series to HBM as lane-consecutive 4-byte stores, one row per channel.
+NMX_DEV void nmx_w64c_epilogue(const NmxBankW64Args& AA, const NmxFilterDev& F, const nmx_c2* v, int w, int c, int l, bool two,
+                               float* out_row) {
+  const NmxBankArgs& A = AA.b;
+  const int W = A.W;
+  // ---- band-pass activity: variance of the tail [W - seglen, W), both channels at once (re / im) ------------------
+  if (F.bp_seglen > 0) {
+    const unsigned span = (unsigned)F.bp_seglen;
+    const int s_l = l - (W - F.bp_seglen);
+    nmx_c2 acc = nmx_mk2(0.f, 0.f), acc2 = nmx_mk2(0.f, 0.f);
+    NMX_UNROLL
+    for (int j = 0; j < 16; ++j) {
+      const float mk = (unsigned)(s_l + 64 * j) < span ? 1.f : 0.f;
+      const nmx_c2 val = v[j] * mk;
+      acc = acc + val;
+      acc2 = nmx_c2_fma(val, val, acc2);
+    }
+    const float inv_n = 1.f / (float)F.bp_seglen;
+    float t1 = nmx_wave_reduce(acc.x, 0.f, [](float a_, float b_) { return a_ + b_; });
+    float t2 = nmx_wave_reduce(acc.y, 0.f, [](float a_, float b_) { return a_ + b_; });
+    const float q1 = nmx_wave_reduce(acc2.x, 0.f, [](float a_, float b_) { return a_ + b_; });
+    const float q2 = nmx_wave_reduce(acc2.y, 0.f, [](float a_, float b_) { return a_ + b_; });
+    const float mean1 = t1 * inv_n, mean2 = t2 * inv_n;
+    t1 = q1 - mean1 * t1;   // sum (y - mean)^2 = sum y^2 - mean sum y
+    t2 = q2 - mean2 * t2;
+    if (mean1 * mean1 * (float)F.bp_seglen > 4.f * t1 || mean2 * mean2 * (float)F.bp_seglen > 4.f * t2) {
+      // wave-uniform, rare (a short tail of a slow band is almost a constant): mean-shifted like np.var
+      nmx_c2 a2 = nmx_mk2(0.f, 0.f);
+      const nmx_c2 mm = nmx_mk2(mean1, mean2);
+      NMX_UNROLL
+      for (int j = 0; j < 16; ++j) {
+        const float mk = (unsigned)(s_l + 64 * j) < span ? 1.f : 0.f;
+        const nmx_c2 d = (v[j] - mm) * mk;
+        a2 = nmx_c2_fma(d, d, a2);
+      }
+      t1 = nmx_wave_reduce(a2.x, 0.f, [](float a_, float b_) { return a_ + b_; });
+      t2 = nmx_wave_reduce(a2.y, 0.f, [](float a_, float b_) { return a_ + b_; });
+    }
+    if (l < 2 && (l == 0 || two)) {
+      const float act = (l == 0 ? t1 : t2) * inv_n;
+      const int col = A.bp_cols.base + (c + l) * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
+      out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u);
+    }
+  }
+  // ---- filtered series to HBM: lane-consecutive 4-byte stores, one row per channel ---------------------------------
+  float* dsw = F.sw_index >= 0 ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
+  float* dyb = F.burst_index >= 0 ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
+  for (int dst = 0; dst < 2; ++dst) {
+    float* d = dst ? dyb : dsw;
+    if (!d) continue;
+    const long long next = (long long)(dst ? A.n_burst_bands : A.n_sw_filters) * W;   // the same band of channel c + 1
+    const nmx_rsrc s1 = nmx_make_rsrc(d, 4 * W);
+    const nmx_rsrc s2 = nmx_make_rsrc(d + next, two ? 4 * W : 0);
+    NMX_UNROLL
+    for (int j = 0; j < 16; ++j) {
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].x), s1, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].y), s2, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
+    }
+  }
+}
+
 // one item: window w, channels c and c + 1 (c even; c + 1 == n_channels: the second half is zeros)
 NMX_DEV void nmx_bank_w64c_item(const NmxBankW64Args& AA, int w, int c, const NmxW64cLane& Ln, const float* htab) {
   w = nmx_uniform_i(w);
@@ -318,61 +381,7 @@ NMX_DEV void nmx_bank_w64c_item(const NmxBankW64Args& AA, int w, int c, const Nm
     for (int j = 0; j < 16; ++j) v[j] = v[j] * unscale;
     NMX_PROF(3)
 
-    // ---- band-pass activity: variance of the tail [W - seglen, W), both channels at once (re / im) ------------------
-    if (F.bp_seglen > 0) {
-      const unsigned span = (unsigned)F.bp_seglen;
-      const int s_l = l - (W - F.bp_seglen);
-      nmx_c2 acc = nmx_mk2(0.f, 0.f), acc2 = nmx_mk2(0.f, 0.f);
-      NMX_UNROLL
-      for (int j = 0; j < 16; ++j) {
-        const float mk = (unsigned)(s_l + 64 * j) < span ? 1.f : 0.f;
-        const nmx_c2 val = v[j] * mk;
-        acc = acc + val;
-        acc2 = nmx_c2_fma(val, val, acc2);
-      }
-      const float inv_n = 1.f / (float)F.bp_seglen;
-      float t1 = nmx_wave_reduce(acc.x, 0.f, [](float a_, float b_) { return a_ + b_; });
-      float t2 = nmx_wave_reduce(acc.y, 0.f, [](float a_, float b_) { return a_ + b_; });
-      const float q1 = nmx_wave_reduce(acc2.x, 0.f, [](float a_, float b_) { return a_ + b_; });
-      const float q2 = nmx_wave_reduce(acc2.y, 0.f, [](float a_, float b_) { return a_ + b_; });
-      const float mean1 = t1 * inv_n, mean2 = t2 * inv_n;
-      t1 = q1 - mean1 * t1;   // sum (y - mean)^2 = sum y^2 - mean sum y
-      t2 = q2 - mean2 * t2;
-      if (mean1 * mean1 * (float)F.bp_seglen > 4.f * t1 || mean2 * mean2 * (float)F.bp_seglen > 4.f * t2) {
-        // wave-uniform, rare (a short tail of a slow band is almost a constant): mean-shifted like np.var
-        nmx_c2 a2 = nmx_mk2(0.f, 0.f);
-        const nmx_c2 mm = nmx_mk2(mean1, mean2);
-        NMX_UNROLL
-        for (int j = 0; j < 16; ++j) {
-          const float mk = (unsigned)(s_l + 64 * j) < span ? 1.f : 0.f;
-          const nmx_c2 d = (v[j] - mm) * mk;
-          a2 = nmx_c2_fma(d, d, a2);
-        }
-        t1 = nmx_wave_reduce(a2.x, 0.f, [](float a_, float b_) { return a_ + b_; });
-        t2 = nmx_wave_reduce(a2.y, 0.f, [](float a_, float b_) { return a_ + b_; });
-      }
-      if (l < 2 && (l == 0 || two)) {
-        const float act = (l == 0 ? t1 : t2) * inv_n;
-        const int col = A.bp_cols.base + (c + l) * A.bp_cols.ch_stride + F.bp_band * A.bp_cols.a_stride;
-        out_row[col] = nmx_bp_activity(A.bp_log ? log10f(act) : act, (A.bp_kalman_mask >> F.bp_band) & 1u);
-      }
-    }
-    NMX_PROF(4)
-    // ---- filtered series to HBM: lane-consecutive 4-byte stores, one row per channel ---------------------------------
-    float* dsw = F.sw_index >= 0 ? A.sw_out + (((long long)w * A.n_channels + c) * A.n_sw_filters + F.sw_index) * W : nullptr;
-    float* dyb = F.burst_index >= 0 ? AA.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr;
-    for (int dst = 0; dst < 2; ++dst) {
-      float* d = dst ? dyb : dsw;
-      if (!d) continue;
-      const long long next = (long long)(dst ? A.n_burst_bands : A.n_sw_filters) * W;   // the same band of channel c + 1
-      const nmx_rsrc s1 = nmx_make_rsrc(d, 4 * W);
-      const nmx_rsrc s2 = nmx_make_rsrc(d + next, two ? 4 * W : 0);
-      NMX_UNROLL
-      for (int j = 0; j < 16; ++j) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].x), s1, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].y), s2, 4 * l + 256 * j, 0, NMX_SERIES_STORE_AUX);
-      }
-    }
+    nmx_w64c_epilogue(AA, F, v, w, c, l, two, out_row);
     NMX_PROF(5)
   }
 #if defined(NMX_BANK_PROFILE)

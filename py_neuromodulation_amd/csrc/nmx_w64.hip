@@ -11,6 +11,7 @@
 #include "nmx_k_bank_w64x2.h"
 #include "nmx_k_bank_w64c.h"
 #include "nmx_k_bank_w64d.h"
+#include "nmx_k_bank_w64e.h"
 
 #if !defined(NMX_W64_NAME) || !defined(NMX_LDS_ASM)
 #error "compile with -DNMX_W64_NAME=rd64 -DNMX_LDS_ASM=1"
@@ -254,6 +255,77 @@ extern "C" int NMX_CAT(nmx_w64d_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   } else {
     hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64d_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk, x_floats);
     NMX_KNAME("nmx_kern_bank_w64d_", "<0>");
+  }
+  return 1;
+}
+
+// M = 2048, one wave per (window, channel pair) (nmx_k_bank_w64e.h): PAD = 0 the "same" FIR bank of the filters the
+// M = 1536 kernel cannot take, PAD = 1 the notch (odd-reflected window, one filter, the window back to HBM).  LDS = the
+// real spectra of the filters, the pass-A twiddles, one 18 KiB exchange tile per wave; contiguous runs of hops per wave.
+template <int PAD, int WC = 0, int HC = 0>
+__global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)(const NmxBankW64Args A0, int n_windows,
+                                                                                   int n_pairs, int chunk) {
+  // (kernel-argument pointer laundered once per item: the plan is re-read with s_load, not hoisted into scalar
+  // registers that spill to lanes of a VGPR)
+  typedef const NmxBankW64Args __attribute__((address_space(4)))* nmx_karg_p;
+  nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+  float* tab = nmx_smem_w64;
+  const int hf = ((const NmxBankW64Args*)Ap)->b.n_filters * NMX_W64E_H_FLOATS;
+  NmxW64cLane Ln;
+  unsigned rt[16];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  {
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    for (int i = threadIdx.x; i < hf; i += blockDim.x) tab[i] = A.hc[i];
+    for (int i = threadIdx.x; i < NMX_W64E_TWA_FLOATS; i += blockDim.x) tab[hf + i] = A.twc[i];
+    nmx_w64c_lane_setup(Ln, tab + hf + NMX_W64E_TWA_FLOATS + wave * NMX_W64E_TILE_FLOATS, tab + hf,
+                        A.twc + NMX_W64E_TWA_FLOATS, (int)(threadIdx.x & 63));
+    if (PAD && !WC) nmx_w64e_reflect_lane(A.b, (int)(threadIdx.x & 63), rt);
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * nw + wave) * chunk;
+  const int q1 = q0 + chunk < n_pairs ? q0 + chunk : n_pairs;
+#pragma nounroll
+  for (int q = q0; q < q1; ++q) {
+    asm volatile("" : "+s"(Ap));
+    const NmxBankW64Args& A = *(const NmxBankW64Args*)Ap;
+    const int cp = q / n_windows;
+    nmx_bank_w64e_item<PAD, WC, HC>(A, q - cp * n_windows, 2 * cp, Ln, tab, rt);
+  }
+}
+
+// returns 0 when the configuration does not fit (caller falls back to the one-channel M = 2048 kernels)
+extern "C" int NMX_CAT(nmx_w64e_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
+  const bool pad = A->b.pad_mode != 0;
+  if (A->b.W > 1024 || (A->b.bp_features & 6u) || !A->hc || !A->twc || A->b.n_filters < 1) return 0;
+  if (pad && (A->b.n_filters != 1 || A->b.W + 2 * A->b.pad_half > NMX_W64E_M)) return 0;
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<1, 1000, 499>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int C = A->b.n_channels, n_windows = n_items / C, n_pairs = n_windows * ((C + 1) / 2);
+  const int fixed = A->b.n_filters * NMX_W64E_H_FLOATS + NMX_W64E_TWA_FLOATS;
+  int nw = (160 * 1024 / 4 - fixed) / NMX_W64E_TILE_FLOATS;
+  if (nw < 4) return 0;
+  static int want = 0;
+  if (!want) { const char* v = getenv("NMX_W64E_WAVES"); want = (v && atoi(v) >= 1 && atoi(v) <= 8) ? atoi(v) : 8; }
+  if (nw > want) nw = want;
+  if (n_pairs < 2048) nw = 2;   // a hop or two: spread the few items over many CUs
+  const size_t lds = (size_t)(fixed + nw * NMX_W64E_TILE_FLOATS) * 4;
+  int grid = n_cu > 0 ? n_cu : 256;
+  if (grid * nw > n_pairs) grid = (n_pairs + nw - 1) / nw;
+  const int chunk = (n_pairs + grid * nw - 1) / (grid * nw);
+  if (pad && A->b.W == 1000 && A->b.pad_half == 499 && A->b.n_edge >= 499) {   // the default notch: 1 kHz x 1 s windows, 999 taps
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<1, 1000, 499>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk);
+    NMX_KNAME("nmx_kern_bank_w64e_", "<1, 1000, 499>");
+  } else if (pad) {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<1>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk);
+    NMX_KNAME("nmx_kern_bank_w64e_", "<1>");
+  } else {
+    hipLaunchKernelGGL((NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_NAME)<0>), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk);
+    NMX_KNAME("nmx_kern_bank_w64e_", "<0>");
   }
   return 1;
 }

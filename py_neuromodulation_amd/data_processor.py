@@ -377,6 +377,10 @@ class DataProcessor:
             out, mask, user = self._process_batch_user(data, starts)
             rows = self._with_user_columns(self._finish_rows(out, mask, self._norm_in_engine), user)
             return self._apply_nan_policy(rows, mask) if mask.any() else rows
+        if self.feature_normalizer is None and (self.device_normalizer is None or self._norm_in_engine):
+            # nothing left to do on the host but the NaN policy: conversions pipelined against the device
+            rows, mask = self.engine.process_batch_f64(data, starts, want_nan_mask=True)
+            return self._apply_nan_policy(rows, mask) if mask.any() else rows
         out, mask = self.engine.process_batch(data, starts, want_nan_mask=True, staged_output=True)
         return self.postprocess_batch(out, mask, normalised=self._norm_in_engine)
 

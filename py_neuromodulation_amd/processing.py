@@ -144,9 +144,9 @@ class Resampler:
 
 class FeatureNormalizer:
     """processing/normalization.py:119-122, the reference's call shape (one feature vector per call) ON THE DEVICE:
-    a ``DeviceFeatureNormalizer`` created at the first call, when the vector length is known.  There is no host
-    implementation: "power" (scikit-learn's PowerTransformer: Yeo-Johnson with a likelihood fit inside scipy.stats)
-    raises ``NotImplementedError``."""
+    a ``DeviceFeatureNormalizer`` created at the first call, when the vector length is known.  Every method of
+    normalization.py:57-70 runs there ("power" included: nmx_k_power.h); there is no host implementation, and an
+    unknown method name raises ``NotImplementedError``."""
 
     def __init__(self, settings) -> None:
         method = settings.feature_normalization_settings.normalization_method

@@ -136,7 +136,7 @@ class Stream:
         rows = np.empty((len(starts), 0))
         keys: list[str] = []
         if len(starts):
-            groups = sorted(set(int(x) for x in lens))
+            groups = [int(g) for g in np.unique(lens)]
             if len(groups) > 1 and "bursts" in st.features.get_enabled():
                 raise NotImplementedError("bursts with a non-integer hop (ragged windows) is not supported")
             if len(groups) > 1 and self.devices is not None and len(self.devices) > 1:
