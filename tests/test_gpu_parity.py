@@ -517,9 +517,9 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
 
     check("default", default)
     # the code paths a SHAPE can select that this shape does not reach by itself: every filter on the M = 2048
-    # one-channel kernel, the generic sharp-wave / time-oscillatory / threshold-walk kernels, the schedules, a
+    # channel-pair / one-channel kernels, the one-channel notch, the generic sharp-wave / time-oscillatory / threshold-walk kernels, the schedules, a
     # chunk boundary every 9 hops
-    for knobs in ({"NMX_BANK_W64C": "0"}, {"NMX_SW_DENSE": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
+    for knobs in ({"NMX_BANK_W64C": "0"}, {"NMX_BANK_W64E": "0"}, {"NMX_BANK_W64C": "0", "NMX_BANK_W64E": "0"}, {"NMX_SW_DENSE": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
                   {"NMX_OVERLAP": "2"}, {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_TIMEOSC_W1000": "0"},
                   {"NMX_TOW_PERSISTENT": "0"}, {"NMX_CHUNK_WINDOWS": "9"}):
         for knob, val in knobs.items():

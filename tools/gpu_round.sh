@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O
 if [[ $STEPS == *all* || $STEPS == *test* ]]; then
-  NMX_WRITE_MISS_TOTALS=$O/${TAG}_accepted_misses.json timeout 1200 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu.log 2>&1; tail -3 $O/${TAG}_pytest_gpu.log
+  NMX_WRITE_MISS_TOTALS=$O/${TAG}_accepted_misses.json timeout 600 python -X faulthandler -m pytest tests -m gpu -q -o faulthandler_timeout=240 > $O/${TAG}_pytest_gpu.log 2>&1; tail -3 $O/${TAG}_pytest_gpu.log
   cat $O/${TAG}_accepted_misses.json
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log
 fi
