@@ -126,3 +126,12 @@ def reref_structure(full: np.ndarray, max_taps: int = 4):
         g.append(index[key])
         b.append(o)
     return taps, np.asarray(g, dtype=np.int64), np.asarray(b, dtype=np.float64), groups
+
+
+def split_hi_lo(v: np.ndarray) -> np.ndarray:
+    """float64 [T] -> float32 [2, T]: hi = float32(v), lo = float32(v - hi); hi + lo carries ~48 bits of v.  The group
+    sums of a channel shard travel this way (sharding.py): a float32 sum of 256 channels with +-500 offsets would add a
+    rounding step the single-device kernel does not have."""
+    v = np.asarray(v, np.float64)
+    hi = v.astype(np.float32)
+    return np.stack([hi, (v - hi.astype(np.float64)).astype(np.float32)])

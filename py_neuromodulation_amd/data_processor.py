@@ -190,7 +190,7 @@ class DataProcessor:
         # picked channels but its re-reference rows still read ALL input rows
         self.all_ch_names_used = list(self.ch_names_used)
         names = self.ch_names_used
-        self.local_rows = None      # local_inputs: the input rows this processor expects, then the group sums
+        self.local_rows = None      # local_inputs: the input rows this processor expects, then hi / lo rows of the group sums
         self.local_groups = []      # local_inputs: member rows (global) of every group sum it expects
         if channel_subset is not None:
             subset = list(channel_subset)
@@ -211,13 +211,17 @@ class DataProcessor:
                 rows = sorted({j for t in taps for j, _ in t})
                 pos = {j: i for i, j in enumerate(rows)}
                 used_groups = sorted({int(k) for k in gi if k >= 0})
-                gpos = {k: len(rows) + i for i, k in enumerate(used_groups)}
-                loc = np.zeros((len(subset), len(rows) + len(used_groups)))
+                # a group sum arrives as TWO float32 rows, hi + lo of the float64 sum (channels.split_hi_lo): the
+                # device accumulates coefficient x row in float64, so the re-referenced sample is rounded to float32
+                # once, as in the single-device kernel that forms the sum itself
+                gpos = {k: len(rows) + 2 * i for i, k in enumerate(used_groups)}
+                loc = np.zeros((len(subset), len(rows) + 2 * len(used_groups)))
                 for r, t in enumerate(taps):
                     for j, c in t:
                         loc[r, pos[j]] += c
                     if gi[r] >= 0:
                         loc[r, gpos[int(gi[r])]] = gb[r]
+                        loc[r, gpos[int(gi[r])] + 1] = gb[r]
                 full = loc if not (loc.shape[0] == loc.shape[1] and np.array_equal(loc, np.eye(len(loc)))) else None
                 self.local_rows = rows
                 self.local_groups = [groups[k] for k in used_groups]

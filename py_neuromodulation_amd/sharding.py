@@ -105,7 +105,7 @@ class ShardedStream:
         for g, members in enumerate(dp.local_groups):
             idx = [pos[int(j)] for j in members if int(j) in own]
             if idx:
-                part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float64)).sum(axis=0)
+                part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float32)).astype(np.float64).sum(axis=0)   # the float32 samples the devices see
         if dist.is_available() and dist.is_initialized() and part.size and (
                 dist.get_world_size(group) > 1 or _force_collectives()):
             t = torch.from_numpy(part).to(self._comm_device(group))
@@ -148,7 +148,7 @@ class ShardedStream:
             raise ValueError(f"local_input: expected the {len(self.local_rows)} rows ShardedStream.local_rows, "
                              f"got {data.shape[0]}")
         sums = self.group_sums(data, group)
-        x = np.concatenate([np.asarray(data, np.float32), sums.astype(np.float32)], axis=0)
+        x = np.concatenate([np.asarray(data, np.float32)] + [chmod.split_hi_lo(v) for v in sums], axis=0)
         if not len(starts):
             return list(dp.keys), np.empty((0, len(dp.keys))), times
         out, mask = dp.engine.process_batch(x, starts, want_nan_mask=True)
@@ -163,13 +163,20 @@ class ShardedStream:
 class MultiDeviceProcessor:
     """Single-process form of the channel shard: one plan per device, one host thread per plan
     (ctypes drops the GIL for the duration of every libnmx call, so the launch sequences, the host <-> device
-    copies and the waits of all devices overlap).  Every device is handed the whole recording and applies its own
-    rows of the folded (re-reference x channel-pick) matrix -- no exchange step; the feature normaliser is per
-    column, so each device normalises its own columns.  Same surface as ``DataProcessor`` for what ``Stream``
-    uses: ``keys`` (reference order over ALL channels), ``process``, ``process_batch``, ``reset``."""
+    copies and the waits of all devices overlap).  Same surface as ``DataProcessor`` for what ``Stream``
+    uses: ``keys`` (reference order over ALL channels), ``process``, ``process_batch``, ``reset``.  The feature
+    normaliser is per column, so each device normalises its own columns.
+
+    ``local_input=True`` (default; SURVEY 8e "CAR hoisted before scatter"): a device is handed ONLY the input rows
+    its own channel block taps (its channels, plus the few rows bipolar references name) and two rows per type
+    group holding (hi, lo) of sum_{j in group} nan_to_num(x_j), formed ONCE on the host in float64 and shared by the devices --
+    the host-to-device volume per device is C / N rows (+ group rows) instead of the whole recording (C5: 4096
+    channels at 30 kS/s).  Channel tables whose re-reference rows are not "a few named channels and / or one group
+    average" (processing/rereference.py:52-86 only builds such rows) fall back to the replicated form:
+    ``local_input=False`` hands every device the whole recording and its rows of the folded matrix."""
 
     def __init__(self, sfreq, settings, channels, line_noise=None, devices=(0,), window=None, lib=None,
-                 verbose: bool = False, resample_features_at_new_rate: bool = False) -> None:
+                 verbose: bool = False, resample_features_at_new_rate: bool = False, local_input: bool = True) -> None:
         from concurrent.futures import ThreadPoolExecutor
 
         self.settings = NMSettings.load(settings)
@@ -186,13 +193,39 @@ class MultiDeviceProcessor:
         self.ch_names_used = layout.ch_names_used
         col = {k: i for i, k in enumerate(self.keys)}
         self.parts, self._cols = [], []
-        for i, dev in enumerate(devices):
-            shard = channel_shard(len(names), len(devices), i)
-            if not len(shard):
-                continue   # more devices than channels
-            dp = DataProcessor(sfreq, self.settings, self.channels, device=dev, channel_subset=shard, staging_slot=i, **kw)
-            self.parts.append(dp)
-            self._cols.append(np.array([col[k] for k in dp.keys], dtype=np.int64))
+        self.local_input = bool(local_input)
+        while True:
+            try:
+                for i, dev in enumerate(devices):
+                    shard = channel_shard(len(names), len(devices), i)
+                    if not len(shard):
+                        continue   # more devices than channels
+                    dp = DataProcessor(sfreq, self.settings, self.channels, device=dev, channel_subset=shard,
+                                       staging_slot=i, local_inputs=self.local_input, **kw)
+                    self.parts.append(dp)
+                    self._cols.append(np.array([col[k] for k in dp.keys], dtype=np.int64))
+                break
+            except NotImplementedError:
+                if not self.local_input:
+                    raise
+                for p in self.parts:   # rows without the taps + group-sum structure: replicated input
+                    p.engine.close()
+                self.parts, self._cols, self.local_input = [], [], False
+        self.h2d_rows = [len(p.local_rows) + 2 * len(p.local_groups) if self.local_input else len(self.channels)
+                         for p in self.parts]   # input rows every device receives (profiles/r04_host_boundary.json)
+        if self.local_input:
+            # every group sum once, whoever needs it
+            self._groups, gid = [], {}
+            self._part_groups = []
+            for p in self.parts:
+                ids = []
+                for members in p.local_groups:
+                    key = tuple(int(j) for j in members)
+                    if key not in gid:
+                        gid[key] = len(self._groups)
+                        self._groups.append(np.asarray(key, dtype=np.int64))
+                    ids.append(gid[key])
+                self._part_groups.append(ids)
         self.devices = devices[:len(self.parts)]
         self.verbose = verbose
         self.settings_token = None
@@ -232,15 +265,60 @@ class MultiDeviceProcessor:
             out[:, cols] = r
         return out
 
+    # -- local input: what every device is handed ------------------------------------------------------
+    def _local_inputs(self, data: np.ndarray):
+        """-> per part float32 [rows of the part + its group-sum rows, T]; the group sums are formed once in float64
+        from nan_to_num(x) (the reference cleans before it re-references, stream/data_processor.py:255)."""
+        data = np.asarray(data)
+        # (the float32-ROUNDED samples are summed: that is what a device that holds the rows itself adds up)
+        hilo = [chmod.split_hi_lo(np.nan_to_num(np.asarray(data[g], np.float32)).astype(np.float64).sum(axis=0)) for g in self._groups]
+        xs = []
+        for p, ids in zip(self.parts, self._part_groups):
+            x = np.empty((len(p.local_rows) + 2 * len(ids), data.shape[1]), np.float32)
+            x[:len(p.local_rows)] = data[p.local_rows]
+            for k, gi in enumerate(ids):
+                x[len(p.local_rows) + 2 * k:len(p.local_rows) + 2 * k + 2] = hilo[gi]
+            xs.append(x)
+        return xs
+
+    def _full_mask(self, masks, n_all: int) -> np.ndarray:
+        """NaN mask over ALL input rows from every part's local rows (a group-sum row is never NaN)."""
+        full = np.zeros((masks[0].shape[0], n_all), dtype=bool)
+        for p, m in zip(self.parts, masks):
+            full[:, p.local_rows] |= m[:, :len(p.local_rows)]
+        return full
+
+    def _run_parts(self, data, starts, tapped: bool):
+        """Every part on its own thread -> [(float32 rows, mask over ALL input rows, windows or None)]."""
+        if not self.local_input:
+            if tapped:
+                return list(self._pool.map(lambda p: p.process_batch_tapped(data, starts), self.parts))
+            return [(o, m, None) for o, m in self._pool.map(
+                lambda p: p.engine.process_batch(data, starts, want_nan_mask=True), self.parts)]
+        xs = self._local_inputs(data)
+
+        def job(px):
+            p, x = px
+            if tapped:   # (a local-input part always has a matrix: never the identity shortcut)
+                o, m, pre = p.engine.process_batch(x, starts, want_nan_mask=True, tap=True)
+                return o, m, pre.astype(np.float64)
+            o, m = p.engine.process_batch(x, starts, want_nan_mask=True)
+            return o, m, None
+
+        got = list(self._pool.map(job, zip(self.parts, xs)))
+        full = self._full_mask([m for _, m, _ in got], len(self.channels))
+        return [(o, full, w) for o, _, w in got]
+
     def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
-        if self._user is None:
-            rows = list(self._pool.map(lambda p: p.process_batch(data, starts), self.parts))
-            return self._merge(rows)
         starts = np.asarray(starts, dtype=np.int64)
+        if self._user is None:
+            got = self._run_parts(data, starts, False)
+            rows = [p.postprocess_batch(o, m, normalised=p._norm_in_engine) for p, (o, m, _) in zip(self.parts, got)]
+            return self._merge(rows)
         tables = []
         for i in range(0, len(starts), self._user_chunk):
             st_ = starts[i:i + self._user_chunk]
-            got = list(self._pool.map(lambda p: p.process_batch_tapped(data, st_), self.parts))
+            got = self._run_parts(data, st_, True)
             # contiguous channel blocks in device order: the joined window is the single-device one
             user = self._user.rows(np.concatenate([w for _, _, w in got], axis=1))
             builtin = [p.postprocess_batch(o, m, normalised=p._norm_in_engine) for p, (o, m, _) in zip(self.parts, got)]
@@ -255,7 +333,7 @@ class MultiDeviceProcessor:
         return np.concatenate(tables) if tables else np.empty((0, len(self.keys)))
 
     def process(self, data: np.ndarray) -> dict:
-        if self._user is not None:
+        if self._user is not None or self.local_input:
             row = self.process_batch(np.asarray(data), np.zeros(1, np.int64))[0]
             return dict(zip(self.keys, row.tolist()))
         parts = list(self._pool.map(lambda p: p.process(data), self.parts))
