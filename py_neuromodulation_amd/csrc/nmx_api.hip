@@ -245,6 +245,7 @@ extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipSt
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
+extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   static int scan_ok = -1;
@@ -254,6 +255,9 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
     nmx_wave_launch_scan(&A, n_items, s);
     return;
   }
+  // FFT band means of 1000-sample windows whose bins fit 32 rows: the spectrum on the matrix pipe (nmx_k_specmm.h)
+  // (any batch size, one window included: a result must not depend on how the hops were batched)
+  if (A.smm_tab && nmx_specmm_launch(&A, n_items, s)) return;
   // default shape (W = 1000, band means): one wave per item, wave-level 500-point transforms
   if (A.w500_tab && nmx_wave_launch_timeosc_w1000(&A, n_items, s)) return;
   if (A.w500_tab && nmx_wave_launch_timeosc_stft500(&A, n_items, s)) return;

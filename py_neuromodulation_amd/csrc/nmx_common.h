@@ -170,6 +170,9 @@ struct NmxTimeOscArgs {
   int off_x, off_a, off_b, off_spec, off_red, lds_floats;
   const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h), else NULL
   const unsigned short* w510_tab;   // 510-sample transforms: position tables of the prime-factor wave kernel (nmx_k_timeosc_w510.h)
+  const float* smm_tab;    // matrix-pipe spectrum kernel (nmx_k_specmm.h): [cos rows k0 .. k0 + 31 | sin rows][1000], else NULL
+  int smm_k0;              // first bin of that table
+  int starts_mod4;         // every window start of this launch is a multiple of 4 samples (16-byte loads of the lanes' runs)
 };
 
 #define NMXD_F_HJORTH (1u << 0)

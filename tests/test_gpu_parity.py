@@ -80,6 +80,51 @@ def test_batch_equals_window_by_window_and_oracle_64ch(gpu_lib):
     eng.close()
 
 
+def test_matrix_pipe_spectrum_kernel(gpu_lib, monkeypatch):
+    """nmx_kern_specmm_w1000 (nmx_k_specmm.h): the FFT band means of BASELINE config[1] as a pruned DFT on the matrix
+    pipe, Hjorth / LineLength / Raw as single-pass per-lane statistics next to it.  70 channels x 45 hops (a ragged last
+    tile of 32-window groups), per-channel offsets of +-500, a NaN stretch (nan_to_num on load) and a flat channel;
+    against the float64 oracle under the standard policy, and against the wave-level FFT kernel it replaces."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+    sfreq, C, n_hops = 1000.0, 70, 45
+    T = 1000 + (n_hops - 1) * 100
+    rng = np.random.default_rng(99)
+    t = np.arange(T) / sfreq
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-500, 500, (C, 1))).astype(np.float32)
+    x[5] = 0.0
+    x[9, 2000:2010] = np.nan
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * 100
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    got = eng.process_batch(x, starts)
+    assert "nmx_kern_specmm_w1000" in eng.kernels(2), eng.kernels(2)
+    one = np.stack([eng.process_window(x[:, a:a + 1000].astype(np.float64)) for a in starts[:3]])
+    np.testing.assert_array_equal(got[:3], one)     # one window == the batch, bit for bit
+    eng.close()
+    monkeypatch.setenv("NMX_SPECMM", "0")
+    eng0 = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    old = eng0.process_batch(x, starts)
+    assert "specmm" not in eng0.kernels(2)
+    eng0.close()
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in s.features.get_enabled()]
+    for i in (0, 7, 19, 20, 21, 44):
+        w = np.nan_to_num(x[:, starts[i]:starts[i] + 1000].astype(np.float64))
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(w))
+        assert list(want) == eng.keys
+        ver = parity.Verifier(s, ch, sfreq, w)
+        for tag, rows in (("specmm", got), ("wave fft", old)):
+            n_bad, rep, _ = parity.compare(eng.keys, rows[i], list(want.values()), s, sfreq, 600.0, 1000, verifier=ver)
+            assert n_bad == 0, f"{tag} hop {i}\n{rep}"
+
+
 def test_pipeline_readme_no_normalisation(gpu_lib):
     pc.case_pipeline_readme_no_normalisation(gpu_lib)
 
