@@ -34,7 +34,8 @@
 #define NMX_SMM_CH 20                                   // samples per half and chunk
 #define NMX_SMM_NCH 25                                  // 25 x 20 = 500
 #define NMX_SMM_CHUNK_FLOATS (2 * 2 * 32 * NMX_SMM_CH)  // [table: cos, sin][half][row][20]
-#define NMX_SMM_LDS_FLOATS (2 * NMX_SMM_CHUNK_FLOATS)   // double buffered: 20 KiB
+#define NMX_SMM_BUF_FLOATS (4 * 768)                    // a staged chunk: 640 float4 + the dead slots of the third staging round
+#define NMX_SMM_LDS_FLOATS (2 * NMX_SMM_BUF_FLOATS)     // double buffered: 24 KiB
 #define NMX_SMM_TAB_FLOATS (64 * 1000)                  // global table: [cos rows 0..31, sin rows 0..31][n]
 
 typedef float nmx_v16 __attribute__((ext_vector_type(16)));
@@ -73,16 +74,23 @@ NMX_DEV void nmx_smm_sample(NmxSmmStat& S, float u, int idx /* compile-time posi
   S.dp = d;
 }
 
-// One tile: the 4 waves of the workgroup take 32 items each, items [item0 + 32 wave, +32).
-template <int NB, bool TD, bool CLEAN>
-NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long item0, long long n_items, float* lds) {
+// One tile = four groups (one per wave) of 32 CONSECUTIVE WINDOWS OF ONE CHANNEL: group g -> channel g % C, windows
+// 32 (g / C) .. + 31.  The lanes of a wave then read one region of one row (overlapping hops share their cache lines; distinct
+// windows lie 4 KB apart) -- 32 channels of one hop would be 32 rows, a recording length apart each: 64 DRAM pages and
+// TLB entries per load instruction (measured: 1.85 ms per 1 M windows that way, matrix pipe 46 % busy).
+template <int NB, bool TD, bool CLEAN, int RING>
+NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long group0, int n_windows, float* lds) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, j = lane & 31;
-  long long it = item0 + 32 * wave + j;
-  const bool valid = it < n_items;
-  if (!valid) it = n_items - 1;
   const int C = A.n_channels;
-  const int w = (int)(it / C), c = (int)(it - (long long)w * C);
+  const long long g = group0 + wave;
+  const int wb = (int)(g / C), c = (int)(g - (long long)wb * C);   // (wave-uniform; a group beyond the last one has wb past the end)
+  int w = 32 * wb + j;
+  const bool valid = w < n_windows;
+  if (!valid) w = n_windows - 1;
+#ifdef NMX_SMM_DEBUG_SAMEWIN   // timing experiment: every lane streams the group's first window (results are wrong)
+  w = 32 * wb < n_windows ? 32 * wb : n_windows - 1;
+#endif
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? A.starts[w] : 0ll) + 500 * half;
   const float* tab = A.smm_tab;
 
@@ -98,28 +106,32 @@ NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long item0, long long
     const int seg = f / 5, q = f - 5 * seg, t = seg >> 6, h = (seg >> 5) & 1, r = seg & 31;
     return (const nmx_v4*)(tab + (long long)(32 * t + r) * 1000 + 500 * h + NMX_SMM_CH * ch) + q;
   };
+  // (every thread issues three loads -- the third one clamped, its store masked: a branch around a global load makes the
+  // compiler's wait-count pass conservative at the join, and the chunk then waits for the loads it has just issued)
   nmx_v4 tg[3];
   auto tab_load = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int f = tid + 256 * i;
-      if (f < 640) tg[i] = *tab_src(f, ch);
+      tg[i] = *tab_src(f < 640 ? f : 639, ch);
     }
   };
-  auto tab_store = [&](int buf) {
+  auto tab_store = [&](int buf) {   // (segment seg at 20 * seg floats: same order; slots 640 .. 767 are never read)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int f = tid + 256 * i;
-      if (f < 640) ((nmx_v4*)(lds + buf * NMX_SMM_CHUNK_FLOATS))[f] = tg[i];   // (segment seg at 20 * seg floats: same order)
-    }
+    for (int i = 0; i < 3; ++i) ((nmx_v4*)(lds + buf * NMX_SMM_BUF_FLOATS))[tid + 256 * i] = tg[i];
   };
-  nmx_v4 xb[2][5];
+  // the lanes' runs are prefetched RING - 1 chunks ahead (a ring of 80-byte buffers per lane): one chunk of matrix work is
+  // ~1 us, a scattered 128-byte line from HBM under load takes several (measured with one chunk of distance: every chunk
+  // waited for its loads, matrix pipe 50 % idle).  RING = 4 needs the 512-register budget (one workgroup per CU).
+  nmx_v4 xb[RING][5];
   auto x_load = [&](int ch, nmx_v4* dst) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) dst[q] = ((const nmx_v4*)(src + NMX_SMM_CH * ch))[q];
   };
 
   x_load(0, xb[0]);
+  x_load(1, xb[1]);
+  if (RING == 4) x_load(2, xb[2]);
   tab_load(0);
   tab_store(0);
   __syncthreads();
@@ -129,10 +141,15 @@ NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long item0, long long
   pilot = __shfl(pilot, j, 64);
   float last = 0.f;   // x[999] (Raw feature): the last sample of half 1
 
-  auto chunk = [&](auto first_tag, int ch, const nmx_v4* xc, nmx_v4* xn, int buf) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    if (ch + 1 < NMX_SMM_NCH) { x_load(ch + 1, xn); tab_load(ch + 1); }
-    const float* tl = lds + buf * NMX_SMM_CHUNK_FLOATS + (half * 32 + j) * NMX_SMM_CH;   // cos rows; sin rows 64 segments on
+  // chunk ch: arithmetic on xc (= ring slot ch & 3) and LDS table buffer ch & 1; XPRE: prefetch the lanes' runs of chunk
+  // ch + 3 into xn (= slot (ch + 3) & 3); TPRE: stage the table of chunk ch + 1
+  auto chunk = [&](auto first_tag, auto xpre_tag, auto tpre_tag, int ch, const nmx_v4* xc, nmx_v4* xn) {
+    constexpr bool FIRST = decltype(first_tag)::value, XPRE = decltype(xpre_tag)::value, TPRE = decltype(tpre_tag)::value;
+    const int buf = ch & 1;
+    if (XPRE) x_load(ch + RING - 1, xn);
+    if (TPRE) tab_load(ch + 1);
+    __builtin_amdgcn_sched_barrier(0);   // the prefetches are issued HERE, ahead of the chunk's arithmetic, not sunk below it
+    const float* tl = lds + buf * NMX_SMM_BUF_FLOATS + (half * 32 + j) * NMX_SMM_CH;   // cos rows; sin rows 64 segments on
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       const nmx_v4 ac = ((const nmx_v4*)tl)[q], as = ((const nmx_v4*)(tl + 64 * NMX_SMM_CH))[q];
@@ -144,19 +161,41 @@ NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long item0, long long
         acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i], u, acc_c, 0, 0, 0);
         acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(as[i], u, acc_s, 0, 0, 0);
         nmx_smm_sample<TD>(S, u, FIRST ? 4 * q + i : 2);
-        if (ch == NMX_SMM_NCH - 1 && q == 4 && i == 3) last = v;
+        if (!TPRE && q == 4 && i == 3) last = v;   // (the last chunk is the one that stages no successor)
       }
     }
-    if (ch + 1 < NMX_SMM_NCH) tab_store(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (TPRE) tab_store(buf ^ 1);
     __syncthreads();
   };
-  chunk(std::true_type{}, 0, xb[0], xb[1], 0);
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
+  if constexpr (RING == 4) {
+    chunk(yes, yes, yes, 0, xb[0], xb[3]);
 #pragma unroll 1
-  for (int ch = 1; ch + 1 < NMX_SMM_NCH; ch += 2) {
-    chunk(std::false_type{}, ch, xb[1], xb[0], 1);
-    chunk(std::false_type{}, ch + 1, xb[0], xb[1], 0);
+    for (int ch = 1; ch + 4 < NMX_SMM_NCH; ch += 4) {   // chunks 1 .. 20
+      chunk(no, yes, yes, ch, xb[1], xb[0]);
+      chunk(no, yes, yes, ch + 1, xb[2], xb[1]);
+      chunk(no, yes, yes, ch + 2, xb[3], xb[2]);
+      chunk(no, yes, yes, ch + 3, xb[0], xb[3]);
+    }
+    chunk(no, yes, yes, 21, xb[1], xb[0]);   // prefetches chunk 24
+    chunk(no, no, yes, 22, xb[2], xb[1]);
+    chunk(no, no, yes, 23, xb[3], xb[2]);
+    chunk(no, no, no, 24, xb[0], xb[3]);
+  } else {
+    chunk(yes, yes, yes, 0, xb[0], xb[2]);
+#pragma unroll 1
+    for (int ch = 1; ch + 3 < NMX_SMM_NCH; ch += 3) {   // chunks 1 .. 21
+      chunk(no, yes, yes, ch, xb[1], xb[0]);
+      chunk(no, yes, yes, ch + 1, xb[2], xb[1]);
+      chunk(no, yes, yes, ch + 2, xb[0], xb[2]);
+    }
+    chunk(no, yes, yes, 22, xb[1], xb[0]);   // prefetches chunk 24
+    chunk(no, no, yes, 23, xb[2], xb[1]);
+    chunk(no, no, no, 24, xb[0], xb[2]);
   }
-  // (25 chunks: 0, then 12 pairs 1..24)
+  static_assert(NMX_SMM_NCH == 25, "the chunk schedule above is written out for 25 chunks");
 
   float* out_row = A.out + (long long)w * A.n_outputs;
   // ---- band means: row of accumulator register r = (r & 3) + 8 (r >> 2) + 4 half, bin k0 + row ---------------------

@@ -101,6 +101,7 @@ def test_matrix_pipe_spectrum_kernel(gpu_lib, monkeypatch):
     x[9, 2000:2010] = np.nan
     ch = [f"ch{i}" for i in range(C)]
     starts = np.arange(n_hops) * 100
+    monkeypatch.setenv("NMX_SPECMM", "1")   # (opt-in: see nmx_specmm.hip)
     eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
     got = eng.process_batch(x, starts)
     assert "nmx_kern_specmm_w1000" in eng.kernels(2), eng.kernels(2)
