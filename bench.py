@@ -292,7 +292,7 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
     eng = dp.engine
     C = len(shard)
     F = eng.n_outputs
-    n_rows = eng.C_in   # own rows (+ the sum row for c4)
+    n_rows = eng.C_in   # own rows (+ the hi / lo rows of the group sum for c4)
     x = torch.empty((n_rows, T), dtype=torch.float32, device=dev)
     x[:C] = torch.from_numpy(synth(C, T, sfreq, 1234 + rank)).to(dev)
     out = torch.empty((n_win, F), dtype=torch.float32, device=dev)
@@ -306,7 +306,10 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
             if world > 1:
                 part = part.to(sum_dev)
                 dist.all_reduce(part, op=dist.ReduceOp.SUM)
-            x[C] = part.to(device=dev, dtype=torch.float32)
+            part = part.to(device=dev)
+            hi = part.to(torch.float32)   # the float64 sum travels as hi + lo float32 rows (channels.split_hi_lo)
+            x[C] = hi
+            x[C + 1] = (part - hi.to(torch.float64)).to(torch.float32)
         eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
 
     for _ in range(args.warmup):

@@ -378,12 +378,14 @@ def test_config4_shard_256_of_1024_notch_car(gpu_lib):
             n_bad, rep, _ = parity.compare(dp.engine.keys, dense[i], [want[k] for k in dp.engine.keys], s, 1000.0, 700.0, W,
                                            verifier=ver)
             assert n_bad == 0, f"dense hop {i}\n{rep}"
-    # the same shard WITHOUT the other ranks' rows: own 256 rows + one row holding the sum over all 1024
-    # (what the all-reduce of sharding.ShardedStream / bench.py --config c4 delivers)
+    # the same shard WITHOUT the other ranks' rows: own 256 rows + two rows (hi, lo) holding the float64 sum over all
+    # 1024 (what the all-reduce of sharding.ShardedStream / bench.py --config c4 delivers)
     dpl = DataProcessor(1000.0, s, channels, line_noise=50, verbose=False, lib=gpu_lib, window=W, channel_subset=shard,
                         local_inputs=True)
-    assert dpl.local_rows == list(shard) and dpl.engine.C_in == 257
-    xs = np.concatenate([x[shard.start:shard.stop], x.astype(np.float64).sum(axis=0, keepdims=True).astype(np.float32)])
+    from py_neuromodulation_amd.channels import split_hi_lo
+
+    assert dpl.local_rows == list(shard) and dpl.engine.C_in == 258
+    xs = np.concatenate([x[shard.start:shard.stop], split_hi_lo(x.astype(np.float64).sum(axis=0))])
     loc = dpl.engine.process_batch(xs, starts[:2])
     assert dpl.engine.keys == dp.engine.keys
     for i in (0, 1):
