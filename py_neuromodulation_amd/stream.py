@@ -137,8 +137,9 @@ class Stream:
         keys: list[str] = []
         if len(starts):
             groups = [int(g) for g in np.unique(lens)]
-            if len(groups) > 1 and "bursts" in st.features.get_enabled():
-                raise NotImplementedError("bursts with a non-integer hop (ragged windows) is not supported")
+            if len(groups) > 1 and "raw_normalization" in st.preprocessing:
+                raise NotImplementedError("raw_normalization with ragged window lengths (a non-integer number of samples per "
+                                          "segment) is not supported: its sample history is laid out per window length")
             if len(groups) > 1 and self.devices is not None and len(self.devices) > 1:
                 raise NotImplementedError("ragged windows (non-integer hop) are not supported on several devices")
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
@@ -165,8 +166,18 @@ class Stream:
                 raw = np.empty((len(starts), len(dp0.engine.keys)), dtype=np.float32)
                 masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
                 wins = [None] * len(starts)   # user features: the pre-processed window of every hop, hop order
-                for w, p in procs.items():
-                    sel = np.where(lens == w)[0]
+                # Hops in ORDER, as consecutive runs of one window length: the burst history (features/bursts.py:149-173)
+                # and the Kalman filters of the band powers (bandpower.py:147-163) carry over from hop to hop whatever
+                # the window length, so the state blob travels from plan to plan where the length changes (its layout
+                # depends on sfreq and the settings, not on the window: nmx_state_export / _import)
+                cuts = [0] + [i for i in range(1, len(lens)) if lens[i] != lens[i - 1]] + [len(lens)]
+                stateful = dp0.engine.export_state() != b""
+                state = None
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    p = procs[int(lens[a])]
+                    sel = np.arange(a, b)
+                    if stateful and state is not None:
+                        p.engine.import_state(state)
                     if dp0.user_features and not p.engine.preprocessing_is_identity:
                         o, m, pre = p.engine.process_batch(data, starts[sel], want_nan_mask=True, tap=True)
                         for j, i in enumerate(sel):
@@ -177,6 +188,8 @@ class Stream:
                             for i, wv in zip(sel, p._host_windows(data, starts[sel])):
                                 wins[i] = wv
                     raw[sel], masks[sel] = o, m
+                    if stateful:
+                        state = p.engine.export_state()
                 if dp0.user_features:
                     user = dp0._user_rows(wins)   # one set of instances sees every hop in order, like the reference
                     rows = dp0._with_user_columns(dp0._finish_rows(raw, masks, False), user)

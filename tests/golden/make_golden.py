@@ -608,6 +608,38 @@ def case_output_files():
     print("output_files", names, rows_per_file)
 
 
+def case_ragged_bursts():
+    """A sampling rate that is not an integer (tests/test_feature_sampling_rates.py: 1111.111 Hz): the generator cuts
+    windows of 1111 AND 1112 samples.  Bursts append the last int(sfreq * seg_s / feat_hz) samples of whatever window
+    arrives to ONE history, the Kalman filters of the band powers run on: state that crosses window lengths."""
+    rng = np.random.default_rng(5150)
+    sfreq = 1111.111
+    T = 9000
+    t = np.arange(T) / sfreq
+    data = rng.standard_normal((2, T)) * 20 + 15 * np.sin(2 * np.pi * 18 * t) * (np.sin(2 * np.pi * 0.7 * t) > 0)
+    s = nm.NMSettings.get_default()
+    s.reset()
+    s.features.fft = True
+    s.features.bursts = True
+    s.features.bandpass_filter = True
+    s.bandpass_filter_settings.kalman_filter = True
+    s.kalman_filter_settings.frequency_bands = ["theta", "low_beta"]
+    s.bursts_settings.time_duration_s = 2
+    s.preprocessing = []
+    s.postprocessing.feature_normalization = False
+    st, df = _run_stream(data, sfreq, s)
+    gen = nm.stream.generator.RawDataGenerator(data, sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    lens = [b.shape[1] for _, b in gen]
+    assert len(set(lens)) == 2, lens
+    bp = nm.features.BandPower(s, ["ch0", "ch1"], sfreq // 1)
+    out = {"sfreq": sfreq, "data": data, "settings_json": dump(st.settings), "columns": np.array(list(df.columns)),
+           "values": df.to_numpy(dtype=np.float64), "window_lengths": np.array(lens),
+           "channels_json": json.dumps(st.channels.to_dict("list")),
+           "bank_taps": np.asarray(bp.bandpass_filter.filter_bank)}
+    np.savez_compressed(HERE / "ragged_bursts.npz", **out)
+    print("ragged_bursts", df.shape, sorted(set(lens)))
+
+
 def case_user_features():
     """User-registered NMFeature plugins (features/feature_processor.py:52-53,90-108; the plugin of
     examples/plot_2_example_add_feature.py is tests/user_plugins.ChannelMean): the reference's own Stream.run with
@@ -680,3 +712,4 @@ if __name__ == "__main__":
     case_resample_quirk()
     case_output_files()
     case_user_features()
+    case_ragged_bursts()

@@ -448,6 +448,10 @@ def test_ragged_float_sfreq_stream(gpu_lib):
     pc.case_ragged_float_sfreq_stream(gpu_lib)
 
 
+def test_ragged_windows_carry_burst_and_kalman_state(gpu_lib):
+    pc.case_ragged_bursts(gpu_lib)
+
+
 def test_odd_windows_and_spectra(gpu_lib):
     pc.case_odd_windows_and_spectra(gpu_lib)
 

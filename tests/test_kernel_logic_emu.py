@@ -212,3 +212,7 @@ def test_burst_fill_walk_equals_workgroup_walk(emu_lib, monkeypatch):
 
 def test_user_registered_features(emu_lib):
     pc.case_user_features(emu_lib)
+
+
+def test_ragged_windows_carry_burst_and_kalman_state(emu_lib):
+    pc.case_ragged_bursts(emu_lib)
