@@ -300,16 +300,19 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
     stream = torch.cuda.current_stream(dev).cuda_stream
     sum_dev = torch.device("cpu") if args.backend == "gloo" else dev
 
+    def exchange():   # partial column sums -> all-reduce -> hi / lo sum rows of this rank's input
+        part = x[:C].sum(dim=0, dtype=torch.float64)
+        if world > 1:
+            part = part.to(sum_dev)
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+        part = part.to(device=dev)
+        hi = part.to(torch.float32)   # the float64 sum travels as hi + lo float32 rows (channels.split_hi_lo)
+        x[C] = hi
+        x[C + 1] = (part - hi.to(torch.float64)).to(torch.float32)
+
     def step():
-        if car:   # the exchange step: partial column sums -> all-reduce -> sum row of this rank's input
-            part = x[:C].sum(dim=0, dtype=torch.float64)
-            if world > 1:
-                part = part.to(sum_dev)
-                dist.all_reduce(part, op=dist.ReduceOp.SUM)
-            part = part.to(device=dev)
-            hi = part.to(torch.float32)   # the float64 sum travels as hi + lo float32 rows (channels.split_hi_lo)
-            x[C] = hi
-            x[C + 1] = (part - hi.to(torch.float64)).to(torch.float32)
+        if car:
+            exchange()
         eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
 
     for _ in range(args.warmup):
@@ -333,6 +336,14 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
     bad = int(torch.isnan(out).sum().item())
+    exchange_ms = None
+    if car:   # the exchange step alone (outside the timed region): partial sums + all-reduce + hi / lo rows, per step
+        torch.cuda.synchronize(dev)
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            exchange()
+        torch.cuda.synchronize(dev)
+        exchange_ms = (time.perf_counter() - te) / args.steps * 1e3
     if rank == 0:
         value = args.steps * n_win / dt               # windows of the WHOLE array (all ranks work on the same windows)
         stage = max(("timeosc", "bank", "sharp", "prep"), key=lambda k: kt[k])
@@ -350,6 +361,7 @@ def run_config(args, torch, dist, world, rank, dev, dev_index) -> None:
                        "parallelism": f"channel-shard x{world}" + (", group sum all-reduced per step" if car else ", no collective")},
             "features_per_sec": value * F * world,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
+            "exchange_ms_per_step": exchange_ms,   # c4: column sums + all-reduce + hi / lo rows (inside the timed step; timed alone here)
             "kernels": {name: eng.kernels(i) for name, i in (("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("sharp", 5))},
             "nan_outputs": bad,
             "roofline": {"bound": "hbm", "kernel": eng.kernels(idx), "stage": stage,
@@ -371,7 +383,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU")
     ap.add_argument("--windows", type=int, default=1024, help="hops per step (batch)")
-    ap.add_argument("--cpu-windows", type=int, default=24, help="hops timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=48, help="hops timed for cpu_baseline (0 = skip; ~0.5 s per hop on one core)")
     ap.add_argument("--cpu-procs", type=int, default=32, help="worker processes of cpu_baseline_allcores (0 = skip)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start_ms measurement")
     ap.add_argument("--no-mode-a", action="store_true", help="skip the roofline_modeA measurement (time / oscillatory kernel from HBM)")
@@ -473,10 +485,17 @@ def main() -> None:
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt
+    rank_ms = None
     if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        cdev = dev if args.backend == "nccl" else "cpu"
+        tdt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
+        # every rank's own wall time per step (the value above uses the slowest): lets a SCALE line be read
+        every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt_own / args.steps * 1e3], dtype=torch.float64, device=cdev))
+        rank_ms = [float(t.item()) for t in every]
     bad = int(torch.isnan(out).sum().item())
 
     if rank == 0:
@@ -513,6 +532,7 @@ def main() -> None:
             "features_per_sec": value * F,
             "algorithmic_GBps_pipeline": value / world * C * bytes_cw / 1e9,
             "kernel_ms_per_step": {k: v / args.steps for k, v in kt.items()},
+            "ms_per_step_by_rank": rank_ms,   # (N > 1: every rank's own wall time per step; `value` uses the slowest)
             "nan_outputs": bad,
             "kernels": {name: eng.kernels(idx) for name, idx in
                         (("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("bursts", 4), ("sharp", 5))},
@@ -554,7 +574,7 @@ def main() -> None:
                     procs = min(args.cpu_procs, os.cpu_count() or 1)
                     va, np_, slow = cpu_baseline_allcores(C, 8, procs)
                     res["cpu_baseline_allcores"] = {
-                        "value": va, "unit": "windows/s", "cores": np_, "kind": "port", "host_cpus": os.cpu_count(),
+                        "value": va, "unit": "windows/s", "cores": np_, "kind": f"port, {np_} processes", "host_cpus": os.cpu_count(),
                         "sample": f"8 hops, channels split over {np_} worker processes (1 core each), common-average "
                                   f"reference applied once by the parent; hops / slowest worker ({slow:.1f} s)"}
                 except Exception as e:   # never let the context row break the bench line

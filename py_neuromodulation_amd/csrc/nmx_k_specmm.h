@@ -158,8 +158,14 @@ NMX_DEV void nmx_specmm_tile(const NmxTimeOscArgs& A, long long group0, int n_wi
         float v = xc[q][i];
         if (CLEAN) v = nmx_clean_bl(v);
         const float u = v - pilot;
+#ifdef NMX_SMM_DEBUG_HALFK   // timing experiment: half the matrix work on the same loads (results are wrong)
+        if (i & 1) {
+#endif
         acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i], u, acc_c, 0, 0, 0);
         acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(as[i], u, acc_s, 0, 0, 0);
+#ifdef NMX_SMM_DEBUG_HALFK
+        }
+#endif
         nmx_smm_sample<TD>(S, u, FIRST ? 4 * q + i : 2);
         if (!TPRE && q == 4 && i == 3) last = v;   // (the last chunk is the one that stages no successor)
       }

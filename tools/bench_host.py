@@ -46,7 +46,27 @@ def main():
         out = eng.process_window(w64)
         d = dict(zip(eng.keys, out.tolist()))
         lat.append(time.perf_counter() - t1)
-    print(json.dumps({"pcie_inclusive_windows_per_s": n / dt, "ms_per_1024_hops": dt * 1e3,
+    # single process, several plans (Stream(devices=[...])): what each device is handed -- local input (its rows + hi / lo
+    # rows per group sum) against the whole recording
+    from py_neuromodulation_amd import _lib
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.sharding import MultiDeviceProcessor
+
+    ndev = _lib.get_library().device_count()
+    devices = list(range(min(ndev, 8))) if ndev >= 2 else [0, 0]
+    channels = chmod.get_default_channels_from_data(x)
+    md = {}
+    for local in (True, False):
+        dp = MultiDeviceProcessor(1000.0, s, channels, line_noise=50, devices=devices, window=W, local_input=local)
+        dp.process_batch(x, starts)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dp.process_batch(x, starts)
+        md["local_input" if dp.local_input else "replicated_input"] = {
+            "devices": devices, "h2d_rows_per_device": dp.h2d_rows, "h2d_MB_per_device": [r * T * 4 / 1e6 for r in dp.h2d_rows],
+            "ms_per_1024_hops": (time.perf_counter() - t0) / 3 * 1e3}
+        dp.close()
+    print(json.dumps({"multi_device_stream": md, "pcie_inclusive_windows_per_s": n / dt, "ms_per_1024_hops": dt * 1e3,
                       "pageable_buffers_windows_per_s": n / dt_pageable, "pageable_ms_per_1024_hops": dt_pageable * 1e3,
                       "h2d_MB": x.nbytes / 1e6, "d2h_MB": n * eng.n_outputs * 4 / 1e6,
                       "one_window_256ch_latency_ms_median": float(np.median(lat)) * 1e3,
