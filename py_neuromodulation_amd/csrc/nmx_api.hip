@@ -321,11 +321,13 @@ static void be_launch_sharp_todo(const NmxSharpArgs& A, int n_items, size_t lds,
   nmx_wave_launch_sharp_todo(&A, n_items, lds, todo, s);
 }
 extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long n_items, hipStream_t s);
+extern "C" void nmx_wave_launch_hilbert_w1000(const NmxHilbertArgs* A, long long n_items, hipStream_t s);
 static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   static int w500 = -1;
   if (w500 < 0) { const char* v = getenv("NMX_HILBERT_W500"); w500 = !(v && v[0] == '0'); }
   if (w500 && A.W == 1000 && !A.hil_full) { nmx_wave_launch_hilbert_w500(&A, n_items, s); return; }
+  if (w500 && A.W == 2000 && A.w1000_tab) { nmx_wave_launch_hilbert_w1000(&A, n_items, s); return; }
   static int fixed_ok = -1;
   if (fixed_ok < 0) { const char* v = getenv("NMX_HILBERT_FIXED"); fixed_ok = !(v && v[0] == '0'); }
   if (fixed_ok && nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }

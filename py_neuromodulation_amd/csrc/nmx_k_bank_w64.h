@@ -787,6 +787,7 @@ struct NmxHilbertArgs {
   int hil_full;
   int off_a, off_b, off_y, lds_floats;
   const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h)
+  const float* w1000_tab;  // W = 2000: tables of the 1000-point wave-level transform (nmx_k_fft500.h)
 };
 
 NMX_DEV void nmx_hilbert_item(const NmxHilbertArgs& A, long long item, float* smem) {
@@ -865,6 +866,33 @@ NMX_DEV void nmx_hilbert_w500_item(const NmxHilbertArgs& A, long long item, floa
   const nmx_c2* ht = nmx_w500_hilbert(ha, hb, T, (const nmx_c2*)A.w500_tab + NMX_W500_TW_N, l);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
+    const nmx_c2 h = ht[l + 64 * q];
+    const nmx_c2 e = nmx_mk2(nmx_sqrt_fast(y[q].x * y[q].x + h.x * h.x), nmx_sqrt_fast(y[q].y * y[q].y + h.y * h.y));
+    __builtin_amdgcn_raw_buffer_store_b64(e, rout, 8 * l + 512 * q, 0, 0);
+  }
+}
+// The same for length-2000 series (BASELINE config 3): 1000 packed points, 1000-point wave-level transforms.
+// LDS per wave: ONE buffer of 1000 complex points (the transforms run in place) = 8 KB.
+#define NMX_W1000_LDS_FLOATS 2000
+NMX_DEV void nmx_hilbert_w1000_item(const NmxHilbertArgs& A, long long item, float* smem) {
+  const int l = NMX_TID;
+  nmx_c2* hb = (nmx_c2*)smem;
+  nmx_c2* ha = hb;
+  const nmx_rsrc rin = nmx_make_rsrc(A.y + item * 2000, 8000);
+  const nmx_rsrc rout = nmx_make_rsrc(A.env + item * 2000, 8000);
+  NmxW1000TwReg T;
+  T.load(A.w1000_tab, l);
+  nmx_c2 y[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) y[q] = __builtin_amdgcn_raw_buffer_load_b64(rin, 8 * l + 512 * q, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    if (q < 15 || l < 40) hb[l + 64 * q] = y[q];
+  NMX_WAVE_FENCE();
+  const nmx_c2* ht = nmx_w1000_hilbert(ha, hb, T, (const nmx_c2*)A.w1000_tab + NMX_W1000_TW_N, l);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (!(q < 15 || l < 40)) continue;
     const nmx_c2 h = ht[l + 64 * q];
     const nmx_c2 e = nmx_mk2(nmx_sqrt_fast(y[q].x * y[q].x + h.x * h.x), nmx_sqrt_fast(y[q].y * y[q].y + h.y * h.y));
     __builtin_amdgcn_raw_buffer_store_b64(e, rout, 8 * l + 512 * q, 0, 0);

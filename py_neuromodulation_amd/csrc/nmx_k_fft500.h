@@ -217,4 +217,104 @@ NMX_DEV const nmx_c2* nmx_w500_hilbert(nmx_c2* a, nmx_c2* b, const TW& T, const 
   NMX_WAVE_FENCE();
   return nmx_w500_fft<+1>(b, a, b, T, lane);
 }
+
+// ---- 1000 points (real length 2000: BASELINE config 3, 2 kHz x 1 s windows) ------------------------------------------
+// Stages 10 . 10 . 10 (the same Stockham index maps), 100 radix-10 butterflies per stage: lane l < 50 takes butterflies
+// l and l + 50 -- they share the stage-2 twiddles ((l + 50) % 10 = l % 10).  27 twiddles per lane:
+//   tw[i * 64 + lane], i = 0..8    stage 2: exp(-2 pi i 10 k r / 1000), k = lane % 10, r = i + 1
+//                      i = 9..17   stage 3, butterfly j = lane:      exp(-2 pi i j r / 1000), r = i - 8
+//                      i = 18..26  stage 3, butterfly j = lane + 50: r = i - 17          (lanes >= 50: copies of lane 0)
+//   cs[k], k = 0..999 (complex): (2 cos(2 pi k / 2000), 2 sin(2 pi k / 2000)) / 2000, cs[0] = 0
+#define NMX_W1000_TW_N (27 * 64)
+#define NMX_W1000_CS_N 1000
+#define NMX_W1000_TAB_FLOATS (2 * (NMX_W1000_TW_N + NMX_W1000_CS_N))
+struct NmxW1000TwReg {
+  nmx_c2 a[27];
+  NMX_DEV void load(const float* tab, int lane) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) a[i] = ((const nmx_c2*)tab)[i * 64 + lane];
+  }
+  NMX_DEV nmx_c2 get(int i) const { return a[i]; }
+};
+
+// in -> a -> b -> a ; returns a (natural order).  A lane reads the points of BOTH its butterflies before it writes any, and
+// a wave executes in lockstep, so every stage may run IN PLACE: in, a and b may all be the same 1000-point buffer (8 KB per
+// wave instead of 16: twice the resident waves).
+template <int DIR, typename TW>
+NMX_DEV nmx_c2* nmx_w1000_fft(const nmx_c2* in, nmx_c2* a, nmx_c2* b, const TW& T, int lane) {
+  nmx_c2 v[10], u[10];
+  if (lane < 50) {
+    // stage 1: R = 10, Ns = 1: in[j + 100 r] -> a[10 j + r]
+    nmx_ds_read_seq<800, 0>(v, nmx_lds_addr(in + lane), std::make_integer_sequence<int, 10>{});
+    nmx_ds_read_seq<800, 0>(u, nmx_lds_addr(in + lane + 50), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]); nmx_lds_tie8(u); nmx_lds_tie2(u[8], u[9]);
+    nmx_dft10_c2<DIR>(v);
+    nmx_dft10_c2<DIR>(u);
+  }
+  NMX_WAVE_FENCE();   // (every lane's reads are done: in-place stores are safe)
+  if (lane < 50) {
+    nmx_c2* o = a + 10 * lane;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { o[r] = v[r]; o[500 + r] = u[r]; }
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+    // stage 2: R = 10, Ns = 10: a[j + 100 r] * w^(10 k r) -> b[100 q + k + 10 r],  q = j / 10, k = j % 10
+    nmx_ds_read_seq<800, 0>(v, nmx_lds_addr(a + lane), std::make_integer_sequence<int, 10>{});
+    nmx_ds_read_seq<800, 0>(u, nmx_lds_addr(a + lane + 50), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]); nmx_lds_tie8(u); nmx_lds_tie2(u[8], u[9]);
+#pragma unroll
+    for (int r = 1; r < 10; ++r) { v[r] = nmx_cmul_tw<(DIR > 0)>(v[r], T.get(r - 1)); u[r] = nmx_cmul_tw<(DIR > 0)>(u[r], T.get(r - 1)); }
+    nmx_dft10_c2<DIR>(v);
+    nmx_dft10_c2<DIR>(u);
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+    const int q0 = lane / 10, k = lane - 10 * q0;
+    nmx_c2* o = b + 100 * q0 + k;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { o[10 * r] = v[r]; o[500 + 10 * r] = u[r]; }
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+    // stage 3: R = 10, Ns = 100: b[j + 100 r] * w^(j r) -> a[j + 100 r]
+    nmx_ds_read_seq<800, 0>(v, nmx_lds_addr(b + lane), std::make_integer_sequence<int, 10>{});
+    nmx_ds_read_seq<800, 0>(u, nmx_lds_addr(b + lane + 50), std::make_integer_sequence<int, 10>{});
+    nmx_lds_wait8(v); nmx_lds_tie2(v[8], v[9]); nmx_lds_tie8(u); nmx_lds_tie2(u[8], u[9]);
+#pragma unroll
+    for (int r = 1; r < 10; ++r) { v[r] = nmx_cmul_tw<(DIR > 0)>(v[r], T.get(9 + r - 1)); u[r] = nmx_cmul_tw<(DIR > 0)>(u[r], T.get(18 + r - 1)); }
+    nmx_dft10_c2<DIR>(v);
+    nmx_dft10_c2<DIR>(u);
+  }
+  NMX_WAVE_FENCE();
+  if (lane < 50) {
+    nmx_c2* o = a + lane;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { o[100 * r] = v[r]; o[50 + 100 * r] = u[r]; }
+  }
+  NMX_WAVE_FENCE();
+  return a;
+}
+
+// Hilbert transform of a real series of 2000 samples: nmx_w500_hilbert with n = 1000 (same collapsed spectral step)
+template <typename TW>
+NMX_DEV const nmx_c2* nmx_w1000_hilbert(nmx_c2* a, nmx_c2* b, const TW& T, const nmx_c2* cs, int lane) {
+  const nmx_c2* Z = nmx_w1000_fft<-1>(b, a, b, T, lane);   // = a
+  nmx_c2 zp[16];   // (a may be b: the whole spectrum is read before any point of Z' is written)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = lane + 64 * q;
+    zp[q] = nmx_mk2(0.f, 0.f);
+    if (k < 1000) {
+      const nmx_c2 zk = Z[k], zc = Z[k == 0 ? 0 : 1000 - k], w = cs[k];
+      zp[q] = nmx_mk2(w.x * zc.x - w.y * zk.y, w.y * zk.x - w.x * zc.y);
+    }
+  }
+  NMX_WAVE_FENCE();
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    if (lane + 64 * q < 1000) b[lane + 64 * q] = zp[q];
+  NMX_WAVE_FENCE();
+  return nmx_w1000_fft<+1>(b, a, b, T, lane);
+}
 #endif

@@ -82,6 +82,22 @@ extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long 
   nmxi_note_kernel("nmx_kern_hilbert_w500");
 }
 
+// Hilbert envelope of length-2000 series (BASELINE config 3), one wave per series, four per workgroup (16 KB of LDS each)
+__global__ void __launch_bounds__(256) nmx_kern_hilbert_w1000(const NmxHilbertArgs A, long long n_items) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long item = (long long)blockIdx.x * 4 + wave;
+  if (item >= n_items) return;
+  nmx_hilbert_w1000_item(A, item, nmx_smem_wave + wave * NMX_W1000_LDS_FLOATS);
+}
+
+extern "C" void nmx_wave_launch_hilbert_w1000(const NmxHilbertArgs* A, long long n_items, hipStream_t s) {
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen))
+    (void)hipFuncSetAttribute((const void*)nmx_kern_hilbert_w1000, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(nmx_kern_hilbert_w1000, dim3((unsigned)((n_items + 3) / 4)), dim3(256), (size_t)4 * NMX_W1000_LDS_FLOATS * 4, s, *A, n_items);
+  nmxi_note_kernel("nmx_kern_hilbert_w1000");
+}
+
 // time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
 template <int NB, unsigned SPEC = 0>
 __global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
