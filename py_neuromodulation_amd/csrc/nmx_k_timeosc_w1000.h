@@ -15,7 +15,7 @@
 //              A[k] = (Z[k] + conj Z[500-k]) / 2,  B[k] = (Z[k] - conj Z[500-k]) / 2i   (3 transforms)
 //   * band means are accumulated per lane while the bins are produced (no spectrum buffer) and reduced
 //     with DPP wave reductions.
-// LDS per wave: xs[1000] + a[500] + b[501] complex = 12 KB -> 13 waves per CU.
+// LDS per wave: xs[1000] + one in-place transform buffer of 500 complex = 8 KB.
 #pragma once
 
 #include "nmx_k_bank_w64.h"
@@ -24,8 +24,10 @@
 
 #ifndef NMX_HOST_EMU
 
-#define NMX_TOW_LDS_FLOATS (1008 + 1008 + 1000)
-#define NMX_TOW_LDS_FLOATS_NOSTFT (1008 + 1008)
+// (every transform runs IN PLACE -- a single wave reads all the points of a stage before it writes any, nmx_k_fft500.h --
+// so one 500-point buffer serves as input, ping and pong: 8 KB per wave with the STFT's copy of the window, 4 KB without)
+#define NMX_TOW_LDS_FLOATS (1008 + 1000)
+#define NMX_TOW_LDS_FLOATS_NOSTFT 1008
 
 // can this configuration run on the wave kernel?  (host side, called by the launcher)
 static inline bool nmx_timeosc_w1000_ok(const NmxTimeOscArgs& A) {
@@ -129,8 +131,8 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
   const bool welch_log = SPEC ? (SPEC & NMX_TOW_SPEC_LOG_WELCH) != 0 : A.welch.log_transform != 0;
   const int lane = (int)(threadIdx.x & 63);
   nmx_c2* fa = (nmx_c2*)smem;                    // [500]
-  nmx_c2* fb = LOW ? fa : (nmx_c2*)(smem + 1008);   // [501] (low-band forms: the transform runs in place)
-  float* xs = smem + 2016;                       // [1000] the window, natural order
+  nmx_c2* fb = fa;                               // (the transforms run in place)
+  float* xs = smem + 1008;                       // [1000] the window, natural order
   float* out_row = A.out + (long long)w * A.n_outputs;
   const int nb = A.n_bands;
 
@@ -312,7 +314,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 // segments -- the reference takes windowlength_ms as a sample count, features/oscillatory.py:199-213), one wave per
 // (window, channel): the window in LDS, two real segments per wave-level 500-point transform as above.  Only when the
 // STFT is the one time / oscillatory feature (the 256-thread generic kernel: 1.4-1.7 ms per 256 hops x 256 channels).
-#define NMX_TOS_LDS_FLOATS (2048 + 1008 + 1008)
+#define NMX_TOS_LDS_FLOATS (2048 + 1008)
 static inline bool nmx_timeosc_stft500_ok(const NmxTimeOscArgs& A) {
   const NmxOsc& O = A.stft;
   if (!A.w500_tab || A.fft.enabled || A.welch.enabled || !O.enabled || A.n_bands > 8 || A.W > 2048 || A.W < 500 || (A.W & 3)) return false;
@@ -327,8 +329,8 @@ NMX_DEV void nmx_timeosc_stft500_item(const NmxTimeOscArgs& A, int w, int c, flo
   const int lane = (int)(threadIdx.x & 63);
   const int W = A.W;
   float* xs = smem;                              // [W <= 2048]
-  nmx_c2* fa = (nmx_c2*)(smem + 2048);           // [500]
-  nmx_c2* fb = (nmx_c2*)(smem + 2048 + 1008);    // [501]
+  nmx_c2* fa = (nmx_c2*)(smem + 2048);           // [500]: the transforms run in place
+  nmx_c2* fb = fa;
   float* out_row = A.out + (long long)w * A.n_outputs;
   const NmxOsc& O = A.stft;
   const int nb = A.n_bands;
