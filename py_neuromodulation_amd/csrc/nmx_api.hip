@@ -375,7 +375,9 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int nt, si
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t s) {
   be_init_once();
   if (A.method >= NMX_RAWNORM_MEDIAN && A.method != NMX_RAWNORM_POWER) {
-    const size_t lds = (size_t)24 * A.max_list + 8 * NMX_RAWNORM_ORDER_NT;
+    // lists in LDS + reduction scratch, or (lists in device memory) reduction scratch + subsample scratch
+    const size_t lds = A.lists ? (size_t)8 * NMX_RAWNORM_ORDER_NT + 4 * (2 * NMX_RAWNORM_ORDER_NT + 272)
+                               : (size_t)24 * A.max_list + 8 * NMX_RAWNORM_ORDER_NT;
     hipLaunchKernelGGL(nmx_kern_rawnorm_order, dim3(A.n_channels), dim3(NMX_RAWNORM_ORDER_NT), lds, s, A);
     const long long n = (long long)A.n_windows * A.n_channels * A.W;
     hipLaunchKernelGGL(nmx_kern_rawnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);

@@ -53,7 +53,8 @@ struct NmxRawNormArgs {
   float* sorted;
   int* cur;
   int sorted_valid;
-  int max_list;              // LDS list capacity: W + add (inserted / dropped values of one hop)
+  int max_list;              // list capacity: W + add (inserted / dropped values of one hop)
+  float* lists;              // null: the six lists live in LDS; else [C][6 max_list] in device memory (long windows)
   // "quantile": qt[n_windows][C][300] the fitted quantiles, qn[n_windows][C] how many of them (min(300, history));
   // sub[C][10000] scratch of the random subsample, seed of its hash
   double* qt;
@@ -396,13 +397,17 @@ NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem)
   float* ring = A.ring + (long long)c * A.cap;
   float* Sbuf = A.sorted + (long long)c * 2 * A.cap;
   const int ML = A.max_list;
-  float* in_raw = smem;              // [ML] this hop's new samples, time order
+  // window + hop beyond 6484 samples: the lists do not fit 160 KiB of LDS and live in device memory (L2-resident,
+  // 24 bytes per sample and channel); LDS then holds the reduction scratch and the subsample scratch only
+  float* lists = A.lists ? A.lists + (long long)c * 6 * ML : smem;
+  float* in_raw = lists;             // [ML] this hop's new samples, time order
   float* in_s = in_raw + ML;         // [ML] sorted
   float* dr_raw = in_s + ML;         // [ML] samples that left after the previous hop
   float* dr_s = dr_raw + ML;         // [ML] sorted
   int* P = (int*)(dr_s + ML);        // [ML] positions of the dropped values in the sorted history
   int* Q = P + ML;                   // [ML] insertion points of the new values
-  double* red = (double*)(Q + ML);   // [NT] reduction scratch (8-byte aligned: ML is a multiple of 2)
+  double* red = A.lists ? (double*)smem : (double*)(Q + ML);   // [NT] reduction scratch (8-byte aligned: ML is a multiple of 2)
+  int* sub_scr = A.lists ? (int*)(smem + 2 * NMX_NT) : (int*)smem;   // 2 NT + 264 ints (the merge lists are dead there)
   long long cnt = A.count[c];
   int len = A.len[c];
   int cur = A.cur[c];
@@ -505,7 +510,7 @@ NMX_DEV void nmx_rawnorm_order_item(const NmxRawNormArgs& A, int c, float* smem)
       int nqs = n_sorted;
       if (n_sorted > NMX_RAWNORM_SUBSAMPLE) {   // scikit-learn draws 10 000 of the history's rows at random
         float* sub = A.sub + (long long)c * NMX_RAWNORM_SUBSAMPLE;
-        nmx_rawnorm_subsample(S, n_sorted, sub, A.seed ^ (unsigned)((A.hop0 + w) * 2654435761u) ^ ((unsigned)c * 40503u), (int*)smem);   // (the merge lists are dead here)
+        nmx_rawnorm_subsample(S, n_sorted, sub, A.seed ^ (unsigned)((A.hop0 + w) * 2654435761u) ^ ((unsigned)c * 40503u), sub_scr);
         Qs = sub;
         nqs = NMX_RAWNORM_SUBSAMPLE;
       }

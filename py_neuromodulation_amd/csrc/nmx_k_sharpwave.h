@@ -191,6 +191,45 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
     mmin = m2;
     no_plateau = !plateau;
   } else
+  if (chunk > 64) {
+    // long windows (W > 4098): the lane's chunk does not fit one 64-bit mask pair -- count, prefix-sum, then walk the
+    // chunk again and store (the plateau walk is shared by both passes)
+    int cmax = 0, cmin = 0, bmax = 0, bmin = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {
+        int total;
+        const int base = nmx_wave_excl_sum_i(cmax | (cmin << 16), &total);
+        bmax = base & 0xffff; bmin = base >> 16;
+        *n_max = total & 0xffff;
+        *n_min = total >> 16;
+      }
+      if (i0 < i1) {
+        float prev = z[i0 - 1], cur = z[i0];
+        for (int i = i0; i < i1; ++i) {
+          const float nxt = z[i + 1];
+          const bool up = prev < cur, dn = prev > cur;
+          bool is_max = up && nxt < cur, is_min = dn && nxt > cur;
+          int ahead = i + 1;
+          if ((up || dn) && nxt == cur) {   // plateau start (rare)
+            float a = nxt;
+            while (a == cur && ahead < W - 1) { ++ahead; a = z[ahead]; }
+            is_max = up && a < cur;
+            is_min = dn && a > cur;
+          }
+          if (is_max) {
+            if (pass == 1) { if (bmax < cap) emax[bmax] = (nmx_u16)((i + ahead - 1) >> 1); ++bmax; } else ++cmax;
+          }
+          if (is_min) {
+            if (pass == 1) { if (bmin < cap) emin[bmin] = (nmx_u16)((i + ahead - 1) >> 1); ++bmin; } else ++cmin;
+          }
+          prev = cur;
+          cur = nxt;
+        }
+      }
+    }
+    NMX_SYNC();
+    return;
+  } else
   if (i0 < i1) {
     float prev = z[i0 - 1], cur = z[i0];
     for (int i = i0; i < i1; ++i) {
@@ -698,10 +737,12 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     // pairing (sharpwaves.py:347-374): ptr = first peak at or after the trough
     int n_leftinv = 0, lastv = 0;
     n_pairs = 0;
+    int step0 = 1024;
+    while (2 * step0 <= nPk) step0 *= 2;   // wave-uniform; only windows beyond 4092 samples get here
     for (int i = NMX_TID; i < nTr; i += NMX_NT) {
       const int t = tr[i];
-      int lo = 0;   // number of peaks before t: branch-free bisection (nPk < 2048)
-      for (int step = 1024; step > 0; step >>= 1) {
+      int lo = 0;   // number of peaks before t: branch-free bisection (nPk < 2 * step0)
+      for (int step = step0; step > 0; step >>= 1) {
         const int idx = lo + step;
         lo = (idx <= nPk && (int)pk[idx - 1] < t) ? idx : lo;
       }

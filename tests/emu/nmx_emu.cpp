@@ -125,7 +125,7 @@ static void be_launch_resample(const NmxResampleArgs& A, int n_items, int, size_
 }
 static void be_launch_rawnorm(const NmxRawNormArgs& A, be_stream_t) {
   if (A.method >= NMX_RAWNORM_MEDIAN && A.method != NMX_RAWNORM_POWER) {
-    std::vector<float> sm(6 * (size_t)A.max_list + 2 * NMX_RAWNORM_ORDER_NT + 16);
+    std::vector<float> sm(6 * (size_t)A.max_list + 4 * NMX_RAWNORM_ORDER_NT + 288);
     for (int c = 0; c < A.n_channels; ++c) nmx_rawnorm_order_item(A, c, sm.data());
   } else
   for (int c = 0; c < A.n_channels; ++c) nmx_rawnorm_stats_item(A, c);

@@ -640,6 +640,60 @@ def case_ragged_bursts():
     print("ragged_bursts", df.shape, sorted(set(lens)))
 
 
+def case_long_windows():
+    """Windows beyond two former kernel limits, at 7 kHz with 1 s windows (7000 samples) and 10 Hz features (700-sample
+    hops): (sw) sharp waves on windows of more than 4092 samples -- the default settings, and every feature with
+    median / var estimators and the estimator applied per polarity; the second channel is coarsely quantised
+    (plateaus).  (rn) raw_normalization with the order-statistic methods where window + hop = 7700 > 6484 samples
+    (0.9 s history: the N - 1 trim acts every hop), in front of fft + return_raw.  The reference's own Stream.run."""
+    rng = np.random.default_rng(707)
+    sfreq = 7000
+    T = 7000 + 9 * 700
+    t = np.arange(T) / sfreq
+    data = np.cumsum(rng.standard_normal((2, T)), axis=1) * 0.05 + rng.standard_normal((2, T)) * 0.5
+    data += 6 * np.sin(2 * np.pi * 11 * t) + 3 * np.sin(2 * np.pi * 47 * t + 1.0)
+    data[1] = np.round(data[1] * 1.5) / 1.5
+    out = {"sfreq": sfreq, "data": data.astype(np.float32)}   # (float32-exact inputs: half the fixture)
+    data = out["data"].astype(np.float64)
+
+    def base():
+        s = nm.NMSettings.get_default()
+        s.reset()
+        s.preprocessing = []
+        s.postprocessing.feature_normalization = False
+        return s
+
+    for tag in ("sw_default", "sw_all"):
+        s = base()
+        s.features.sharpwave_analysis = True
+        if tag == "sw_all":
+            sharpwave_all(s)
+            s.sharpwave_analysis_settings.apply_estimator_between_peaks_and_troughs = False
+        st, df = _run_stream(data, sfreq, s)
+        sw = nm.features.SharpwaveAnalyzer(st.settings, ["ch0", "ch1"], sfreq)
+        out.update({f"{tag}_settings_json": dump(st.settings), f"{tag}_columns": np.array(list(df.columns)),
+                    f"{tag}_values": df.to_numpy(dtype=np.float64),
+                    f"{tag}_channels_json": json.dumps(st.channels.to_dict("list"))})
+        for i, (_, taps) in enumerate(sw.list_filter):
+            out[f"sw_taps_{i}"] = np.asarray(taps)
+        print("long_windows", tag, df.shape)
+    for method in ("median", "zscore-median", "robust", "minmax"):
+        s = base()
+        s.features.fft = True
+        s.features.return_raw = True
+        s.preprocessing = ["raw_normalization"]
+        s.raw_normalization_settings.normalization_time_s = 0.9
+        s.raw_normalization_settings.normalization_method = method
+        s.raw_normalization_settings.clip = 3
+        st, df = _run_stream(data + 20.0, sfreq, s)    # (offset: "median" divides by the median)
+        tag = "rn_" + method.replace("-", "_")
+        out.update({f"{tag}_settings_json": dump(st.settings), f"{tag}_columns": np.array(list(df.columns)),
+                    f"{tag}_values": df.to_numpy(dtype=np.float64),
+                    f"{tag}_channels_json": json.dumps(st.channels.to_dict("list"))})
+        print("long_windows", tag, df.shape)
+    np.savez_compressed(HERE / "long_windows.npz", **out)
+
+
 def case_user_features():
     """User-registered NMFeature plugins (features/feature_processor.py:52-53,90-108; the plugin of
     examples/plot_2_example_add_feature.py is tests/user_plugins.ChannelMean): the reference's own Stream.run with
@@ -706,6 +760,7 @@ if __name__ == "__main__":
     case_bursts_sequence()
     case_c5_degenerate()
     case_sharpwave_tests()
+    case_long_windows()
     case_pipeline()
     case_nan_and_channels()
     case_notch()

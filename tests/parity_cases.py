@@ -2006,3 +2006,41 @@ def case_ragged_bursts(lib):
         n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[i, :-1], s, sfreq, 60.0, 1111, verifier=pv.row(i))
         assert n_bad == 0, f"hop {i}\n{rep}"
     np.testing.assert_array_equal(got[:, -1], want[:, -1])
+
+
+def case_long_windows(lib, tags=("sw_default", "sw_all", "rn_median", "rn_zscore_median", "rn_robust", "rn_minmax")):
+    """Windows of 7000 samples (reference golden tests/golden/long_windows.npz, 7 kHz, 700-sample hops): sharp waves
+    beyond 4092 samples (per-lane chunks of more than 64 samples take the two-pass extrema walk, the lists are sized by the
+    window) and the order-statistic raw normalisers beyond window + hop = 6484 samples (their merge lists move from LDS
+    to device memory)."""
+    import json
+
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("long_windows")
+    sfreq, data = float(g["sfreq"]), g["data"].astype(np.float64)
+    for tag in tags:
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        ch = json.loads(str(g[f"{tag}_channels_json"]))
+        x = data + 20.0 if tag.startswith("rn_") else data
+        df = Stream(sfreq, channels=ch, settings=s, line_noise=50, lib=lib).run(x, save_csv=False)
+        cols = [str(c) for c in g[f"{tag}_columns"]]
+        assert list(df.columns) == cols, tag
+        got, want = df.to_numpy(float), g[f"{tag}_values"]
+        assert got.shape == want.shape, tag
+        np.testing.assert_array_equal(got[:, -1], want[:, -1])
+        starts, ends, _ = orc.window_schedule(x.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        if tag.startswith("rn_"):
+            # z-scores of fp32 samples against float64 order statistics (case_raw_normalizer's tolerance); the fft
+            # columns are log10 of band means of the normalised window
+            raw = [j for j, c in enumerate(cols[:-1]) if c.endswith("_raw")]
+            oth = [j for j, c in enumerate(cols[:-1]) if not c.endswith("_raw")]
+            np.testing.assert_allclose(got[:, raw], want[:, raw], rtol=2e-5, atol=5e-6, err_msg=tag)
+            np.testing.assert_allclose(got[:, oth], want[:, oth], rtol=2e-5, atol=2e-5, err_msg=tag)
+            continue
+        pv = parity.PipelineVerifiers(s, ch, sfreq, x, starts, 7000, line_noise=50, ends=ends)
+        for i in range(len(got)):
+            n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[i, :-1], s, sfreq, 20.0, 7000, verifier=pv.row(i))
+            assert n_bad == 0, f"{tag} hop {i}\n{rep}"

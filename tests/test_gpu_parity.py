@@ -452,6 +452,17 @@ def test_ragged_windows_carry_burst_and_kalman_state(gpu_lib):
     pc.case_ragged_bursts(gpu_lib)
 
 
+def test_long_windows_sharp_waves_and_order_normalisers(gpu_lib):
+    pc.case_long_windows(gpu_lib)
+
+
+def test_raw_order_normalisers_with_lists_in_device_memory(gpu_lib, monkeypatch):
+    """The reference goldens of the order-statistic raw normalisers (1000-sample windows) with the merge lists forced
+    into device memory -- the layout windows beyond 6484 samples take."""
+    monkeypatch.setenv("NMX_RAWNORM_GLOBAL_LISTS", "1")
+    pc.case_raw_normalizer_order_methods(gpu_lib)
+
+
 def test_odd_windows_and_spectra(gpu_lib):
     pc.case_odd_windows_and_spectra(gpu_lib)
 

@@ -216,3 +216,12 @@ def test_user_registered_features(emu_lib):
 
 def test_ragged_windows_carry_burst_and_kalman_state(emu_lib):
     pc.case_ragged_bursts(emu_lib)
+
+
+def test_long_windows_sharp_waves_and_order_normalisers(emu_lib):
+    pc.case_long_windows(emu_lib)
+
+
+def test_raw_order_normalisers_with_lists_in_device_memory(emu_lib, monkeypatch):
+    monkeypatch.setenv("NMX_RAWNORM_GLOBAL_LISTS", "1")
+    pc.case_raw_normalizer_order_methods(emu_lib)
