@@ -1286,7 +1286,7 @@ def random_settings(seed):
         on = [f for f in fams if rng.random() < 0.55]
         if not on:
             on = ["fft"]
-        if seg_ms < 500 or sfreq * seg_ms / 1000 > 4092:   # (the sharp-wave kernel takes windows up to 4092 samples)
+        if seg_ms < 500 or sfreq * seg_ms / 1000 > 14000:   # (the sharp-wave kernel takes windows up to ~14 500 samples: LDS)
             on = [f for f in on if f != "sharpwave_analysis"] or ["fft"]
         # (ragged window LENGTHS -- a non-integer segment -- run one plan per length; the burst history and the Kalman
         # filters travel between them: case_ragged_bursts)
@@ -1553,8 +1553,10 @@ def random_settings_wide(seed):
                 "sharpwave_analysis", "bursts"]
         on = [f for f in fams if rng.random() < 0.5] or ["fft"]
         W = int(sfreq * seg_ms / 1000)
-        if W > 4092 or seg_ms < 1000 and "welch" in on:
-            on = [f for f in on if f not in ("sharpwave_analysis", "welch")] or ["fft"]
+        if W > 14000:
+            on = [f for f in on if f != "sharpwave_analysis"] or ["fft"]
+        if seg_ms < 1000 and "welch" in on:
+            on = [f for f in on if f != "welch"] or ["fft"]
         if (sfreq * seg_ms / 1000) % 1 or "raw_resampling" in pre or W > 6000:   # (W > 6000: the Hilbert stage of the generic
             on = [f for f in on if f != "bursts"] or ["fft"]                 # bank kernel needs 2 x 8 W bytes of LDS)
         for f in on:
@@ -1612,8 +1614,8 @@ def random_settings_wide(seed):
             pre.append("preprocessing_filter")
             for f in ("bandstop_filter", "bandpass_filter", "lowpass_filter", "highpass_filter"):
                 setattr(s.preprocessing_filter, f, bool(rng.random() < 0.5))
-        # (the order-statistic raw normalisers keep window + hop samples in LDS lists: <= 6484)
-        raw_norm = bool(rng.random() < 0.15) and "raw_resampling" not in pre and W + sfreq / feat_hz <= 6400
+        # (window + hop beyond 6484 samples: the order-statistic normalisers keep their merge lists in device memory)
+        raw_norm = bool(rng.random() < 0.15) and "raw_resampling" not in pre
         if raw_norm:
             pre.append("raw_normalization")
             # ("mean" / "median" divide by the centre: ill-conditioned on re-referenced, near-zero-mean rows; they are
