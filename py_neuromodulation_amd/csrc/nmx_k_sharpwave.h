@@ -144,35 +144,53 @@ NMX_DEV void nmx_extrema(const float* z, int W, nmx_u16* emax, nmx_u16* emin, in
   const int i1 = (i0 + chunk) < (W - 1) ? (i0 + chunk) : (W - 1);
   unsigned long long mmax = 0ull, mmin = 0ull;
   bool no_plateau = false;   // this lane saw no plateau start: every extremum is its own midpoint
-  if (chunk == 16 && NMX_NT == 64) {
-    // default window (962 < W <= 1026): the lane's 16 positions and their two neighbours are 18 consecutive
-    // floats starting at the 64-byte aligned z[16 lane] -- four 16-byte LDS reads + one 8-byte read instead
-    // of 17 dword reads, and 32-bit masks built from compile-time bit constants
+  if ((chunk == 16 || chunk == 8) && NMX_NT == 64) {
+    // default window (962 < W <= 1026; 450 < W <= 514 at chunk 8: BASELINE config 5): the lane's positions and their two
+    // neighbours are chunk + 2 consecutive floats starting at the aligned z[chunk lane] -- 16-byte LDS reads + one 8-byte
+    // read instead of chunk + 1 dword reads, and 32-bit masks built from compile-time bit constants
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     float sv[18];
-    const f4* q4 = (const f4*)(z + 16 * NMX_TID);
+    unsigned m1 = 0u, m2 = 0u;
+    bool plateau = false;
+    if (chunk == 16) {
+      const f4* q4 = (const f4*)(z + 16 * NMX_TID);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f4 t = q4[g];
-      sv[4 * g] = t.x; sv[4 * g + 1] = t.y; sv[4 * g + 2] = t.z; sv[4 * g + 3] = t.w;
-    }
-    {
+      for (int g = 0; g < 4; ++g) {
+        const f4 t = q4[g];
+        sv[4 * g] = t.x; sv[4 * g + 1] = t.y; sv[4 * g + 2] = t.z; sv[4 * g + 3] = t.w;
+      }
       // (the last lane's tail lies beyond the window: the list / scratch region that follows z in LDS is
       // readable, the values are masked out below)
       const f2 t = *(const f2*)(z + 16 * NMX_TID + 16);
       sv[16] = t.x; sv[17] = t.y;
-    }
-    unsigned m1 = 0u, m2 = 0u;
-    bool plateau = false;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const bool in = (i0 + k) < i1;
-      const float prev = sv[k], cur = sv[k + 1], nxt = sv[k + 2];
-      const bool up = in && prev < cur, dn = in && prev > cur;
-      m1 |= (up && nxt < cur) ? (1u << k) : 0u;
-      m2 |= (dn && nxt > cur) ? (1u << k) : 0u;
-      plateau = plateau || ((up || dn) && nxt == cur);
+      for (int k = 0; k < 16; ++k) {
+        const bool in = (i0 + k) < i1;
+        const float prev = sv[k], cur = sv[k + 1], nxt = sv[k + 2];
+        const bool up = in && prev < cur, dn = in && prev > cur;
+        m1 |= (up && nxt < cur) ? (1u << k) : 0u;
+        m2 |= (dn && nxt > cur) ? (1u << k) : 0u;
+        plateau = plateau || ((up || dn) && nxt == cur);
+      }
+    } else {
+      const f4* q4 = (const f4*)(z + 8 * NMX_TID);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f4 t = q4[g];
+        sv[4 * g] = t.x; sv[4 * g + 1] = t.y; sv[4 * g + 2] = t.z; sv[4 * g + 3] = t.w;
+      }
+      const f2 t = *(const f2*)(z + 8 * NMX_TID + 8);
+      sv[8] = t.x; sv[9] = t.y;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool in = (i0 + k) < i1;
+        const float prev = sv[k], cur = sv[k + 1], nxt = sv[k + 2];
+        const bool up = in && prev < cur, dn = in && prev > cur;
+        m1 |= (up && nxt < cur) ? (1u << k) : 0u;
+        m2 |= (dn && nxt > cur) ? (1u << k) : 0u;
+        plateau = plateau || ((up || dn) && nxt == cur);
+      }
     }
     if (plateau) {   // rare: resolve plateau starts with the generic walk
       for (int i = i0; i < i1; ++i) {
@@ -370,41 +388,47 @@ NMX_DEV void nmx_select2(const float* z, NmxSelProb* P) {
 #ifndef NMX_HOST_EMU
 struct NmxMask128 { unsigned long long a, b; };   // elements 0..63, 64..127
 
-NMX_DEV unsigned nmx_bit128(const NmxMask128& K, int e) {   // element e of the set; 0 outside [0, 128)
+// NSL = 1: windows with at most 64 extrema of each kind -- one slot per lane, K.b is empty (every helper below is
+// compiled for both: about half the instructions of the selection / pairing / estimator phases for such a window)
+template <int NSL>
+NMX_DEV unsigned nmx_bit128(const NmxMask128& K, int e) {   // element e of the set; 0 outside [0, 64 NSL)
+  if (NSL == 1) return ((unsigned)e < 64u) ? (unsigned)((K.a >> (e & 63)) & 1ull) : 0u;
   const unsigned long long w = e < 64 ? K.a : K.b;
   return ((unsigned)e < 128u) ? (unsigned)((w >> (e & 63)) & 1ull) : 0u;
 }
 // bits (4 - d) <- element e - d and bits (d - 1) <- element e + d, d = 1..4
+template <int NSL>
 NMX_DEV void nmx_win128(const NmxMask128& K, int e, unsigned* wl, unsigned* wr) {
   unsigned l = 0, r = 0;
 #pragma unroll
   for (int d = 1; d <= 4; ++d) {
-    l |= nmx_bit128(K, e - d) << (4 - d);
-    r |= nmx_bit128(K, e + d) << (d - 1);
+    l |= nmx_bit128<NSL>(K, e - d) << (4 - d);
+    r |= nmx_bit128<NSL>(K, e + d) << (d - 1);
   }
   *wl = l; *wr = r;
 }
 
 // SciPy _select_by_peak_distance as a fixed point: an extremum is removed iff a higher-priority
 // neighbour inside the distance is kept, kept iff all of them are removed (hl / hr: those neighbours)
+template <int NSL>
 NMX_DEV NmxMask128 nmx_dense_fixpoint(const bool* valid, const unsigned* hl, const unsigned* hr, int lane) {
   int s0 = !valid[0] ? 2 : ((hl[0] | hr[0]) == 0u ? 1 : 0);
-  int s1 = !valid[1] ? 2 : ((hl[1] | hr[1]) == 0u ? 1 : 0);
+  int s1 = (NSL == 1 || !valid[1]) ? 2 : ((hl[1] | hr[1]) == 0u ? 1 : 0);
   for (;;) {
     NmxMask128 K, U;
-    K.a = __ballot(s0 == 1); K.b = __ballot(s1 == 1);
-    U.a = __ballot(s0 == 0); U.b = __ballot(s1 == 0);
+    K.a = __ballot(s0 == 1); K.b = NSL == 1 ? 0ull : __ballot(s1 == 1);
+    U.a = __ballot(s0 == 0); U.b = NSL == 1 ? 0ull : __ballot(s1 == 0);
     if ((U.a | U.b) == 0ull) return K;
     unsigned kl, kr, ul, ur;
     if (s0 == 0) {
-      nmx_win128(K, lane, &kl, &kr);
-      nmx_win128(U, lane, &ul, &ur);
+      nmx_win128<NSL>(K, lane, &kl, &kr);
+      nmx_win128<NSL>(U, lane, &ul, &ur);
       const bool removed = ((kl & hl[0]) | (kr & hr[0])) != 0u, wait = ((ul & hl[0]) | (ur & hr[0])) != 0u;
       s0 = removed ? 2 : (wait ? 0 : 1);
     }
-    if (s1 == 0) {
-      nmx_win128(K, 64 + lane, &kl, &kr);
-      nmx_win128(U, 64 + lane, &ul, &ur);
+    if (NSL == 2 && s1 == 0) {
+      nmx_win128<NSL>(K, 64 + lane, &kl, &kr);
+      nmx_win128<NSL>(U, 64 + lane, &ul, &ur);
       const bool removed = ((kl & hl[1]) | (kr & hr[1])) != 0u, wait = ((ul & hl[1]) | (ur & hr[1])) != 0u;
       s1 = removed ? 2 : (wait ? 0 : 1);
     }
@@ -419,8 +443,14 @@ struct NmxDenseSel {
 };
 
 // neighbours at element distance d of both slots: rotations by d lanes wrap slot 0 into slot 1
-template <typename T>
+template <int NSL, typename T>
 NMX_DEV void nmx_dense_nb(const T* v, int d, int lane, T* left, T* right) {
+  if (NSL == 1) {   // (wrapped values are never used: the callers test e >= d and e + d < n <= 64)
+    left[0] = __shfl(v[0], (lane - d) & 63);
+    right[0] = __shfl(v[0], (lane + d) & 63);
+    left[1] = left[0]; right[1] = right[0];
+    return;
+  }
   const T a_dn = __shfl(v[0], (lane - d) & 63), b_dn = __shfl(v[1], (lane - d) & 63);
   const T a_up = __shfl(v[0], (lane + d) & 63), b_up = __shfl(v[1], (lane + d) & 63);
   left[0] = a_dn;                          // element lane - d          (valid when lane >= d)
@@ -429,13 +459,15 @@ NMX_DEV void nmx_dense_nb(const T* v, int d, int lane, T* left, T* right) {
   right[1] = b_up;                         // element 64 + lane + d     (valid when lane + d < 64)
 }
 
+template <int NSL>
 NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16* emin, int n_max, int n_min,
                               int dp, int dt, NmxDenseSel& D) {
   const int lane = NMX_TID;
-  bool vmax[2], vmin[2];
-  float qmax[2], qmin[2];   // priorities (heights)
+  bool vmax[2] = {false, false}, vmin[2] = {false, false};
+  float qmax[2] = {0.f, 0.f}, qmin[2] = {0.f, 0.f};   // priorities (heights)
+  D.pmax[1] = 0; D.pmin[1] = 0;
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int e = 64 * sl + lane;
     vmax[sl] = e < n_max; vmin[sl] = e < n_min;
     D.pmax[sl] = vmax[sl] ? (int)emax[e] : 0;
@@ -448,11 +480,11 @@ NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16
 #pragma unroll
   for (int d = 1; d <= 4; ++d) {
     int aL[2], aR[2], bL[2], bR[2];
-    nmx_dense_nb(D.pmax, d, lane, aL, aR);
-    nmx_dense_nb(D.pmin, d, lane, bL, bR);
+    nmx_dense_nb<NSL>(D.pmax, d, lane, aL, aR);
+    nmx_dense_nb<NSL>(D.pmin, d, lane, bL, bR);
     bool maxL[2], maxR[2], minL[2], minR[2], any = false;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < NSL; ++sl) {
       const int e = 64 * sl + lane;
       maxL[sl] = vmax[sl] && e >= d; maxR[sl] = vmax[sl] && e + d < n_max;
       minL[sl] = vmin[sl] && e >= d; minR[sl] = vmin[sl] && e + d < n_min;
@@ -461,11 +493,11 @@ NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16
     }
     if (!__any(any)) break;   // wave-uniform: farther neighbours are farther away
     float qaL[2], qaR[2], qbL[2], qbR[2];
-    nmx_dense_nb(qmax, d, lane, qaL, qaR);
-    nmx_dense_nb(qmin, d, lane, qbL, qbR);
+    nmx_dense_nb<NSL>(qmax, d, lane, qaL, qaR);
+    nmx_dense_nb<NSL>(qmin, d, lane, qbL, qbR);
     const unsigned bl = 1u << (4 - d), br = 1u << (d - 1);
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < NSL; ++sl) {
       // strictly higher on the left, higher-or-equal on the right: equal heights -> the later one wins
       const bool hAL = maxL[sl] && qaL[sl] > qmax[sl], hAR = maxR[sl] && qaR[sl] >= qmax[sl];
       const bool hBL = minL[sl] && qbL[sl] > qmin[sl], hBR = minR[sl] && qbR[sl] >= qmin[sl];
@@ -477,10 +509,10 @@ NMX_DEV void nmx_dense_select(const float* z, const nmx_u16* emax, const nmx_u16
       hl[2][sl] |= (hBL && gbL < dp) ? bl : 0u; hr[2][sl] |= (hBR && gbR < dp) ? br : 0u;
     }
   }
-  D.K[0] = nmx_dense_fixpoint(vmax, hl[0], hr[0], lane);
-  D.K[1] = nmx_dense_fixpoint(vmin, hl[1], hr[1], lane);
-  D.K[2] = nmx_dense_fixpoint(vmin, hl[2], hr[2], lane);
-  D.K[3] = nmx_dense_fixpoint(vmax, hl[3], hr[3], lane);
+  D.K[0] = nmx_dense_fixpoint<NSL>(vmax, hl[0], hr[0], lane);
+  D.K[1] = nmx_dense_fixpoint<NSL>(vmin, hl[1], hr[1], lane);
+  D.K[2] = nmx_dense_fixpoint<NSL>(vmin, hl[2], hr[2], lane);
+  D.K[3] = nmx_dense_fixpoint<NSL>(vmax, hl[3], hr[3], lane);
 }
 
 NMX_DEV int nmx_mbcnt64(unsigned long long m) {   // set bits of m below this lane
@@ -489,6 +521,7 @@ NMX_DEV int nmx_mbcnt64(unsigned long long m) {   // set bits of m below this la
 
 // compaction of the kept peaks / troughs into selP / selT, pairing (sharpwaves.py:347-374) and the
 // (left, right) peak lists; returns the same quantities as the generic code path
+template <int NSL>
 NMX_DEV void nmx_dense_pair_bisect(const NmxMask128& KP, const int* ppos, const NmxMask128& KT, const int* tpos,
                             nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
                             int* nTr_out, int* n_pairs_out, int* first_valid_out, int* nT_out) {
@@ -496,21 +529,21 @@ NMX_DEV void nmx_dense_pair_bisect(const NmxMask128& KP, const int* ppos, const 
   const int nPa = __popcll(KP.a), nTa = __popcll(KT.a);
   const int nPk = nPa + __popcll(KP.b), nTr = nTa + __popcll(KT.b);
   if ((KP.a >> lane) & 1ull) selP[nmx_mbcnt64(KP.a)] = (nmx_u16)ppos[0];
-  if ((KP.b >> lane) & 1ull) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
+  if (NSL == 2 && ((KP.b >> lane) & 1ull)) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
   if ((KT.a >> lane) & 1ull) selT[nmx_mbcnt64(KT.a)] = (nmx_u16)tpos[0];
-  if ((KT.b >> lane) & 1ull) selT[nTa + nmx_mbcnt64(KT.b)] = (nmx_u16)tpos[1];
+  if (NSL == 2 && ((KT.b >> lane) & 1ull)) selT[nTa + nmx_mbcnt64(KT.b)] = (nmx_u16)tpos[1];
   NMX_SYNC();
-  // number of kept peaks before each of this lane's troughs (nPk <= 128: 8 bisection steps)
-  int lo[2];
-  unsigned long long L0[2], Vm[2];
+  // number of kept peaks before each of this lane's troughs (nPk <= 64 NSL: 7 or 8 bisection steps)
+  int lo[2] = {0, 0};
+  unsigned long long L0[2] = {0ull, 0ull}, Vm[2] = {0ull, 0ull};
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int i = 64 * sl + lane;
     const bool has_t = i < nTr;
     const int t = has_t ? (int)selT[i] : 0;
     int l = 0;
 #pragma unroll
-    for (int step = 128; step > 0; step >>= 1) {
+    for (int step = 64 * NSL; step > 0; step >>= 1) {
       const int idx = l + step;
       l = (idx <= nPk && (int)selP[idx <= nPk ? idx - 1 : 0] < t) ? idx : l;
     }
@@ -526,13 +559,13 @@ NMX_DEV void nmx_dense_pair_bisect(const NmxMask128& KP, const int* ppos, const 
   NMX_SYNC();
   int lp[2];
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int p = 64 * sl + lane;
     lp[sl] = p < n_pairs ? (int)lf[first_valid + p] : 1;
   }
   NMX_SYNC();   // lf[] is overwritten with the left peaks only after every pointer was read
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int p = 64 * sl + lane;
     if (p < n_pairs) {
       rt[p] = selP[lp[sl]];
@@ -555,6 +588,7 @@ NMX_DEV int nmx_popc_below128(const NmxMask128& K, int r) {
 // before raw trough e is e or e + 1 (whichever kind comes first) and the number of KEPT peaks before
 // it is a popcount of the keep mask below that index.  The alternation is verified against the raw
 // lists (two independent LDS reads per trough); if it ever fails the bisection version runs instead.
+template <int NSL>
 NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const nmx_u16* rawP, int n_rawP,
                             const NmxMask128& KT, const int* tpos, int n_rawT,
                             nmx_u16* selP, nmx_u16* selT, nmx_u16* lf, nmx_u16* rt,
@@ -562,10 +596,10 @@ NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const nmx_u16
   const int lane = NMX_TID;
   const int off = (n_rawP > 0 && n_rawT > 0 && __builtin_amdgcn_readfirstlane(ppos[0]) <
                                                    __builtin_amdgcn_readfirstlane(tpos[0])) ? 1 : 0;
-  int lo[2];
+  int lo[2] = {0, 0};
   bool ok = true;
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int e = 64 * sl + lane;
     const int r = e + off;
     const bool has = e < n_rawT;
@@ -579,14 +613,14 @@ NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const nmx_u16
     lo[sl] = nmx_popc_below128(KP, r);
   }
   if (!__all(ok)) {   // wave-uniform; never seen on real or synthetic data
-    nmx_dense_pair_bisect(KP, ppos, KT, tpos, selP, selT, lf, rt, nTr_out, n_pairs_out, first_valid_out, nT_out);
+    nmx_dense_pair_bisect<NSL>(KP, ppos, KT, tpos, selP, selT, lf, rt, nTr_out, n_pairs_out, first_valid_out, nT_out);
     return;
   }
   const int nPa = __popcll(KP.a), nTa = __popcll(KT.a);
   const int nPk = nPa + __popcll(KP.b), nTr = nTa + __popcll(KT.b);
   if ((KP.a >> lane) & 1ull) selP[nmx_mbcnt64(KP.a)] = (nmx_u16)ppos[0];
-  if ((KP.b >> lane) & 1ull) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
-  const bool k0 = (KT.a >> lane) & 1ull, k1 = (KT.b >> lane) & 1ull;
+  if (NSL == 2 && ((KP.b >> lane) & 1ull)) selP[nPa + nmx_mbcnt64(KP.b)] = (nmx_u16)ppos[1];
+  const bool k0 = (KT.a >> lane) & 1ull, k1 = NSL == 2 && ((KT.b >> lane) & 1ull);
   if (k0) { const int rk = nmx_mbcnt64(KT.a); selT[rk] = (nmx_u16)tpos[0]; lf[rk] = (nmx_u16)lo[0]; }
   if (k1) { const int rk = nTa + nmx_mbcnt64(KT.b); selT[rk] = (nmx_u16)tpos[1]; lf[rk] = (nmx_u16)lo[1]; }
   const unsigned long long L0a = __ballot(k0 && lo[0] == 0), L0b = __ballot(k1 && lo[1] == 0);
@@ -602,13 +636,13 @@ NMX_DEV void nmx_dense_pair(const NmxMask128& KP, const int* ppos, const nmx_u16
   NMX_SYNC();
   int lp[2];
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int p = 64 * sl + lane;
     lp[sl] = p < n_pairs ? (int)lf[first_valid + p] : 1;
   }
   NMX_SYNC();   // lf[] is overwritten with the left peaks only after every pointer was read
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < NSL; ++sl) {
     const int p = 64 * sl + lane;
     if (p < n_pairs) {
       rt[p] = selP[lp[sl]];
@@ -646,6 +680,67 @@ NMX_DEV float nmx_sw_pair(int est, float a, float b) {
     default: { const float m = 0.5f * (a + b); return 0.5f * ((a - m) * (a - m) + (b - m) * (b - m)); }
   }
 }
+
+#ifndef NMX_HOST_EMU
+// fast estimators of one polarity with at most 64 NSL troughs / pairs: NSL entries per lane
+template <int NSL>
+NMX_DEV void nmx_sw_fast_est(const NmxSharpArgs& A, const float* z, float sgn, const nmx_u16* trv, const nmx_u16* lf,
+                             const nmx_u16* rt, int nT, int n_pairs, int nPT, int W, int s_off, float* res, int pol) {
+  // at most two entries per lane: gather the list entries and the samples they point at ONCE,
+  // then every (feature, estimator) pair is register arithmetic + one reduction
+  int tq[2] = {0, 0}, lq[2] = {0, 0}, rq[2] = {0, 0}, tprev[2] = {0, 0};
+  float zt[2], zl[2], zr[2], zm[2], zp[2];
+  bool okT[2], okP[2], okS[2];
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    const int p = NMX_TID + 64 * sl;
+    okT[sl] = p < nT; okP[sl] = p < n_pairs;
+    tq[sl] = okT[sl] ? (int)trv[p] : 0;
+    tprev[sl] = (okT[sl] && p > 0) ? (int)trv[p - 1] : tq[sl];
+    lq[sl] = okP[sl] ? (int)lf[p] : 0;
+    rq[sl] = okP[sl] ? (int)rt[p] : 0;
+    okS[sl] = okT[sl] && (tq[sl] - s_off > 0) && (tq[sl] + s_off < W);
+    zt[sl] = sgn * z[tq[sl]]; zl[sl] = sgn * z[lq[sl]]; zr[sl] = sgn * z[rq[sl]];
+    zm[sl] = okS[sl] ? sgn * z[tq[sl] - s_off] : 0.f;
+    zp[sl] = okS[sl] ? sgn * z[tq[sl] + s_off] : 0.f;
+  }
+  for (int cb = 0; cb < A.n_combos; ++cb) {
+    const int f = A.combo_feature[cb], e = A.combo_est[cb];
+    if (f == NMX_SW_NUM_PEAKS) continue;
+    float acc = e == NMX_SWE_MEAN ? 0.f : (e == NMX_SWE_MAX ? -INFINITY : INFINITY);
+    bool has_nan = false;
+    int cnt = 0;   // entries that take part: counted with ballots (scalar), not reduced
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      const bool pt = okP[sl] && (NMX_TID + 64 * sl) < nPT;   // arrays that pair troughs with peaks
+      float v;
+      bool ok;
+      switch (f) {
+        case NMX_SW_PEAK_LEFT: v = zl[sl]; ok = okP[sl]; break;
+        case NMX_SW_PEAK_RIGHT: v = zr[sl]; ok = okP[sl]; break;
+        case NMX_SW_TROUGH: v = zt[sl]; ok = okT[sl]; break;
+        case NMX_SW_WIDTH: v = (float)(rq[sl] - lq[sl]); ok = okP[sl]; break;
+        case NMX_SW_PROMINENCE: v = fabsf((zr[sl] + zl[sl]) * 0.5f - zt[sl]); ok = pt; break;
+        case NMX_SW_INTERVAL: v = (float)(tq[sl] - tprev[sl]) * A.ms; ok = okT[sl]; break;
+        case NMX_SW_DECAY_TIME: v = (float)(lq[sl] - tq[sl]) * A.ms; ok = pt; break;
+        case NMX_SW_RISE_TIME: v = (float)(rq[sl] - tq[sl]) * A.ms; ok = pt; break;
+        default: v = zt[sl] - 0.5f * (zm[sl] + zp[sl]); ok = okS[sl]; break;   // NMX_SW_SHARPNESS
+      }
+      cnt += __popcll(__ballot(ok));
+      // max / min through the hardware instruction (it skips a NaN operand); np.max / np.min propagate NaN: one
+      // flag per lane, one ballot per estimator -- the NaN-propagating form was five instructions per step of the
+      // DPP reduction, 36 per estimator
+      has_nan = has_nan || (ok && v != v);
+      if (ok) acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_vmax(acc, v) : nmx_vmin(acc, v));
+    }
+    if (e == NMX_SWE_MEAN) acc = nmx_wave_reduce(acc, 0.f, [](float a, float b) { return a + b; });
+    else if (e == NMX_SWE_MAX) acc = nmx_wave_reduce(acc, -INFINITY, [](float a, float b) { return nmx_vmax(a, b); });
+    else acc = nmx_wave_reduce(acc, INFINITY, [](float a, float b) { return nmx_vmin(a, b); });
+    if (e != NMX_SWE_MEAN && __ballot(has_nan)) acc = NAN;
+    if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
+  }
+}
+#endif
 
 // one WAVE per (window, channel, filter)
 // LDS working set of one item (pointers, so that the analysis can also run inside the FIR-bank
@@ -706,8 +801,17 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   // wave-uniform: the register-resident path applies (else the generic list code below)
   const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128;
   if (dense_only && !dense) return false;
+  // at most 64 extrema of each kind (wave-uniform): one slot per lane
+#ifdef NMX_SW_NO_ONE_SLOT   // (experiment: the two-slot code only -- 20 % less code, more instructions per small window)
+  const bool one = false;
+#else
+  const bool one = n_max <= 64 && n_min <= 64;
+#endif
   NmxDenseSel D;
-  if (dense) nmx_dense_select(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
+  if (dense) {
+    if (one) nmx_dense_select<1>(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
+    else nmx_dense_select<2>(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
+  }
 #endif
   NMX_SWP(2)   // distance selection
   for (int pol = 0; pol < 2; ++pol) {
@@ -716,11 +820,16 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
     // peaks of sgn*z with distance_peaks, troughs (= peaks of -sgn*z) with distance_troughs
     int nTr = 0, n_pairs = 0, first_valid = 0, nT = 0;
 #ifndef NMX_HOST_EMU
-    if (dense) {
-      nmx_dense_pair(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin, pol == 0 ? emax : emin,
-                     pol == 0 ? n_max : n_min,
-                     pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax, pol == 0 ? n_min : n_max,
-                     selP, selT, lf, rt, &nTr, &n_pairs, &first_valid, &nT);
+    if (dense && one) {
+      nmx_dense_pair<1>(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin, pol == 0 ? emax : emin,
+                        pol == 0 ? n_max : n_min,
+                        pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax, pol == 0 ? n_min : n_max,
+                        selP, selT, lf, rt, &nTr, &n_pairs, &first_valid, &nT);
+    } else if (dense) {
+      nmx_dense_pair<2>(pol == 0 ? D.K[0] : D.K[2], pol == 0 ? D.pmax : D.pmin, pol == 0 ? emax : emin,
+                        pol == 0 ? n_max : n_min,
+                        pol == 0 ? D.K[1] : D.K[3], pol == 0 ? D.pmin : D.pmax, pol == 0 ? n_min : n_max,
+                        selP, selT, lf, rt, &nTr, &n_pairs, &first_valid, &nT);
     } else
 #endif
     {
@@ -798,59 +907,11 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
       // one shuffle reduction per pair (default settings: 3 pairs)
       const int s_off = A.sharp_off;
       if (nT <= 128 && n_pairs <= 128) {
-        // at most two entries per lane: gather the list entries and the samples they point at ONCE,
-        // then every (feature, estimator) pair is register arithmetic + one reduction
-        int tq[2], lq[2], rq[2], tprev[2];
-        float zt[2], zl[2], zr[2], zm[2], zp[2];
-        bool okT[2], okP[2], okS[2];
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-          const int p = NMX_TID + 64 * sl;
-          okT[sl] = p < nT; okP[sl] = p < n_pairs;
-          tq[sl] = okT[sl] ? (int)trv[p] : 0;
-          tprev[sl] = (okT[sl] && p > 0) ? (int)trv[p - 1] : tq[sl];
-          lq[sl] = okP[sl] ? (int)lf[p] : 0;
-          rq[sl] = okP[sl] ? (int)rt[p] : 0;
-          okS[sl] = okT[sl] && (tq[sl] - s_off > 0) && (tq[sl] + s_off < W);
-          zt[sl] = sgn * z[tq[sl]]; zl[sl] = sgn * z[lq[sl]]; zr[sl] = sgn * z[rq[sl]];
-          zm[sl] = okS[sl] ? sgn * z[tq[sl] - s_off] : 0.f;
-          zp[sl] = okS[sl] ? sgn * z[tq[sl] + s_off] : 0.f;
-        }
-        for (int cb = 0; cb < A.n_combos; ++cb) {
-          const int f = A.combo_feature[cb], e = A.combo_est[cb];
-          if (f == NMX_SW_NUM_PEAKS) continue;
-          float acc = e == NMX_SWE_MEAN ? 0.f : (e == NMX_SWE_MAX ? -INFINITY : INFINITY);
-          bool has_nan = false;
-          int cnt = 0;   // entries that take part: counted with ballots (scalar), not reduced
-#pragma unroll
-          for (int sl = 0; sl < 2; ++sl) {
-            const bool pt = okP[sl] && (NMX_TID + 64 * sl) < nPT;   // arrays that pair troughs with peaks
-            float v;
-            bool ok;
-            switch (f) {
-              case NMX_SW_PEAK_LEFT: v = zl[sl]; ok = okP[sl]; break;
-              case NMX_SW_PEAK_RIGHT: v = zr[sl]; ok = okP[sl]; break;
-              case NMX_SW_TROUGH: v = zt[sl]; ok = okT[sl]; break;
-              case NMX_SW_WIDTH: v = (float)(rq[sl] - lq[sl]); ok = okP[sl]; break;
-              case NMX_SW_PROMINENCE: v = fabsf((zr[sl] + zl[sl]) * 0.5f - zt[sl]); ok = pt; break;
-              case NMX_SW_INTERVAL: v = (float)(tq[sl] - tprev[sl]) * A.ms; ok = okT[sl]; break;
-              case NMX_SW_DECAY_TIME: v = (float)(lq[sl] - tq[sl]) * A.ms; ok = pt; break;
-              case NMX_SW_RISE_TIME: v = (float)(rq[sl] - tq[sl]) * A.ms; ok = pt; break;
-              default: v = zt[sl] - 0.5f * (zm[sl] + zp[sl]); ok = okS[sl]; break;   // NMX_SW_SHARPNESS
-            }
-            cnt += __popcll(__ballot(ok));
-            // max / min through the hardware instruction (it skips a NaN operand); np.max / np.min propagate NaN: one
-            // flag per lane, one ballot per estimator -- the NaN-propagating form was five instructions per step of the
-            // DPP reduction, 36 per estimator
-            has_nan = has_nan || (ok && v != v);
-            if (ok) acc = e == NMX_SWE_MEAN ? acc + v : (e == NMX_SWE_MAX ? nmx_vmax(acc, v) : nmx_vmin(acc, v));
-          }
-          if (e == NMX_SWE_MEAN) acc = nmx_wave_reduce(acc, 0.f, [](float a, float b) { return a + b; });
-          else if (e == NMX_SWE_MAX) acc = nmx_wave_reduce(acc, -INFINITY, [](float a, float b) { return nmx_vmax(a, b); });
-          else acc = nmx_wave_reduce(acc, INFINITY, [](float a, float b) { return nmx_vmin(a, b); });
-          if (e != NMX_SWE_MEAN && __ballot(has_nan)) acc = NAN;
-          if (NMX_TID == 0) res[pol * A.n_combos + cb] = cnt == 0 ? 0.f : (e == NMX_SWE_MEAN ? acc / (float)cnt : acc);
-        }
+#ifndef NMX_SW_NO_ONE_SLOT
+        if (nT <= 64 && n_pairs <= 64) nmx_sw_fast_est<1>(A, z, sgn, trv, lf, rt, nT, n_pairs, nPT, W, s_off, res, pol);
+        else
+#endif
+        nmx_sw_fast_est<2>(A, z, sgn, trv, lf, rt, nT, n_pairs, nPT, W, s_off, res, pol);
       } else
       for (int cb = 0; cb < A.n_combos; ++cb) {
         const int f = A.combo_feature[cb], e = A.combo_est[cb];

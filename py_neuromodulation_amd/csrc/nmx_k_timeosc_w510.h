@@ -173,8 +173,16 @@ NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2
   }
 }
 
+#ifdef NMX_W510_PROFILE
+#define NMX_W5P(i) { const long long t_ = clock64(); w5p[i] += t_ - w5l; w5l = t_; }
+#else
+#define NMX_W5P(i)
+#endif
 template <int NB>
 NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short* tab, int w, int c, float* smem) {
+#ifdef NMX_W510_PROFILE
+  long long w5p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w5l = clock64();
+#endif
   w = nmx_uniform_i(w);
   c = nmx_uniform_i(c);
   const int lane = (int)(threadIdx.x & 63);
@@ -195,6 +203,7 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
     if (n0 < W) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};   // (W % 4 == 0 or the tail reads zeros)
   }
   NMX_WAVE_FENCE();
+  NMX_W5P(0)   // load + time-domain features
 
   // the real sequences, in order: [FFT window] + STFT segments 0 .. nseg - 1
   const bool stft_long = A.stft.enabled && A.stft.n == 510;
@@ -247,17 +256,22 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
       }
     }
     NMX_WAVE_FENCE();
+    NMX_W5P(1)   // fill
     nmx_pfa510_phase10(bufA, tab, lane);
     if (two) nmx_pfa510_phase10(bufB, tab, lane);
     NMX_WAVE_FENCE();
+    NMX_W5P(2)
     nmx_pfa510_phase3(bufA, tab, lane);
     if (two) nmx_pfa510_phase3(bufB, tab, lane);
     NMX_WAVE_FENCE();
+    NMX_W5P(3)
     nmx_pfa510_phase17(bufA, bufB, two, tab, lane);
     NMX_WAVE_FENCE();
+    NMX_W5P(4)
     bins(bufA, q0, q0 + 1 < n_seq ? q0 + 1 : -1);
     if (two) bins(bufB, q0 + 2, q0 + 3 < n_seq ? q0 + 3 : -1);
     NMX_WAVE_FENCE();
+    NMX_W5P(5)
   }
   if (A.stft.enabled && !stft_long) {
     // short segments (17 samples at 30 kHz: dozens of segments per window): ONE SEGMENT per lane and round, all its
@@ -290,5 +304,11 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
   }
   if (A.fft.enabled) acc_f.emit(A.fft, nb, 1, out_row, c, lane);
   if (A.stft.enabled) acc_s.emit(OS, nb, OS.nseg, out_row, c, lane);
+  NMX_W5P(6)
+#ifdef NMX_W510_PROFILE
+  if (lane == 0 && c == 7 && (w == 3 || w == 600))
+    printf("[w510 w=%d] cycles: load %lld fill %lld p10 %lld p3 %lld p17 %lld bins %lld emit %lld\n", w, w5p[0], w5p[1], w5p[2],
+           w5p[3], w5p[4], w5p[5], w5p[6]);
+#endif
 }
 #endif

@@ -23,6 +23,29 @@
 
 extern __shared__ __attribute__((aligned(16))) float nmx_smem_wave[];
 
+// One-wave-per-item kernels can be launched with several waves per workgroup (each wave its own item and LDS slice, no
+// barrier between them).  Measured on the MI355X (profiles/r04_waves_per_wg.txt): the sharp-wave kernels -- 30+ KB of
+// code, waves at unrelated program counters -- gain 13 % (1000-sample windows) to 24 % (BASELINE config 5) with TWO
+// waves per workgroup, which start together and fetch the same instructions; four are no better; the transform kernels
+// (time / oscillatory, Hilbert) do not gain, and lose when they overlap the bursts chain.  `dflt` is that choice,
+// NMX_WAVES_PER_WG = 1 .. 4 overrides it for every kernel.
+static int waves_per_wg(size_t lds_one, int dflt = 1) {
+  static int k = -1;
+  if (k < 0) {
+    const char* v = getenv("NMX_WAVES_PER_WG");
+    k = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 0;
+  }
+  int kk = k ? k : dflt;
+  while (kk > 1 && lds_one * kk > 64 * 1024) --kk;
+  return kk;
+}
+// (item, LDS slice) of this wave in a launch of `blockDim.x / 64` waves per workgroup; slice in floats
+#define NMX_WAVE_ITEM(item, smem, n_items, slice)                                                   \
+  const int wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                        \
+  const int item = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_;                                \
+  if (item >= (n_items)) return;                                                                    \
+  float* smem = nmx_smem_wave + wave_ * (slice)
+
 __global__ void __launch_bounds__(256) nmx_kern_burst_stat(const NmxBurstStatArgs A, int n_items, int slice) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
   const int item = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -73,12 +96,15 @@ extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items,
 }
 
 // Hilbert envelope of length-1000 series, one wave per series (wave-level 500-point transforms)
-__global__ void __launch_bounds__(64) nmx_kern_hilbert_w500(const NmxHilbertArgs A) {
-  nmx_hilbert_w500_item(A, (long long)blockIdx.x, nmx_smem_wave);
+__global__ void __launch_bounds__(256) nmx_kern_hilbert_w500(const NmxHilbertArgs A, int n_items) {
+  NMX_WAVE_ITEM(item, smem, n_items, NMX_W500_LDS_FLOATS);
+  nmx_hilbert_w500_item(A, (long long)item, smem);
 }
 
 extern "C" void nmx_wave_launch_hilbert_w500(const NmxHilbertArgs* A, long long n_items, hipStream_t s) {
-  hipLaunchKernelGGL(nmx_kern_hilbert_w500, dim3((unsigned)n_items), dim3(64), (size_t)NMX_W500_LDS_FLOATS * 4, s, *A);
+  const int k = waves_per_wg((size_t)NMX_W500_LDS_FLOATS * 4);
+  hipLaunchKernelGGL(nmx_kern_hilbert_w500, dim3((unsigned)((n_items + k - 1) / k)), dim3(64 * k),
+                     (size_t)NMX_W500_LDS_FLOATS * 4 * k, s, *A, (int)n_items);
   nmxi_note_kernel("nmx_kern_hilbert_w500");
 }
 
@@ -100,14 +126,14 @@ extern "C" void nmx_wave_launch_hilbert_w1000(const NmxHilbertArgs* A, long long
 
 // time-domain + FFT / Welch / STFT band means of the default shape, one wave per (window, channel)
 template <int NB, unsigned SPEC = 0>
-__global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A) {
-  const int item = blockIdx.x;
+__global__ void __launch_bounds__(256) nmx_kern_timeosc_w1000(const NmxTimeOscArgs A, int n_items, int slice) {
+  NMX_WAVE_ITEM(item, smem, n_items, slice);
   const int w = nmx_uniform_i(item / A.n_channels), c = nmx_uniform_i(item % A.n_channels);
   NmxW500TwReg T;
   T.load(A.w500_tab, (int)(threadIdx.x & 63));
   NmxTdRegs R;
   nmx_td_load<1000>(A, w, c, R);
-  nmx_timeosc_w1000_body<NB, false, NmxW500TwReg, false, SPEC>(A, w, c, R, T, nmx_smem_wave);
+  nmx_timeosc_w1000_body<NB, false, NmxW500TwReg, false, SPEC>(A, w, c, R, T, smem);
 }
 
 // low bands, no STFT, ONE item per workgroup at 5 waves per SIMD (96 VGPRs: compact twiddles, no prefetch registers):
@@ -241,14 +267,17 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
   const size_t lds = (size_t)(A->stft.enabled ? NMX_TOW_LDS_FLOATS : NMX_TOW_LDS_FLOATS_NOSTFT) * 4;
   static int spec_full = -1;
   if (spec_full < 0) { const char* v = getenv("NMX_TOW_SPEC"); spec_full = !(v && v[0] == '0'); }
+  const int k = waves_per_wg(lds);
+  const dim3 grid((unsigned)((n_items + k - 1) / k)), block(64 * k);
+  const int slice = (int)(lds / 4);
   if (A->n_bands <= 4 && spec_full && nmx_tow_spec(*A) == NMX_TOW_SPEC_ALL) {   // the headline set: feature tests folded
-    hipLaunchKernelGGL((nmx_kern_timeosc_w1000<4, NMX_TOW_SPEC_ALL>), dim3(n_items), dim3(64), lds, s, *A);
+    hipLaunchKernelGGL((nmx_kern_timeosc_w1000<4, NMX_TOW_SPEC_ALL>), grid, block, lds * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<4, 196923u>");
   } else if (A->n_bands <= 4) {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, dim3(n_items), dim3(64), lds, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<4>, grid, block, lds * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<4>");
   } else {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, dim3(n_items), dim3(64), lds, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w1000<8>, grid, block, lds * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<8>");
   }
   return 1;
@@ -256,17 +285,19 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
 
 // STFT with 500-sample segments on windows of other lengths (<= 2048), the only time / oscillatory feature
 template <int NB>
-__global__ void __launch_bounds__(64) nmx_kern_timeosc_stft500(const NmxTimeOscArgs A) {
-  const int item = blockIdx.x;
-  nmx_timeosc_stft500_item<NB>(A, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+__global__ void __launch_bounds__(256) nmx_kern_timeosc_stft500(const NmxTimeOscArgs A, int n_items) {
+  NMX_WAVE_ITEM(item, smem, n_items, NMX_TOS_LDS_FLOATS);
+  nmx_timeosc_stft500_item<NB>(A, item / A.n_channels, item % A.n_channels, smem);
 }
 extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_stft500_ok(*A)) return 0;
+  const int k = waves_per_wg((size_t)NMX_TOS_LDS_FLOATS * 4);
+  const dim3 grid((unsigned)((n_items + k - 1) / k)), block(64 * k);
   if (A->n_bands <= 4) {
-    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<4>, dim3(n_items), dim3(64), (size_t)NMX_TOS_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<4>, grid, block, (size_t)NMX_TOS_LDS_FLOATS * 4 * k, s, *A, n_items);
     nmxi_note_kernel("nmx_kern_timeosc_stft500<4>");
   } else {
-    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<8>, dim3(n_items), dim3(64), (size_t)NMX_TOS_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_stft500<8>, grid, block, (size_t)NMX_TOS_LDS_FLOATS * 4 * k, s, *A, n_items);
     nmxi_note_kernel("nmx_kern_timeosc_stft500<8>");
   }
   return 1;
@@ -274,17 +305,19 @@ extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_it
 
 // 510-sample transforms (17 ms at 30 kHz): prime-factor transform per wave (nmx_k_timeosc_w510.h)
 template <int NB>
-__global__ void __launch_bounds__(64) nmx_kern_timeosc_w510(const NmxTimeOscArgs A) {
-  const int item = blockIdx.x;
-  nmx_timeosc_w510_item<NB>(A, A.w510_tab, item / A.n_channels, item % A.n_channels, nmx_smem_wave);
+__global__ void __launch_bounds__(256) nmx_kern_timeosc_w510(const NmxTimeOscArgs A, int n_items) {
+  NMX_WAVE_ITEM(item, smem, n_items, NMX_TO510_LDS_FLOATS);
+  nmx_timeosc_w510_item<NB>(A, A.w510_tab, item / A.n_channels, item % A.n_channels, smem);
 }
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w510_ok(*A, A->w510_tab)) return 0;
+  const int k = waves_per_wg((size_t)NMX_TO510_LDS_FLOATS * 4);
+  const dim3 grid((unsigned)((n_items + k - 1) / k)), block(64 * k);
   if (A->n_bands <= 4) {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w510<4>, dim3(n_items), dim3(64), (size_t)NMX_TO510_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w510<4>, grid, block, (size_t)NMX_TO510_LDS_FLOATS * 4 * k, s, *A, n_items);
     nmxi_note_kernel("nmx_kern_timeosc_w510<4>");
   } else {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w510<8>, dim3(n_items), dim3(64), (size_t)NMX_TO510_LDS_FLOATS * 4, s, *A);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w510<8>, grid, block, (size_t)NMX_TO510_LDS_FLOATS * 4 * k, s, *A, n_items);
     nmxi_note_kernel("nmx_kern_timeosc_w510<8>");
   }
   return 1;
@@ -307,14 +340,17 @@ extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipSt
 }
 
 // dense-first launch: compact LDS layout (more waves per CU); overflowing items are flagged
-__global__ void __launch_bounds__(64) nmx_kern_sharp_dense(const NmxSharpArgs A, int n_items) {
-  const int item = blockIdx.x;
+__global__ void __launch_bounds__(256) nmx_kern_sharp_dense(const NmxSharpArgs A, int n_items, int slice) {
+  NMX_WAVE_ITEM(item, smem, n_items, slice);
   const int fi = item % A.n_filters, r = item / A.n_filters;
-  nmx_sharp_item_dense(A, r / A.n_channels, r % A.n_channels, fi, (long long)item, nmx_smem_wave);
+  nmx_sharp_item_dense(A, r / A.n_channels, r % A.n_channels, fi, (long long)item, smem);
 }
 
 extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s) {
-  hipLaunchKernelGGL(nmx_kern_sharp_dense, dim3(n_items), dim3(64), (size_t)A->dz_lds_floats * 4, s, *A, n_items);
+  const int slice = (A->dz_lds_floats + 3) & ~3;
+  const int k = waves_per_wg((size_t)slice * 4, 2);
+  hipLaunchKernelGGL(nmx_kern_sharp_dense, dim3((unsigned)((n_items + k - 1) / k)), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
+                     n_items, slice);
   nmxi_note_kernel("nmx_kern_sharp_dense");
 }
 
@@ -338,17 +374,6 @@ extern "C" void nmx_wave_launch_sharp_todo(const NmxSharpArgs* A, int n_items, s
   const int grid = n_items < 256 * 14 ? n_items : 256 * 14;
   hipLaunchKernelGGL(nmx_kern_sharp_todo, dim3(grid), dim3(64), lds, s, *A, n_items, todo);
   nmxi_note_kernel("nmx_kern_sharp_todo");
-}
-
-static int waves_per_wg(size_t lds_one) {
-  static int k = 0;
-  if (!k) {
-    const char* v = getenv("NMX_WAVES_PER_WG");
-    k = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 1;
-  }
-  int kk = k;
-  while (kk > 1 && lds_one * kk > 64 * 1024) --kk;
-  return kk;
 }
 
 extern "C" void nmx_wave_launch_burst_stat(const NmxBurstStatArgs* A, int n_items, size_t lds, hipStream_t s) {
@@ -378,7 +403,7 @@ extern "C" void nmx_wave_launch_sharp(const NmxSharpArgs* A, int n_items, size_t
   if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_sharp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const int k = waves_per_wg(lds);
+  const int k = waves_per_wg(lds, 2);
   const int slice = (int)((lds / 4 + 3) & ~(size_t)3);
   hipLaunchKernelGGL(nmx_kern_sharp, dim3((n_items + k - 1) / k), dim3(64 * k), (size_t)slice * 4 * k, s, *A,
                      n_items, slice);
