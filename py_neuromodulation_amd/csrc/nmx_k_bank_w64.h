@@ -852,7 +852,11 @@ NMX_DEV void nmx_hilbert_w500_item(const NmxHilbertArgs& A, long long item, floa
   const int l = NMX_TID;
   nmx_c2* hb = (nmx_c2*)smem;
   nmx_c2* ha = hb + 504;
+#ifdef NMX_DEBUG_HILBERT_SAMEROW   // (bound experiment, wrong results: every series comes from 4 MB that stay in L2)
+  const nmx_rsrc rin = nmx_make_rsrc(A.y + (item & 1023) * 1000, 4000);
+#else
   const nmx_rsrc rin = nmx_make_rsrc(A.y + item * 1000, 4000);
+#endif
   const nmx_rsrc rout = nmx_make_rsrc(A.env + item * 1000, 4000);
   NmxW500TwReg T;
   T.load(A.w500_tab, l);

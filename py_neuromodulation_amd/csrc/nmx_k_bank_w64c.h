@@ -300,6 +300,9 @@ NMX_DEV void nmx_w64c_epilogue(const NmxBankW64Args& AA, const NmxFilterDev& F, 
   for (int dst = 0; dst < 2; ++dst) {
     float* d = dst ? dyb : dsw;
     if (!d) continue;
+#ifdef NMX_DEBUG_NO_YB   // (bound experiment, tools/exp_fuse_bound.sh: the launcher nulls yb_out after a few launches --
+    if (dst == 1 && !AA.yb_out) continue;   // the band series of the previous, identical step stay in place)
+#endif
     const long long next = (long long)(dst ? A.n_burst_bands : A.n_sw_filters) * W;   // the same band of channel c + 1
     const nmx_rsrc s1 = nmx_make_rsrc(d, 4 * W);
     const nmx_rsrc s2 = nmx_make_rsrc(d + next, two ? 4 * W : 0);

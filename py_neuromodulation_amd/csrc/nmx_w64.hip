@@ -346,6 +346,12 @@ extern "C" int NMX_CAT(nmx_w64c_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   int grid = n_cu > 0 ? n_cu : 256;
   if (grid * nw > n_pairs) grid = (n_pairs + nw - 1) / nw;
   const int chunk = (n_pairs + grid * nw - 1) / (grid * nw);
+#ifdef NMX_DEBUG_NO_YB
+  static int launches = 0;
+  NmxBankW64Args B = *A;
+  if (++launches > 6) B.yb_out = nullptr;
+  A = &B;
+#endif
   hipLaunchKernelGGL(NMX_CAT(nmx_kern_bank_w64c_, NMX_W64_NAME), dim3(grid), dim3(64 * nw), lds, s, *A, n_windows, n_pairs, chunk);
   NMX_KNAME("nmx_kern_bank_w64c_", "");
   return 1;
