@@ -390,47 +390,51 @@ struct NmxMask128 { unsigned long long a, b; };   // elements 0..63, 64..127
 
 // NSL = 1: windows with at most 64 extrema of each kind -- one slot per lane, K.b is empty (every helper below is
 // compiled for both: about half the instructions of the selection / pairing / estimator phases for such a window)
-template <int NSL>
-NMX_DEV unsigned nmx_bit128(const NmxMask128& K, int e) {   // element e of the set; 0 outside [0, 64 NSL)
-  if (NSL == 1) return ((unsigned)e < 64u) ? (unsigned)((K.a >> (e & 63)) & 1ull) : 0u;
-  const unsigned long long w = e < 64 ? K.a : K.b;
-  return ((unsigned)e < 128u) ? (unsigned)((w >> (e & 63)) & 1ull) : 0u;
+//
+// The nine set bits around element e (e - 4 .. e + 4 -> bits 0 .. 8; elements outside the set read 0) come from the
+// set shifted up by four elements, five 32-bit words computed on the scalar unit: per lane two selects, one
+// v_alignbit and one mask -- the bit-by-bit form took ~50 vector instructions per window, four windows per lane and
+// fixed-point step, and made the selection the largest block of the kernel's 2 100 vector instructions per series.
+struct NmxPad128 { unsigned p0, p1, p2, p3, p4; };
+NMX_DEV NmxPad128 nmx_pad128(const NmxMask128& K) {
+  const unsigned a0 = (unsigned)K.a, a1 = (unsigned)(K.a >> 32), b0 = (unsigned)K.b, b1 = (unsigned)(K.b >> 32);
+  NmxPad128 P;
+  P.p0 = a0 << 4;
+  P.p1 = (a1 << 4) | (a0 >> 28);
+  P.p2 = (b0 << 4) | (a1 >> 28);
+  P.p3 = (b1 << 4) | (b0 >> 28);
+  P.p4 = b1 >> 28;
+  return P;
 }
-// bits (4 - d) <- element e - d and bits (d - 1) <- element e + d, d = 1..4
-template <int NSL>
-NMX_DEV void nmx_win128(const NmxMask128& K, int e, unsigned* wl, unsigned* wr) {
-  unsigned l = 0, r = 0;
-#pragma unroll
-  for (int d = 1; d <= 4; ++d) {
-    l |= nmx_bit128<NSL>(K, e - d) << (4 - d);
-    r |= nmx_bit128<NSL>(K, e + d) << (d - 1);
-  }
-  *wl = l; *wr = r;
+template <int SL>
+NMX_DEV unsigned nmx_win9(const NmxPad128& P, int lane) {   // e = 64 SL + lane
+  const bool low = lane < 32;
+  const unsigned lo = SL == 0 ? (low ? P.p0 : P.p1) : (low ? P.p2 : P.p3);
+  const unsigned hi = SL == 0 ? (low ? P.p1 : P.p2) : (low ? P.p3 : P.p4);
+  return __builtin_amdgcn_alignbit(hi, lo, (unsigned)(lane & 31)) & 0x1ffu;
 }
 
 // SciPy _select_by_peak_distance as a fixed point: an extremum is removed iff a higher-priority
-// neighbour inside the distance is kept, kept iff all of them are removed (hl / hr: those neighbours)
+// neighbour inside the distance is kept, kept iff all of them are removed (hl / hr: those neighbours; bit (4 - d)
+// of hl = element e - d, bit (d - 1) of hr = element e + d)
 template <int NSL>
 NMX_DEV NmxMask128 nmx_dense_fixpoint(const bool* valid, const unsigned* hl, const unsigned* hr, int lane) {
-  int s0 = !valid[0] ? 2 : ((hl[0] | hr[0]) == 0u ? 1 : 0);
-  int s1 = (NSL == 1 || !valid[1]) ? 2 : ((hl[1] | hr[1]) == 0u ? 1 : 0);
+  const unsigned h0 = hl[0] | (hr[0] << 5), h1 = hl[1] | (hr[1] << 5);   // in the layout of nmx_win9
+  int s0 = !valid[0] ? 2 : (h0 == 0u ? 1 : 0);
+  int s1 = (NSL == 1 || !valid[1]) ? 2 : (h1 == 0u ? 1 : 0);
   for (;;) {
     NmxMask128 K, U;
     K.a = __ballot(s0 == 1); K.b = NSL == 1 ? 0ull : __ballot(s1 == 1);
     U.a = __ballot(s0 == 0); U.b = NSL == 1 ? 0ull : __ballot(s1 == 0);
     if ((U.a | U.b) == 0ull) return K;
-    unsigned kl, kr, ul, ur;
-    if (s0 == 0) {
-      nmx_win128<NSL>(K, lane, &kl, &kr);
-      nmx_win128<NSL>(U, lane, &ul, &ur);
-      const bool removed = ((kl & hl[0]) | (kr & hr[0])) != 0u, wait = ((ul & hl[0]) | (ur & hr[0])) != 0u;
-      s0 = removed ? 2 : (wait ? 0 : 1);
+    const NmxPad128 PK = nmx_pad128(K), PU = nmx_pad128(U);
+    {
+      const bool removed = (nmx_win9<0>(PK, lane) & h0) != 0u, wait = (nmx_win9<0>(PU, lane) & h0) != 0u;
+      s0 = s0 != 0 ? s0 : (removed ? 2 : (wait ? 0 : 1));
     }
-    if (NSL == 2 && s1 == 0) {
-      nmx_win128<NSL>(K, 64 + lane, &kl, &kr);
-      nmx_win128<NSL>(U, 64 + lane, &ul, &ur);
-      const bool removed = ((kl & hl[1]) | (kr & hr[1])) != 0u, wait = ((ul & hl[1]) | (ur & hr[1])) != 0u;
-      s1 = removed ? 2 : (wait ? 0 : 1);
+    if (NSL == 2) {
+      const bool removed = (nmx_win9<1>(PK, lane) & h1) != 0u, wait = (nmx_win9<1>(PU, lane) & h1) != 0u;
+      s1 = s1 != 0 ? s1 : (removed ? 2 : (wait ? 0 : 1));
     }
   }
 }
