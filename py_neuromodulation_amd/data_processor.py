@@ -388,6 +388,42 @@ class DataProcessor:
         out, mask = self.engine.process_batch(data, starts, want_nan_mask=True, staged_output=True)
         return self.postprocess_batch(out, mask, normalised=self._norm_in_engine)
 
+    # -- ragged window lengths (a non-integer number of samples per segment): `Stream.run` cuts the hops into
+    # consecutive runs of one length, one processor per length; what carries over from hop to hop travels between them
+    def ragged_prepare(self) -> None:
+        """The feature normaliser is sequential over ALL hops: it runs on the merged table (`ragged_finish`)."""
+        if self._norm_in_engine:
+            self.engine.attach_normalizer(None)
+            self._norm_in_engine = False
+
+    def ragged_state(self):
+        """Burst history, Kalman filters ... of the engine (its layout depends on sfreq and the settings, not on the
+        window length: nmx_state_export / _import); None when the plan carries nothing."""
+        return self.engine.export_state() or None
+
+    def ragged_set_state(self, state) -> None:
+        self.engine.import_state(state)
+
+    def ragged_run(self, data: np.ndarray, starts: np.ndarray):
+        """One run of equal-length hops -> (float32 engine rows, NaN mask, [pre-processed windows] or None)."""
+        eng = self.engine
+        if self._user is not None and not eng.preprocessing_is_identity:
+            o, m, pre = eng.process_batch(data, starts, want_nan_mask=True, tap=True)
+            return o, m, [pre[j].astype(np.float64) for j in range(len(starts))]
+        o, m = eng.process_batch(data, starts, want_nan_mask=True)
+        return o, m, (self._host_windows(data, starts) if self._user is not None else None)
+
+    def ragged_finish(self, runs) -> np.ndarray:
+        """The runs of `ragged_run` in hop order -> the float64 table (normaliser, user columns, NaN policy)."""
+        raw = np.concatenate([r[0] for r in runs])
+        masks = np.concatenate([r[1] for r in runs])
+        if self._user is None:
+            return self.postprocess_batch(raw, masks)
+        wins = [w for r in runs for w in r[2]]
+        user = self._user_rows(wins)   # one set of instances sees every hop in order, like the reference
+        rows = self._with_user_columns(self._finish_rows(raw, masks, False), user)
+        return self._apply_nan_policy(rows, masks) if masks.any() else rows
+
     def _finish_rows(self, out: np.ndarray, mask: np.ndarray, normalised: bool) -> np.ndarray:
         """Built-in columns: normalisation (unless it ran inside the engine) and the cast to float64; the NaN policy
         is applied by the caller once the user columns are in place."""

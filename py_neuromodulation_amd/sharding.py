@@ -376,6 +376,51 @@ class MultiDeviceProcessor:
             tables.append(table)
         return np.concatenate(tables) if tables else np.empty((0, len(self.keys)))
 
+    # -- ragged window lengths: the protocol of DataProcessor.ragged_* over the parts --------------------------------
+    def ragged_prepare(self) -> None:
+        for p in self.parts:
+            p.ragged_prepare()
+        self._norm_in_engine = False
+
+    def ragged_state(self):
+        st = [p.engine.export_state() for p in self.parts]
+        return st if any(st) else None
+
+    def ragged_set_state(self, state) -> None:
+        for p, s_ in zip(self.parts, state):
+            if s_:
+                p.engine.import_state(s_)
+
+    def ragged_run(self, data: np.ndarray, starts: np.ndarray):
+        got = self._run_parts(data, np.asarray(starts, dtype=np.int64), self._user is not None)
+        wins = None
+        if self._user is not None:   # contiguous channel blocks in device order: the joined window is the single-device one
+            joined = np.concatenate([w for _, _, w in got], axis=1)
+            wins = [joined[j] for j in range(joined.shape[0])]
+        return [o for o, _, _ in got], got[0][1], wins
+
+    def ragged_finish(self, runs) -> np.ndarray:
+        masks = np.concatenate([r[1] for r in runs])
+        zero = np.zeros_like(masks)
+        # every part normalises its own columns over ALL hops (the normaliser is per column)
+        rows = [p.postprocess_batch(np.concatenate([r[0][i] for r in runs]), zero, normalised=False)
+                for i, p in enumerate(self.parts)]
+        table = self._merge(rows)
+        if self._user is not None:
+            user = self._user.rows([w for r in runs for w in r[2]])
+            if table.shape[1] != len(self.keys):   # the first call appended the plugin keys
+                wide = np.full((table.shape[0], len(self.keys)), np.nan)
+                wide[:, :table.shape[1]] = table
+                table = wide
+            table[:, self._user.cols] = user
+        if masks.any():
+            nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
+            if masks.shape[1] != len(self.ch_names_used):
+                raise IndexError("boolean index did not match: NaN handling needs every channel used")
+            for ci in np.where(masks.any(axis=0))[0]:
+                table[np.ix_(masks[:, ci], nan_cols[ci])] = np.nan
+        return table
+
     def process(self, data: np.ndarray) -> dict:
         if self._user is not None or self.local_input:
             row = self.process_batch(np.asarray(data), np.zeros(1, np.int64))[0]

@@ -140,8 +140,6 @@ class Stream:
             if len(groups) > 1 and "raw_normalization" in st.preprocessing:
                 raise NotImplementedError("raw_normalization with ragged window lengths (a non-integer number of samples per "
                                           "segment) is not supported: its sample history is laid out per window length")
-            if len(groups) > 1 and self.devices is not None and len(self.devices) > 1:
-                raise NotImplementedError("ragged windows (non-integer hop) are not supported on several devices")
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
             # processor per window length.  The processor built by __init__ (or by the previous run) is
             # reused with its state reset when it fits -- same results, no second plan build.
@@ -158,44 +156,22 @@ class Stream:
                 rows = dp0.process_batch(data, starts)
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
-                # cannot run inside the per-length engines: detach, normalise the merged rows afterwards
-                for p in procs.values():
-                    if p._norm_in_engine:
-                        p.engine.attach_normalizer(None)
-                        p._norm_in_engine = False
-                raw = np.empty((len(starts), len(dp0.engine.keys)), dtype=np.float32)
-                masks = np.zeros((len(starts), data.shape[0]), dtype=bool)
-                wins = [None] * len(starts)   # user features: the pre-processed window of every hop, hop order
+                # cannot run inside the per-length engines: detached, it normalises the merged rows afterwards.
                 # Hops in ORDER, as consecutive runs of one window length: the burst history (features/bursts.py:149-173)
                 # and the Kalman filters of the band powers (bandpower.py:147-163) carry over from hop to hop whatever
-                # the window length, so the state blob travels from plan to plan where the length changes (its layout
-                # depends on sfreq and the settings, not on the window: nmx_state_export / _import)
+                # the window length, so the state travels from processor to processor where the length changes
+                # (DataProcessor.ragged_* / MultiDeviceProcessor.ragged_*: one state blob per device there)
+                for p in procs.values():
+                    p.ragged_prepare()
                 cuts = [0] + [i for i in range(1, len(lens)) if lens[i] != lens[i - 1]] + [len(lens)]
-                stateful = dp0.engine.export_state() != b""
-                state = None
+                state, runs = None, []
                 for a, b in zip(cuts[:-1], cuts[1:]):
                     p = procs[int(lens[a])]
-                    sel = np.arange(a, b)
-                    if stateful and state is not None:
-                        p.engine.import_state(state)
-                    if dp0.user_features and not p.engine.preprocessing_is_identity:
-                        o, m, pre = p.engine.process_batch(data, starts[sel], want_nan_mask=True, tap=True)
-                        for j, i in enumerate(sel):
-                            wins[i] = pre[j].astype(np.float64)
-                    else:
-                        o, m = p.engine.process_batch(data, starts[sel], want_nan_mask=True)
-                        if dp0.user_features:
-                            for i, wv in zip(sel, p._host_windows(data, starts[sel])):
-                                wins[i] = wv
-                    raw[sel], masks[sel] = o, m
-                    if stateful:
-                        state = p.engine.export_state()
-                if dp0.user_features:
-                    user = dp0._user_rows(wins)   # one set of instances sees every hop in order, like the reference
-                    rows = dp0._with_user_columns(dp0._finish_rows(raw, masks, False), user)
-                    rows = dp0._apply_nan_policy(rows, masks) if masks.any() else rows
-                else:
-                    rows = dp0.postprocess_batch(raw, masks)
+                    if state is not None:
+                        p.ragged_set_state(state)
+                    runs.append(p.ragged_run(data, starts[a:b]))
+                    state = p.ragged_state()
+                rows = dp0.ragged_finish(runs)
             keys = list(dp0.keys)   # after the first hop: user-feature keys are known once calc_feature has run
         df = pd.DataFrame(rows, columns=keys)
         df["time"] = times

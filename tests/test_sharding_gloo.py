@@ -297,3 +297,50 @@ def test_multi_device_parts_on_one_device_do_not_share_staging():
     many = st.run(save_csv=False).to_numpy(float)
     assert one.shape[0] * (one.shape[1] - 1) // 2 >= 1 << 18   # each part's output crosses the staging threshold
     np.testing.assert_array_equal(many, one)
+
+
+def test_multi_device_stream_with_ragged_window_lengths():
+    """A sampling rate that is not an integer (1111.111 Hz: windows of 1111 and 1112 samples) on several devices: one
+    set of plans per window length, the burst histories / Kalman filters of every device travel between them where the
+    length changes, the feature normaliser runs per part over all hops, a registered plugin sees the joined windows in
+    hop order.  Same table as the one-plan stream (which the reference golden ragged_bursts.npz pins)."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+
+    import py_neuromodulation_amd as nmx
+    from py_neuromodulation_amd import NMSettings, _lib
+    from py_neuromodulation_amd.stream import Stream
+    from tests import user_plugins as up
+
+    lib = _lib.NmxLibrary(ge.build_emu())
+    rng = np.random.default_rng(41)
+    sfreq, T = 1111.111, 6000
+    t = np.arange(T) / sfreq
+    data = rng.standard_normal((5, T)) * 20 + 15 * np.sin(2 * np.pi * 18 * t) * (np.sin(2 * np.pi * 0.7 * t) > 0)
+    data[2, 3000:3003] = np.nan
+    s = NMSettings.get_default()
+    s.reset()
+    s.features.fft = True
+    s.features.bursts = True
+    s.features.bandpass_filter = True
+    s.bandpass_filter_settings.kalman_filter = True
+    s.kalman_filter_settings.frequency_bands = ["theta", "low_beta"]
+    s.bursts_settings.time_duration_s = 2
+    s.preprocessing = ["re_referencing"]
+    s.postprocessing.feature_normalization = True
+    for plugins in (False, True):
+        if plugins:
+            nmx.add_custom_feature("hop_stats", up.HopStats)
+        os.environ["NMX_CAR_FAST"] = "0"   # (the one-plan stream through the same row form as the parts: equal to rounding)
+        try:
+            one = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+            many = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib, devices=[0, 0, 0]).run(save_csv=False)
+        finally:
+            os.environ.pop("NMX_CAR_FAST", None)
+            if plugins:
+                nmx.remove_custom_feature("hop_stats")
+        assert list(many.columns) == list(one.columns)
+        a, b = many.to_numpy(float), one.to_numpy(float)
+        assert a.shape == b.shape and len(a) > 40
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any()
+        np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=2e-5, atol=2e-6)
