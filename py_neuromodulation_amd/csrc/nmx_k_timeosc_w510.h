@@ -22,7 +22,10 @@
 
 #ifndef NMX_HOST_EMU
 
-#define NMX_TO510_LDS_FLOATS (1024 + 2 * 1024)
+// the window (its length rounded up to 16 floats + 16: the extension reads stay inside) + two 512-point complex buffers:
+// 10.1 KB per wave for 512-sample windows, 12 KB for 1024
+#define NMX_TO510_XS_FLOATS(W) ((((W) + 15) & ~15) + 16)
+#define NMX_TO510_LDS_FLOATS(W) (NMX_TO510_XS_FLOATS(W) + 2 * 1024)
 // table layout (unsigned short): g10[51] (padded to 64) | g3[170] (padded to 192) | g17[30] (padded to 32) | pos_of_k[510] (padded to 512)
 #define NMX_TO510_TAB_G10 0
 #define NMX_TO510_TAB_G3 64
@@ -179,28 +182,51 @@ NMX_DEV void nmx_w510_short_stft(const NmxOsc& OS, const float* xs, const float2
 #define NMX_W5P(i)
 #endif
 template <int NB>
-NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short* tab, int w, int c, float* smem) {
+NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A0, const unsigned short* tab, int w, int c, float* smem) {
 #ifdef NMX_W510_PROFILE
   long long w5p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w5l = clock64();
 #endif
   w = nmx_uniform_i(w);
   c = nmx_uniform_i(c);
   const int lane = (int)(threadIdx.x & 63);
+  // The plan is re-read (s_load) where a phase needs it instead of living in scalar registers from the top of the kernel:
+  // the pointer is laundered between the phases (kept alive, the plan spilled 260 scalars to VGPR lanes and every use paid
+  // a v_readlane / v_writelane -- vector instructions of an issue-bound kernel)
+  typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;   // (A0 lives in the kernel-argument segment)
+  nmx_karg_p Aq = (nmx_karg_p)(unsigned long long)&A0;
+#define NMX_W510_RELOAD() asm volatile("" : "+s"(Aq))
+#define A (*(const NmxTimeOscArgs*)Aq)
+  NMX_W510_RELOAD();
   const int W = A.W;
   float* xs = smem;                              // [W] the window, natural order
-  float2* bufA = (float2*)(smem + 1024);         // [510]
-  float2* bufB = (float2*)(smem + 2048);         // [510]
+  float2* bufA = (float2*)(smem + NMX_TO510_XS_FLOATS(W));          // [512] (510 used)
+  float2* bufB = (float2*)(smem + NMX_TO510_XS_FLOATS(W) + 1024);   // [512]
   float* out_row = A.out + (long long)w * A.n_outputs;
   const int nb = A.n_bands;
 
-  NmxScanRegs R;
-  nmx_scan_load(A, w, c, R);
-  R.sum = 0.f;
-  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) nmx_scan_emit(A, w, c, R);
+  // time domain on packed arithmetic (nmx_k_td.h: 200 vector instructions where the scalar formulation of nmx_k_scan.h
+  // takes 600); its window sum is also the NaN / infinity test of the window
+  bool fast = false;
+  if (nmx_td_ok(A)) {
+    NmxTdRegs Rt;
+    nmx_td_load(A, w, c, Rt);
+    fast = nmx_td_emit(A, w, c, Rt, nullptr);
+    if (fast) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int n0 = 4 * (lane + 64 * k);
-    if (n0 < W) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};   // (W % 4 == 0 or the tail reads zeros)
+      for (int k = 0; k < 4; ++k)
+        if (4 * (lane + 64 * k) < W) ((nmx_f4*)xs)[lane + 64 * k] = Rt.x[k];
+    }
+  }
+  if (!fast) {   // odd window lengths, a NaN or an infinity in the window: cleaning loads, scalar formulation
+    NmxScanRegs R;
+    nmx_scan_load(A, w, c, R);
+    R.sum = 0.f;
+    if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) nmx_scan_emit(A, w, c, R);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n0 = 4 * (lane + 64 * k);
+      if (n0 < W) ((nmx_f4*)xs)[lane + 64 * k] = nmx_f4{R.x[k][0], R.x[k][1], R.x[k][2], R.x[k][3]};   // (W % 4 == 0 or the tail reads zeros)
+    }
   }
   NMX_WAVE_FENCE();
   NMX_W5P(0)   // load + time-domain features
@@ -208,17 +234,16 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
   // the real sequences, in order: [FFT window] + STFT segments 0 .. nseg - 1
   const bool stft_long = A.stft.enabled && A.stft.n == 510;
   const int n_fft = A.fft.enabled ? 1 : 0, n_seq = n_fft + (stft_long ? A.stft.nseg : 0);
-  const NmxOsc& OS = A.stft;
+#define OS (A.stft)
   const int h = OS.half;
-  auto sample = [&](int q, int i) -> float {   // element i of sequence q
-    if (q < n_fft) return xs[W - 510 + i];
-    const int e = (q - n_fft) * 255 + i;        // position in the evenly extended, zero padded window
-    float v;
-    if (e < h) v = xs[h - e];
-    else if (e < h + W) v = xs[e - h];
-    else if (e < 2 * h + W) v = xs[W - 2 - (e - h - W)];
-    else v = 0.f;
-    return v * OS.win[i];
+  // element i of STFT segment sg (branch-free): position e of the evenly extended, zero padded window is x[|e - h|] up to
+  // the window's end, x[2 W - 2 + h - e] in the right extension, 0 beyond; wv = the segment window's coefficient
+  auto seg_sample = [&](int sg, int i, float wv) -> float {
+    const int e = sg * 255 + i;
+    const int d = e - h;
+    const int idx = e < h + W ? (d < 0 ? -d : d) : 2 * W - 2 - d;
+    const bool valid = e < 2 * h + W;
+    return valid ? xs[valid ? idx : 0] * wv : 0.f;
   };
   NmxBandAcc<NB> acc_f, acc_s;
   acc_f.clear();
@@ -245,15 +270,20 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
     }
   };
   for (int q0 = 0; q0 < n_seq; q0 += 4) {
+    NMX_W510_RELOAD();
     // up to two complex transforms (four real sequences) per round: bufA = (q0, q0 + 1), bufB = (q0 + 2, q0 + 3)
     const bool two = q0 + 2 < n_seq;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
+      // (entries 510 and 511 of the 512-point buffers take whatever lanes 62 / 63 compute: never read)
       const int i = lane + 64 * r;
-      if (i < 510) {
-        bufA[i] = make_float2(sample(q0, i), q0 + 1 < n_seq ? sample(q0 + 1, i) : 0.f);
-        if (two) bufB[i] = make_float2(sample(q0 + 2, i), q0 + 3 < n_seq ? sample(q0 + 3, i) : 0.f);
-      }
+      const float wv = stft_long ? OS.win[i < 510 ? i : 509] : 0.f;
+      auto seq = [&](int q) -> float {   // sequence q: the FFT window first, then the segments (q wave-uniform)
+        if (q >= n_seq) return 0.f;
+        return q < n_fft ? xs[W - 510 + i] : seg_sample(q - n_fft, i, wv);
+      };
+      bufA[i] = make_float2(seq(q0), seq(q0 + 1));
+      if (two) bufB[i] = make_float2(seq(q0 + 2), seq(q0 + 3));
     }
     NMX_WAVE_FENCE();
     NMX_W5P(1)   // fill
@@ -268,6 +298,7 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
     nmx_pfa510_phase17(bufA, bufB, two, tab, lane);
     NMX_WAVE_FENCE();
     NMX_W5P(4)
+    NMX_W510_RELOAD();
     bins(bufA, q0, q0 + 1 < n_seq ? q0 + 1 : -1);
     if (two) bins(bufB, q0 + 2, q0 + 3 < n_seq ? q0 + 3 : -1);
     NMX_WAVE_FENCE();
@@ -302,6 +333,7 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
       }
     }
   }
+  NMX_W510_RELOAD();
   if (A.fft.enabled) acc_f.emit(A.fft, nb, 1, out_row, c, lane);
   if (A.stft.enabled) acc_s.emit(OS, nb, OS.nseg, out_row, c, lane);
   NMX_W5P(6)
@@ -311,4 +343,8 @@ NMX_DEV void nmx_timeosc_w510_item(const NmxTimeOscArgs& A, const unsigned short
            w5p[3], w5p[4], w5p[5], w5p[6]);
 #endif
 }
+#undef A
+#undef OS
+#undef NMX_W510_RELOAD
+
 #endif

@@ -304,20 +304,32 @@ extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_it
 }
 
 // 510-sample transforms (17 ms at 30 kHz): prime-factor transform per wave (nmx_k_timeosc_w510.h)
+#ifndef NMX_W510_WAVES   // resident waves per SIMD the kernel is compiled for (4: 127 VGPRs, measured 6 % faster than 3)
+#define NMX_W510_WAVES 4
+#endif
+#if NMX_W510_WAVES
+#define NMX_W510_WPE __attribute__((amdgpu_waves_per_eu(NMX_W510_WAVES, NMX_W510_WAVES)))
+#else
+#define NMX_W510_WPE
+#endif
 template <int NB>
-__global__ void __launch_bounds__(256) nmx_kern_timeosc_w510(const NmxTimeOscArgs A, int n_items) {
-  NMX_WAVE_ITEM(item, smem, n_items, NMX_TO510_LDS_FLOATS);
+__global__ void __launch_bounds__(256) NMX_W510_WPE nmx_kern_timeosc_w510(const NmxTimeOscArgs A0, int n_items, int slice) {
+  NMX_WAVE_ITEM(item, smem, n_items, slice);
+  // (the plan through the kernel-argument segment pointer: the item launders it between its phases)
+  typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;
+  const NmxTimeOscArgs& A = *(const NmxTimeOscArgs*)(nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
   nmx_timeosc_w510_item<NB>(A, A.w510_tab, item / A.n_channels, item % A.n_channels, smem);
 }
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w510_ok(*A, A->w510_tab)) return 0;
-  const int k = waves_per_wg((size_t)NMX_TO510_LDS_FLOATS * 4);
+  const int slice = NMX_TO510_LDS_FLOATS(A->W);
+  const int k = waves_per_wg((size_t)slice * 4);
   const dim3 grid((unsigned)((n_items + k - 1) / k)), block(64 * k);
   if (A->n_bands <= 4) {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w510<4>, grid, block, (size_t)NMX_TO510_LDS_FLOATS * 4 * k, s, *A, n_items);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w510<4>, grid, block, (size_t)slice * 4 * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w510<4>");
   } else {
-    hipLaunchKernelGGL(nmx_kern_timeosc_w510<8>, grid, block, (size_t)NMX_TO510_LDS_FLOATS * 4 * k, s, *A, n_items);
+    hipLaunchKernelGGL(nmx_kern_timeosc_w510<8>, grid, block, (size_t)slice * 4 * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w510<8>");
   }
   return 1;
