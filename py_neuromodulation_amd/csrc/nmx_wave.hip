@@ -30,11 +30,8 @@ extern __shared__ __attribute__((aligned(16))) float nmx_smem_wave[];
 // (time / oscillatory, Hilbert) do not gain, and lose when they overlap the bursts chain.  `dflt` is that choice,
 // NMX_WAVES_PER_WG = 1 .. 4 overrides it for every kernel.
 static int waves_per_wg(size_t lds_one, int dflt = 1) {
-  static int k = -1;
-  if (k < 0) {
-    const char* v = getenv("NMX_WAVES_PER_WG");
-    k = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 0;
-  }
+  const char* v = getenv("NMX_WAVES_PER_WG");   // (read per launch: the GPU tests switch it inside one process)
+  const int k = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 0;
   int kk = k ? k : dflt;
   while (kk > 1 && lds_one * kk > 64 * 1024) --kk;
   return kk;
