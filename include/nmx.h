@@ -239,7 +239,11 @@ int nmx_preprocess_window(nmx_plan* plan, const double* x, int64_t ldx, double* 
 /* FIR bank only (MNEFilter.filter_data): x[C][W] -> y[C][n_filters][W] float64 host. */
 int nmx_filter_window(nmx_plan* plan, const double* x, int64_t ldx, double* y);
 
-/* Burst ring state (the only state carried across windows, features/bursts.py:105-115). */
+/* State carried across windows: burst histories (features/bursts.py:105-115), Kalman filters, raw-normaliser sample
+ * histories.  The blob is opaque and belongs to one library build; a plan built from the same description with ANOTHER
+ * window length accepts it (ragged window lengths of a non-integer sampling rate: the raw-normaliser part carries the
+ * exporting plan's ring capacity and is re-laid on import), so n_bytes of nmx_state_import is the exporter's
+ * nmx_state_size. */
 int nmx_state_reset(nmx_plan* plan);
 int nmx_state_size(const nmx_plan* plan, int64_t* n_bytes);
 int nmx_state_export(nmx_plan* plan, void* dst, int64_t n_bytes);

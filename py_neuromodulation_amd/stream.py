@@ -137,9 +137,6 @@ class Stream:
         keys: list[str] = []
         if len(starts):
             groups = [int(g) for g in np.unique(lens)]
-            if len(groups) > 1 and "raw_normalization" in st.preprocessing:
-                raise NotImplementedError("raw_normalization with ragged window lengths (a non-integer number of samples per "
-                                          "segment) is not supported: its sample history is laid out per window length")
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
             # processor per window length.  The processor built by __init__ (or by the previous run) is
             # reused with its state reset when it fits -- same results, no second plan build.

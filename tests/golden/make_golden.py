@@ -694,6 +694,38 @@ def case_long_windows():
     np.savez_compressed(HERE / "long_windows.npz", **out)
 
 
+def case_ragged_rawnorm():
+    """raw_normalization on a stream with ragged window lengths (1111.111 Hz: windows of 1111 and 1112 samples): ONE
+    sample history -- the whole first window, then the last int(sfreq / feat_hz) samples of every later one, trimmed to
+    N - 1 = int(time_s * sfreq) - 1 (processing/normalization.py:31-116) -- whatever the window length; zscore with a
+    1.5 s history (trimmed every hop) and the order-statistic median on a 3 s one."""
+    rng = np.random.default_rng(8112)
+    sfreq, T = 1111.111, 7000
+    t = np.arange(T) / sfreq
+    data = rng.standard_normal((2, T)) * 12 + 30 + 8 * np.sin(2 * np.pi * 9 * t)
+    out = {"sfreq": sfreq, "data": data}
+    for tag, method, ts in (("zscore", "zscore", 1.5), ("median", "median", 3.0)):
+        s = nm.NMSettings.get_default()
+        s.reset()
+        s.features.fft = True
+        s.features.return_raw = True
+        s.features.raw_hjorth = True
+        s.preprocessing = ["raw_normalization"]
+        s.raw_normalization_settings.normalization_time_s = ts
+        s.raw_normalization_settings.normalization_method = method
+        s.raw_normalization_settings.clip = 3
+        s.postprocessing.feature_normalization = False
+        st, df = _run_stream(data, sfreq, s)
+        out.update({f"{tag}_settings_json": dump(st.settings), f"{tag}_columns": np.array(list(df.columns)),
+                    f"{tag}_values": df.to_numpy(dtype=np.float64),
+                    f"{tag}_channels_json": json.dumps(st.channels.to_dict("list"))})
+        print("ragged_rawnorm", tag, df.shape)
+    gen = nm.stream.generator.RawDataGenerator(data, sfreq, 10, 1000)
+    out["window_lengths"] = np.array([b.shape[1] for _, b in gen])
+    assert len(set(out["window_lengths"].tolist())) == 2
+    np.savez_compressed(HERE / "ragged_rawnorm.npz", **out)
+
+
 def case_user_features():
     """User-registered NMFeature plugins (features/feature_processor.py:52-53,90-108; the plugin of
     examples/plot_2_example_add_feature.py is tests/user_plugins.ChannelMean): the reference's own Stream.run with
@@ -761,6 +793,7 @@ if __name__ == "__main__":
     case_c5_degenerate()
     case_sharpwave_tests()
     case_long_windows()
+    case_ragged_rawnorm()
     case_pipeline()
     case_nan_and_channels()
     case_notch()

@@ -2046,3 +2046,31 @@ def case_long_windows(lib, tags=("sw_default", "sw_all", "rn_median", "rn_zscore
         for i in range(len(got)):
             n_bad, rep, _ = parity.compare(cols[:-1], got[i, :-1], want[i, :-1], s, sfreq, 20.0, 7000, verifier=pv.row(i))
             assert n_bad == 0, f"{tag} hop {i}\n{rep}"
+
+
+def case_ragged_rawnorm(lib):
+    """raw_normalization with ragged window lengths (reference golden tests/golden/ragged_rawnorm.npz, 1111.111 Hz): one
+    sample history for the whole stream -- the state blob of the raw normaliser carries its ring capacity, the plan of
+    the other window length re-lays the histories into its own rings (nmx_state_import)."""
+    import json
+
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("ragged_rawnorm")
+    sfreq, data = float(g["sfreq"]), g["data"]
+    for tag in ("zscore", "median"):
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        ch = json.loads(str(g[f"{tag}_channels_json"]))
+        df = Stream(sfreq, channels=ch, settings=s, line_noise=50, lib=lib).run(data, save_csv=False)
+        cols = [str(c) for c in g[f"{tag}_columns"]]
+        assert list(df.columns) == cols, tag
+        got, want = df.to_numpy(float), g[f"{tag}_values"]
+        assert got.shape == want.shape, tag
+        np.testing.assert_array_equal(got[:, -1], want[:, -1])
+        # z-scores of fp32 samples against float64 statistics (case_raw_normalizer's tolerance); fft columns are log10
+        # band means of the normalised window
+        raw = [j for j, c in enumerate(cols[:-1]) if c.endswith("_raw")]
+        oth = [j for j, c in enumerate(cols[:-1]) if not c.endswith("_raw")]
+        np.testing.assert_allclose(got[:, raw], want[:, raw], rtol=2e-5, atol=5e-6, err_msg=tag)
+        np.testing.assert_allclose(got[:, oth], want[:, oth], rtol=5e-5, atol=2e-5, err_msg=tag)

@@ -456,6 +456,10 @@ def test_long_windows_sharp_waves_and_order_normalisers(gpu_lib):
     pc.case_long_windows(gpu_lib)
 
 
+def test_raw_normalisation_with_ragged_window_lengths(gpu_lib):
+    pc.case_ragged_rawnorm(gpu_lib)
+
+
 def test_raw_order_normalisers_with_lists_in_device_memory(gpu_lib, monkeypatch):
     """The reference goldens of the order-statistic raw normalisers (1000-sample windows) with the merge lists forced
     into device memory -- the layout windows beyond 6484 samples take."""
