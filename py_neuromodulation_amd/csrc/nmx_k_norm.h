@@ -260,7 +260,7 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
           out = ((double)x - mean) / mean;
         } else {
           double var = s2 / (double)cnt - mean * mean;
-          if (var < 1e-9 * mean * mean) {  // cancellation: two-pass over the ring (rare)
+          if (var < 1e-8 * mean * mean) {  // cancellation (one-pass error ~ eps mean^2 / var): two-pass over the ring (rare)
             double acc = 0.0;
             for (long long t = q - len + 1; t <= q; ++t) {
               const float h = A.ring[(t % cap) * A.n_cols + j];
@@ -289,8 +289,14 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       if (med && (sk || o == o)) { pend = true; pend_val = sk ? nmx_clean(o) : o; }
       --len;
       // a value far larger than what stays behind leaves the sliding sums with ITS rounding (4e1 leaving a window of
-      // 1e-5's: s2 is 1e-13 off against 7e-9): rebuild the sums from the rows that remain (rare)
-      if (nmx_norm_finite(o) && !((double)o * (double)o <= 1e4 * s2)) {
+      // 1e-5's: s2 is 1e-13 off against 7e-9): rebuild the sums from the rows that remain (rare).  "Far larger" is
+      // measured against the SPREAD that stays (cnt x variance = s2 - s1^2 / cnt), not against s2: -13.1 leaving
+      // four values of -0.2023 +- 5e-5 left 2e-14 in s2 against 8e-9 -- the z-scores of the next hops were 7e-6 off
+      // (and differed by as much between a batch call and window-by-window calls, which rebuild: fuzz seed 5195)
+      // (its residue in cnt x variance = s2 - s1^2 / cnt is ~ eps (o^2 + 2 |mean| |o|) per addition it sat through)
+      const double spread = cnt > 0 ? s2 - s1 * s1 / (double)cnt : 0.0;
+      const double mabs = cnt > 0 ? fabs(s1) / (double)cnt : 0.0, oabs = fabs((double)o);
+      if (nmx_norm_finite(o) && (!(oabs * oabs <= 1e4 * s2) || !(oabs * (oabs + 2.0 * mabs) <= 1e5 * spread))) {
         s1 = 0.0; s2 = 0.0; cnt = 0; ninf = 0;
         for (long long t = q - len + 1; t <= q; ++t) {
           const float h = A.ring[(t % cap) * A.n_cols + j];
