@@ -131,6 +131,43 @@ class ShardedStream:
             full[:, rows] = m.astype(bool)
         return full
 
+    def _run_ragged(self, data, starts, lens, times, group):
+        """Ragged window lengths (a non-integer number of samples per segment): one processor per length, the hops in
+        order as runs of one length, this rank's state (burst histories, Kalman filters, raw-normaliser histories)
+        handed from processor to processor where the length changes (DataProcessor.ragged_*, as Stream.run does)."""
+        procs = {int(w): self._processor(int(w)) for w in sorted(set(lens.tolist()))}
+        for p in procs.values():
+            p.ragged_prepare()
+        dp0 = procs[min(procs)]
+        x = None
+        if self.local_input:
+            if data.shape[0] != len(self.local_rows):
+                raise ValueError(f"local_input: expected the {len(self.local_rows)} rows ShardedStream.local_rows, "
+                                 f"got {data.shape[0]}")
+            sums = self.group_sums(data, group)
+            x = np.concatenate([np.asarray(data, np.float32)] + [chmod.split_hi_lo(v) for v in sums], axis=0)
+        cuts = [0] + [i for i in range(1, len(lens)) if lens[i] != lens[i - 1]] + [len(lens)]
+        state, runs = None, []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            p = procs[int(lens[a])]
+            if state is not None:
+                p.ragged_set_state(state)
+            if x is None:
+                runs.append(p.ragged_run(data, starts[a:b]))
+            else:
+                o, m = p.engine.process_batch(x, starts[a:b], want_nan_mask=True)
+                runs.append((o, m, None))
+            state = p.ragged_state()
+        if x is None:
+            return list(dp0.keys), dp0.ragged_finish(runs), times
+        out = np.concatenate([r[0] for r in runs])
+        mask_all = self._gather_mask(np.concatenate([r[1] for r in runs]), len(self.channels), group)
+        if mask_all.any() and mask_all.shape[1] != len(dp0.ch_names_used):
+            raise IndexError("boolean index did not match: NaN handling needs every channel used")
+        rows = dp0.postprocess_batch(out, mask_all if mask_all.any() else np.zeros((len(out), len(dp0.ch_names_used)), bool),
+                                     normalised=False)
+        return list(dp0.keys), rows, times
+
     def run(self, data: np.ndarray, group=None):
         """-> (local_keys, float64[n_windows, n_local], time_ms) for this rank's channels.
         ``data``: the whole recording [C_all, T], or -- with ``local_input`` -- only its rows
@@ -139,7 +176,7 @@ class ShardedStream:
         starts, lens, times = window_schedule(data.shape[1], self.sfreq, st.sampling_rate_features_hz,
                                               st.segment_length_features_ms)
         if len(set(lens.tolist())) > 1:
-            raise NotImplementedError("ragged windows are not supported in sharded mode")
+            return self._run_ragged(data, starts, lens, times, group)
         dp = self._processor(int(lens[0]) if len(lens) else None)
         if not self.local_input:
             rows = dp.process_batch(data, starts) if len(starts) else np.empty((0, len(dp.keys)))

@@ -63,6 +63,29 @@ df2 = gather_dataframe(keys2, rows2, times2, global_keys(1000.0, s, ch2))
 if rank == 0:
     df2.to_pickle(sys.argv[2] + ".local")
 dist.barrier()
+# ragged window lengths (1111.111 Hz: windows of 1111 and 1112 samples): one processor per length on every rank, the
+# rank's burst histories and Kalman filters handed over where the length changes -- both input forms
+s3 = NMSettings.get_default()
+s3.reset()
+s3.features.fft = True
+s3.features.bursts = True
+s3.features.bandpass_filter = True
+s3.bandpass_filter_settings.kalman_filter = True
+s3.kalman_filter_settings.frequency_bands = ["theta", "low_beta"]
+s3.bursts_settings.time_duration_s = 2
+s3.preprocessing = ["re_referencing"]
+s3.postprocessing.feature_normalization = True
+rng3 = np.random.default_rng(19)
+t3 = np.arange(4500) / 1111.111
+data3 = rng3.standard_normal((5, 4500)) * 20 + 15 * np.sin(2 * np.pi * 18 * t3) * (np.sin(2 * np.pi * 0.7 * t3) > 0)
+data3[2, 2000:2003] = np.nan
+for tag, local in (("ragged", False), ("ragged_local", True)):
+    st3 = ShardedStream(1111.111, ch, s3, line_noise=50, rank=rank, world_size=world, device=dev, lib=lib, local_input=local)
+    keys3, rows3, times3 = st3.run(data3[st3.local_rows] if local else data3)
+    df3 = gather_dataframe(keys3, rows3, times3, global_keys(1111.111, s3, ch))
+    if rank == 0:
+        df3.to_pickle(sys.argv[2] + "." + tag)
+    dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -218,6 +241,35 @@ def _run_two_ranks(tmp_path, backend, port, nproc=2):
             continue
         n_bad, rep, _ = parity.compare([k for k, o in zip(keys, ok) if o], a2[r, :-1][ok], b2[r, :-1][ok], s, 1000.0, 200.0, 1000)
         assert n_bad == 0, f"row {r}\n{rep}"
+
+    # ragged window lengths: both input forms against the one-plan stream (bursts, Kalman filters, z-score, NaN policy)
+    s3 = NMSettings.get_default()
+    s3.reset()
+    s3.features.fft = True
+    s3.features.bursts = True
+    s3.features.bandpass_filter = True
+    s3.bandpass_filter_settings.kalman_filter = True
+    s3.kalman_filter_settings.frequency_bands = ["theta", "low_beta"]
+    s3.bursts_settings.time_duration_s = 2
+    s3.preprocessing = ["re_referencing"]
+    s3.postprocessing.feature_normalization = True
+    rng3 = np.random.default_rng(19)
+    t3 = np.arange(4500) / 1111.111
+    data3 = rng3.standard_normal((5, 4500)) * 20 + 15 * np.sin(2 * np.pi * 18 * t3) * (np.sin(2 * np.pi * 0.7 * t3) > 0)
+    data3[2, 2000:2003] = np.nan
+    os.environ["NMX_CAR_FAST"] = "0"
+    try:
+        single3 = Stream(1111.111, data=data3, settings=s3, line_noise=50, lib=lib).run(save_csv=False)
+    finally:
+        del os.environ["NMX_CAR_FAST"]
+    for tag in ("ragged", "ragged_local"):
+        got3 = pd.read_pickle(str(out) + "." + tag)
+        assert list(got3.columns) == list(single3.columns), tag
+        a3, b3 = got3.to_numpy(float), single3.to_numpy(float)
+        assert a3.shape == b3.shape and len(a3) > 25, tag
+        assert np.array_equal(np.isnan(a3), np.isnan(b3)) and np.isnan(a3).any(), tag
+        np.testing.assert_allclose(np.nan_to_num(a3), np.nan_to_num(b3), rtol=1e-3 if loose else 2e-5, atol=1e-4 if loose else 2e-6,
+                                   err_msg=tag)
 
 
 def test_multi_device_stream_runs_user_registered_features():
