@@ -351,20 +351,36 @@ def test_multi_device_parts_on_one_device_do_not_share_staging():
     np.testing.assert_array_equal(many, one)
 
 
+@pytest.mark.gpu
+def test_multi_device_stream_with_ragged_window_lengths_on_the_gpu():
+    """The same on the product library (two plans per window length on the box's GPU(s)): fp32 kernels pair other
+    channels in a shard than in the one-plan stream, and the z-score divides by small spreads."""
+    from py_neuromodulation_amd import _lib
+
+    lib = _lib.get_library()
+    _ragged_multi_device_case(lib, [0, 1] if lib.device_count() >= 2 else [0, 0], rtol=2e-3, atol=2e-3)
+
+
 def test_multi_device_stream_with_ragged_window_lengths():
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+
+    from py_neuromodulation_amd import _lib
+
+    _ragged_multi_device_case(_lib.NmxLibrary(ge.build_emu()), [0, 0, 0], rtol=2e-5, atol=2e-6)
+
+
+def _ragged_multi_device_case(lib, devices, rtol, atol):
     """A sampling rate that is not an integer (1111.111 Hz: windows of 1111 and 1112 samples) on several devices: one
     set of plans per window length, the burst histories / Kalman filters of every device travel between them where the
     length changes, the feature normaliser runs per part over all hops, a registered plugin sees the joined windows in
     hop order.  Same table as the one-plan stream (which the reference golden ragged_bursts.npz pins)."""
     sys.path.insert(0, str(ROOT))
-    import __graft_entry__ as ge
-
     import py_neuromodulation_amd as nmx
-    from py_neuromodulation_amd import NMSettings, _lib
+    from py_neuromodulation_amd import NMSettings
     from py_neuromodulation_amd.stream import Stream
     from tests import user_plugins as up
 
-    lib = _lib.NmxLibrary(ge.build_emu())
     rng = np.random.default_rng(41)
     sfreq, T = 1111.111, 6000
     t = np.arange(T) / sfreq
@@ -386,7 +402,7 @@ def test_multi_device_stream_with_ragged_window_lengths():
         os.environ["NMX_CAR_FAST"] = "0"   # (the one-plan stream through the same row form as the parts: equal to rounding)
         try:
             one = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
-            many = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib, devices=[0, 0, 0]).run(save_csv=False)
+            many = Stream(sfreq, data=data, settings=s, line_noise=50, lib=lib, devices=devices).run(save_csv=False)
         finally:
             os.environ.pop("NMX_CAR_FAST", None)
             if plugins:
@@ -395,4 +411,4 @@ def test_multi_device_stream_with_ragged_window_lengths():
         a, b = many.to_numpy(float), one.to_numpy(float)
         assert a.shape == b.shape and len(a) > 40
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any()
-        np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=rtol, atol=atol)
