@@ -806,11 +806,7 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
   const bool dense = A.dense_ok && n_max <= 128 && n_min <= 128;
   if (dense_only && !dense) return false;
   // at most 64 extrema of each kind (wave-uniform): one slot per lane
-#ifdef NMX_SW_NO_ONE_SLOT   // (experiment: the two-slot code only -- 20 % less code, more instructions per small window)
-  const bool one = false;
-#else
   const bool one = n_max <= 64 && n_min <= 64;
-#endif
   NmxDenseSel D;
   if (dense) {
     if (one) nmx_dense_select<1>(z, emax, emin, n_max, n_min, A.dist_peaks, A.dist_troughs, D);
@@ -911,11 +907,8 @@ NMX_DEV bool nmx_sharp_body(const NmxSharpArgs& A, const NmxSharpLds& L, int w, 
       // one shuffle reduction per pair (default settings: 3 pairs)
       const int s_off = A.sharp_off;
       if (nT <= 128 && n_pairs <= 128) {
-#ifndef NMX_SW_NO_ONE_SLOT
         if (nT <= 64 && n_pairs <= 64) nmx_sw_fast_est<1>(A, z, sgn, trv, lf, rt, nT, n_pairs, nPT, W, s_off, res, pol);
-        else
-#endif
-        nmx_sw_fast_est<2>(A, z, sgn, trv, lf, rt, nT, n_pairs, nPT, W, s_off, res, pol);
+        else nmx_sw_fast_est<2>(A, z, sgn, trv, lf, rt, nT, n_pairs, nPT, W, s_off, res, pol);
       } else
       for (int cb = 0; cb < A.n_combos; ++cb) {
         const int f = A.combo_feature[cb], e = A.combo_est[cb];
