@@ -98,6 +98,9 @@ __device__ __forceinline__ long long nmx_uniform_ll(long long v) {
 
 #define NMX_MAX_STAGES 12
 #define NMX_MAX_BANDS_DEV 16
+// table of the matrix-pipe spectrum kernel (nmx_k_specmm.h): granules of four n, n < 250 live
+#define NMX_SMM_NG 63
+#define NMX_SMM_TAB_FLOATS (4 * NMX_SMM_NG * 64)
 #define NMX_MAX_FILTERS_DEV 24
 #define NMX_MAX_SW_COMBOS_DEV 48
 
@@ -170,7 +173,7 @@ struct NmxTimeOscArgs {
   int off_x, off_a, off_b, off_spec, off_red, lds_floats;
   const float* w500_tab;   // W = 1000: tables of the wave-level kernel (nmx_k_fft500.h), else NULL
   const unsigned short* w510_tab;   // 510-sample transforms: position tables of the prime-factor wave kernel (nmx_k_timeosc_w510.h)
-  const float* smm_tab;    // matrix-pipe spectrum kernel (nmx_k_specmm.h): [cos rows k0 .. k0 + 31 | sin rows][1000], else NULL
+  const float* smm_tab;    // matrix-pipe spectrum kernel (nmx_k_specmm.h): [cos even k, cos odd k, sin even k, sin odd k][n / 4][row 16][n % 4], else NULL
   int smm_k0;              // first bin of that table
   int starts_mod4;         // every window start of this launch is a multiple of 4 samples (16-byte loads of the lanes' runs)
 };

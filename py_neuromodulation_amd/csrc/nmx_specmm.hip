@@ -1,57 +1,104 @@
 // nmx_specmm.hip -- translation unit of the matrix-pipe spectrum kernel (nmx_k_specmm.h): FFT band power + Hjorth /
-// LineLength / Raw of 1000-sample windows, 32 windows per wave, four waves per workgroup (they share the staged DFT table).
+// LineLength / Raw of 1000-sample windows; 16 windows per wave, one persistent four-wave workgroup per CU (the waves share
+// the LDS-resident DFT table and nothing else).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 
 #include "nmx_k_specmm.h"
 
-extern __shared__ __attribute__((aligned(16))) float nmx_smem_smm[];
+#ifndef NMX_SMM_MINWAVES
+#define NMX_SMM_MINWAVES 2   // register budget of two waves per SIMD (the LDS admits one workgroup per CU): the scheduler
+#endif                       // spends a 512-register budget on instruction-level parallelism and spills
 
-// RING = 3: two workgroups per CU (256 registers per lane); RING = 4: one (512)
-template <int NB, bool TD, bool CLEAN, int RING>
-__global__ void __launch_bounds__(256, RING == 4 ? 1 : 2) nmx_kern_specmm_w1000(const NmxTimeOscArgs A0, long long n_items) {
-  // (kernel-argument pointer laundered once per tile: the plan -- 150 dwords -- is re-read with s_load instead of being
-  // hoisted, together with every loop-invariant band mask, into scalar registers that spill)
+extern __shared__ __attribute__((aligned(16))) char nmx_smem_smm[];
+
+template <int NB, bool TD, bool CLEAN>
+__global__ void __launch_bounds__(256, NMX_SMM_MINWAVES) nmx_kern_specmm_w1000(const NmxTimeOscArgs A0, long long n_items) {
   typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;
   nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
-  const int C = ((const NmxTimeOscArgs*)Ap)->n_channels, n_windows = (int)(n_items / C);
-  const long long n_groups = (long long)((n_windows + 31) / 32) * C, n_tiles = (n_groups + 3) / 4;
-#pragma unroll 1
-  for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    asm volatile("" : "+s"(Ap));
-    nmx_specmm_tile<NB, TD, CLEAN, RING>(*(const NmxTimeOscArgs*)Ap, 4 * t, n_windows, nmx_smem_smm);
+  const NmxTimeOscArgs& A = *(const NmxTimeOscArgs*)Ap;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds = nmx_lds_addr(nmx_smem_smm);
+  // the table, once per workgroup
+  {
+    const nmx_v4* tg = (const nmx_v4*)A.smm_tab;
+    nmx_v4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + 256 * i;
+      v[i] = tg[f < NMX_SMM_TAB_FLOATS / 4 ? f : NMX_SMM_TAB_FLOATS / 4 - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + 256 * i;
+      if (f < NMX_SMM_TAB_FLOATS / 4)
+        *(__attribute__((address_space(3))) nmx_v4*)(unsigned long)(lds + NMX_SMM_TAB_OFF + 16u * (unsigned)f) = v[i];
+    }
   }
+  __syncthreads();
+  const int C = A.n_channels, n_windows = (int)(n_items / C);
+  const long long n_tiles = (long long)((n_windows + 15) / 16) * C, stride = (long long)gridDim.x * NMX_SMM_WAVES;
+  long long t = (long long)blockIdx.x * NMX_SMM_WAVES + wave;
+  if (t >= n_tiles) return;
+  typedef NmxSmmWave<NB, TD, CLEAN> Wave;
+  Wave W(Ap, lds, wave, lane);
+  W.rows(t, n_windows);
+  W.adopt();
+  W.template dma<0>(0, W.src0, W.src1);
+  W.template dma<1>(1, W.src0, W.src1);
+#pragma unroll 1
+  for (;;) {
+    const long long tn = t + stride;
+    const bool more = tn < n_tiles;
+    typename Wave::Tile T;
+    Wave::clear(T);
+    W.template step<0>(T, more, tn, n_windows);
+    W.template step<1>(T, more, tn, n_windows);
+    W.template step<2>(T, more, tn, n_windows);
+    W.template step<3>(T, more, tn, n_windows);
+    W.template step<4>(T, more, tn, n_windows);
+    W.template step<5>(T, more, tn, n_windows);
+    W.template step<6>(T, more, tn, n_windows);
+    W.template step<7>(T, more, tn, n_windows);
+    W.finish(T, t, n_windows);
+    if (!more) break;
+    W.adopt();
+    t = tn;
+  }
+  W.flush();
 }
 
 // returns 0 when the configuration needs another kernel
 extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   static int on = -1;
-  // (opt-in while it is slower than nmx_kern_timeosc_w1000_low on the Mode A workload: 1.84 ms against 1.40 per 1 M windows;
-  // the same launch with cache-friendly loads 1.20 ms, the matrix pipe's own floor 0.86 -- profiles/r04_specmm.txt)
-  if (on < 0) { const char* v = getenv("NMX_SPECMM"); on = (v && v[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* v = getenv("NMX_SPECMM"); on = (v && v[0] == '0') ? 0 : 1; }
   if (!on || !nmx_specmm_ok(*A) || n_items < 1) return 0;
-  static int n_cu = 0;
-  if (!n_cu) {
+  static thread_local int n_cu = 0, n_cu_dev = -1;   // per host thread and device (multi-device streams)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (!n_cu || n_cu_dev != dev) {
     hipDeviceProp_t prop;
-    int dev = 0;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    n_cu_dev = dev;
   }
   const int n_win = n_items / A->n_channels;
-  const long long n_tiles = ((long long)((n_win + 31) / 32) * A->n_channels + 3) / 4;
-  static int wg_per_cu = 0, ring = 0;
-  if (!wg_per_cu) { const char* v = getenv("NMX_SPECMM_WG"); wg_per_cu = (v && atoi(v) >= 1 && atoi(v) <= 4) ? atoi(v) : 2; }
-  if (!ring) { const char* v = getenv("NMX_SPECMM_RING"); ring = (v && atoi(v) == 4) ? 4 : 3; }
-  if (ring == 4) wg_per_cu = 1;
-  long long grid = (long long)n_cu * wg_per_cu;
-  if (grid > n_tiles) grid = n_tiles;
-  const size_t lds = (size_t)NMX_SMM_LDS_FLOATS * 4;
+  const long long n_tiles = (long long)((n_win + 15) / 16) * A->n_channels;
+  long long grid = (n_tiles + NMX_SMM_WAVES - 1) / NMX_SMM_WAVES;
+  if (grid > n_cu) grid = n_cu;
+  const size_t lds = (size_t)NMX_SMM_LDS_BYTES;
   const bool td = (A->features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0, clean = A->clean_on_load != 0;
-#define NMX_SMM_LAUNCH(NB, TD, CL)                                                                                          \
-  do {                                                                                                                      \
-    if (ring == 4) hipLaunchKernelGGL((nmx_kern_specmm_w1000<NB, TD, CL, 4>), dim3((unsigned)grid), dim3(256), lds, s, *A, (long long)n_items); \
-    else hipLaunchKernelGGL((nmx_kern_specmm_w1000<NB, TD, CL, 3>), dim3((unsigned)grid), dim3(256), lds, s, *A, (long long)n_items);          \
+#define NMX_SMM_LAUNCH(NB, TD, CL)                                                                                       \
+  do {                                                                                                                   \
+    static unsigned long long seen = 0; /* per instantiation and device */                                               \
+    if (nmx_first_on_device(seen)) (void)hipFuncSetAttribute((const void*)nmx_kern_specmm_w1000<NB, TD, CL>,                                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, NMX_SMM_LDS_BYTES);                 \
+    hipLaunchKernelGGL((nmx_kern_specmm_w1000<NB, TD, CL>), dim3((unsigned)grid), dim3(256), lds, s, *A, (long long)n_items); \
   } while (0)
+#ifdef NMX_SMM_SINGLE
+  (void)td; (void)clean;
+  NMX_SMM_LAUNCH(4, true, false);
+#else
   if (A->n_bands <= 4) {
     if (td && clean) NMX_SMM_LAUNCH(4, true, true); else if (td) NMX_SMM_LAUNCH(4, true, false);
     else if (clean) NMX_SMM_LAUNCH(4, false, true); else NMX_SMM_LAUNCH(4, false, false);
@@ -61,6 +108,7 @@ extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream
     else if (clean) NMX_SMM_LAUNCH(8, false, true); else NMX_SMM_LAUNCH(8, false, false);
     nmxi_note_kernel("nmx_kern_specmm_w1000<8>");
   }
+#endif
 #undef NMX_SMM_LAUNCH
   return 1;
 }
