@@ -77,6 +77,7 @@ NMX_DEV void nmx_smm_dma8(const char* g0, const char* g1, const char* g2, const 
       "s_add_u32 m0, %9, 0xc00\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %4, off\n\t"
+#ifndef NMX_SMM_DEBUG_HALFDMA
       "s_add_u32 m0, %9, 0x1000\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %5, off\n\t"
@@ -89,6 +90,7 @@ NMX_DEV void nmx_smm_dma8(const char* g0, const char* g1, const char* g2, const 
       "s_add_u32 m0, %9, 0x1c00\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %8, off\n\t"
+#endif
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7), "s"(lds_base)
@@ -187,7 +189,11 @@ struct NmxSmmWave {
   template <int C>
   NMX_DEV void dma(unsigned slot, const char* s0, const char* s1) {
     // byte offsets of the step's runs inside a window: a, b, c, d
+#ifdef NMX_SMM_DEBUG_CONTIG   // (experiment: the step's 512 bytes of a window in ONE run -- wrong results)
+    constexpr int oa = 512 * C, ob = 512 * C + 128, oc = 512 * C + 256, od = C == 7 ? 3872 : 512 * C + 384;
+#else
     constexpr int oa = 128 * C, ob = 1872 - 128 * C, oc = 2000 + 128 * C, od = 3872 - 128 * C;
+#endif
     nmx_smm_dma8(s0 + oa, s1 + oa, s0 + ob, s1 + ob, s0 + oc, s1 + oc, s0 + od, s1 + od,
                  (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + slot * NMX_SMM_STEP_BYTES)));
   }
@@ -262,7 +268,11 @@ struct NmxSmmWave {
   NMX_DEV void step(Tile& T, bool more, long long t_next, int n_windows) {
     const bool dma_ahead = C < 6 || more, next_in_flight = C < 7 || more;
     // the newest eight DMAs (the step after this one) may still be in flight
+#ifdef NMX_SMM_DEBUG_HALFDMA   // (experiment: half the bytes per step in flight -- wrong results)
+    if (next_in_flight) nmx_smm_wait_vm<4>(); else nmx_smm_wait_vm<0>();
+#else
     if (next_in_flight) nmx_smm_wait_vm<8>(); else nmx_smm_wait_vm<0>();
+#endif
     if (C == 0) flush();
     if (C == 5 && more) rows(t_next, n_windows);
     const unsigned cur = ring + r * NMX_SMM_STEP_BYTES;
@@ -309,6 +319,12 @@ struct NmxSmmWave {
       const unsigned slot = r == 0 ? 2u : r - 1u;
       if (C < 6) dma<(C + 2) & 7>(slot, src0, src1); else dma<(C + 2) & 7>(slot, nsrc0, nsrc1);
     }
+#ifdef NMX_SMM_DEBUG_NOCOMP   // (experiment: the streaming rate of the DMA pipeline alone -- wrong results)
+    T.acc[0][0] += va[0] + vb[1] + vc[2] + vd[3] + tab[0][0][0];
+    r = r == 2 ? 0u : r + 1u;
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+#endif
     // fold: n = 32 C + 8 ks + i pairs a[i], b[7 - i] (address order reversed), c[i], d[7 - i]
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
