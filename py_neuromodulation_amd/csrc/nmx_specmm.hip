@@ -1,66 +1,54 @@
 // nmx_specmm.hip -- translation unit of the matrix-pipe spectrum kernel (nmx_k_specmm.h): FFT band power + Hjorth /
 // LineLength / Raw of 1000-sample windows; 16 windows per wave, one persistent four-wave workgroup per CU (the waves share
-// the LDS-resident DFT table and nothing else).
+// nothing: the DFT table lives in each lane's registers, the LDS is four rings of step buffers).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 
 #include "nmx_k_specmm.h"
 
-#ifndef NMX_SMM_MINWAVES
-#define NMX_SMM_MINWAVES 2   // register budget of two waves per SIMD (the LDS admits one workgroup per CU): the scheduler
-#endif                       // spends a 512-register budget on instruction-level parallelism and spills
-
 extern __shared__ __attribute__((aligned(16))) char nmx_smem_smm[];
 
+// one wave per SIMD: the 512-entry register file holds a lane's 256 table entries next to its working set
 template <int NB, bool TD, bool CLEAN>
-__global__ void __launch_bounds__(256, NMX_SMM_MINWAVES) nmx_kern_specmm_w1000(const NmxTimeOscArgs A0, long long n_items) {
+__global__ void __launch_bounds__(256, 1) nmx_kern_specmm_w1000(const NmxTimeOscArgs A0, long long n_items) {
   typedef const NmxTimeOscArgs __attribute__((address_space(4)))* nmx_karg_p;
   nmx_karg_p Ap = (nmx_karg_p)__builtin_amdgcn_kernarg_segment_ptr();
   const NmxTimeOscArgs& A = *(const NmxTimeOscArgs*)Ap;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds = nmx_lds_addr(nmx_smem_smm);
-  // the table, once per workgroup
-  {
-    const nmx_v4* tg = (const nmx_v4*)A.smm_tab;
-    nmx_v4 v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int f = tid + 256 * i;
-      v[i] = tg[f < NMX_SMM_TAB_FLOATS / 4 ? f : NMX_SMM_TAB_FLOATS / 4 - 1];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int f = tid + 256 * i;
-      if (f < NMX_SMM_TAB_FLOATS / 4)
-        *(__attribute__((address_space(3))) nmx_v4*)(unsigned long)(lds + NMX_SMM_TAB_OFF + 16u * (unsigned)f) = v[i];
-    }
-  }
-  __syncthreads();
   const int C = A.n_channels, n_windows = (int)(n_items / C);
   const long long n_tiles = (long long)((n_windows + 15) / 16) * C, stride = (long long)gridDim.x * NMX_SMM_WAVES;
   long long t = (long long)blockIdx.x * NMX_SMM_WAVES + wave;
   if (t >= n_tiles) return;
   typedef NmxSmmWave<NB, TD, CLEAN> Wave;
+  constexpr int R = Wave::R;
   Wave W(Ap, lds, wave, lane);
   W.rows(t, n_windows);
   W.adopt();
+  // the first R steps of the first tile, one per slot; then step 0 into registers
   W.template dma<0>(0, W.src0, W.src1);
   W.template dma<1>(1, W.src0, W.src1);
+  W.template dma<2>(2, W.src0, W.src1);
+  if (R > 3) W.template dma<3>(3, W.src0, W.src1);
+  if (R > 4) W.template dma<4>(4, W.src0, W.src1);
+  nmx_smm_wait_vm<8 * (R - 1)>();
+  NmxSmmRegs Cu;
+  W.template read<0>(0, 0, Cu);
 #pragma unroll 1
   for (;;) {
     const long long tn = t + stride;
     const bool more = tn < n_tiles;
     typename Wave::Tile T;
     Wave::clear(T);
-    W.template step<0>(T, more, tn, n_windows);
-    W.template step<1>(T, more, tn, n_windows);
-    W.template step<2>(T, more, tn, n_windows);
-    W.template step<3>(T, more, tn, n_windows);
-    W.template step<4>(T, more, tn, n_windows);
-    W.template step<5>(T, more, tn, n_windows);
-    W.template step<6>(T, more, tn, n_windows);
-    W.template step<7>(T, more, tn, n_windows);
+    W.template step<0>(T, Cu, more, tn, n_windows);
+    W.template step<1>(T, Cu, more, tn, n_windows);
+    W.template step<2>(T, Cu, more, tn, n_windows);
+    W.template step<3>(T, Cu, more, tn, n_windows);
+    W.template step<4>(T, Cu, more, tn, n_windows);
+    W.template step<5>(T, Cu, more, tn, n_windows);
+    W.template step<6>(T, Cu, more, tn, n_windows);
+    W.template step<7>(T, Cu, more, tn, n_windows);
     W.finish(T, t, n_windows);
     if (!more) break;
     W.adopt();
@@ -68,6 +56,8 @@ __global__ void __launch_bounds__(256, NMX_SMM_MINWAVES) nmx_kern_specmm_w1000(c
   }
   W.flush();
 }
+
+extern "C" void nmx_wave_launch_timeosc_w1000_todo(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 
 // returns 0 when the configuration needs another kernel
 extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
@@ -87,7 +77,7 @@ extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream
   long long grid = (n_tiles + NMX_SMM_WAVES - 1) / NMX_SMM_WAVES;
   if (grid > n_cu) grid = n_cu;
   const size_t lds = (size_t)NMX_SMM_LDS_BYTES;
-  const bool td = (A->features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0, clean = A->clean_on_load != 0;
+  const bool td = (A->features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) != 0, clean = false;   // (cleaning is the todo kernel's: nmx_k_specmm.h, finish())
 #define NMX_SMM_LAUNCH(NB, TD, CL)                                                                                       \
   do {                                                                                                                   \
     static unsigned long long seen = 0; /* per instantiation and device */                                               \
@@ -110,5 +100,6 @@ extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream
   }
 #endif
 #undef NMX_SMM_LAUNCH
+  if (A->clean_on_load) nmx_wave_launch_timeosc_w1000_todo(A, n_items, s);
   return 1;
 }

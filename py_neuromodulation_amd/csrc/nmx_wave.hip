@@ -280,6 +280,49 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
   return 1;
 }
 
+// The windows the matrix-pipe kernel (nmx_k_specmm.h) flagged -- a NaN or an infinity among the samples: it does not clean
+// on load -- through the wave-level kernel's item code, which does.  One 16-bit mask per tile of that kernel (16
+// consecutive windows of a channel, tile = group * n_channels + channel); a wave looks at 64 masks at a time; a clean
+// recording never sets a bit.
+template <int NB>
+__global__ void __launch_bounds__(64) nmx_kern_timeosc_w1000_todo(const NmxTimeOscArgs A, int n_items) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int C = A.n_channels, n_windows = n_items / C, n_tiles = ((n_windows + 15) / 16) * C;
+  NmxW500TwReg T;
+  bool loaded = false;
+  for (int base = (int)blockIdx.x * 64; base < n_tiles; base += (int)gridDim.x * 64) {
+    const int i = base + lane;
+    const unsigned mine = i < n_tiles ? A.todo[i] : 0u;
+    unsigned long long m = __ballot(mine != 0u);
+    while (m) {
+      const int src = (int)__ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int tile = base + src;
+      unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, src);
+      const int g = tile / C, c = nmx_uniform_i(tile - g * C);
+      while (bits) {
+        const int j = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        if (!loaded) { T.load(A.w500_tab, lane); loaded = true; }
+        const int w = nmx_uniform_i(16 * g + j);
+        NmxTdRegs R;
+        nmx_td_load<1000>(A, w, c, R);
+        nmx_timeosc_w1000_body<NB, false, NmxW500TwReg, false, 0>(A, w, c, R, T, nmx_smem_wave);
+        NMX_WAVE_FENCE();
+      }
+    }
+  }
+}
+extern "C" void nmx_wave_launch_timeosc_w1000_todo(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
+  const size_t lds = (size_t)NMX_TOW_LDS_FLOATS_NOSTFT * 4;
+  const int n_windows = n_items / A->n_channels, n_tiles = ((n_windows + 15) / 16) * A->n_channels;
+  const int blocks = (n_tiles + 63) / 64;
+  const int grid = blocks < 256 * 8 ? blocks : 256 * 8;
+  if (A->n_bands <= 4) hipLaunchKernelGGL(nmx_kern_timeosc_w1000_todo<4>, dim3(grid), dim3(64), lds, s, *A, n_items);
+  else hipLaunchKernelGGL(nmx_kern_timeosc_w1000_todo<8>, dim3(grid), dim3(64), lds, s, *A, n_items);
+  nmxi_note_kernel("nmx_kern_timeosc_w1000_todo");
+}
+
 // STFT with 500-sample segments on windows of other lengths (<= 2048), the only time / oscillatory feature
 template <int NB>
 __global__ void __launch_bounds__(256) nmx_kern_timeosc_stft500(const NmxTimeOscArgs A, int n_items) {
