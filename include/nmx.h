@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NMX_ABI_VERSION 7
+#define NMX_ABI_VERSION 8
 
 /* error codes */
 #define NMX_OK 0
@@ -204,6 +204,29 @@ const char* nmx_last_error(void);           /* thread-local message of the last 
 int nmx_plan_create(const nmx_plan_desc* desc, nmx_plan** out);
 int nmx_plan_destroy(nmx_plan* plan);
 int nmx_plan_n_outputs(const nmx_plan* plan, int64_t* n_outputs);
+
+/* Offset split of the fp32 path.  The reference computes in float64 from the raw recording
+ * (stream/data_processor.py:238-260): a channel's DC offset of 10^3 .. 10^5 times its signal costs it nothing, a cast to
+ * float32 rounds at the offset's magnitude.  A plan therefore accepts a recording as  x[j][t] = u[j][t] + d[j]:
+ *   nmx_plan_set_offsets   d_in[n_channels_in] float64 (copied; NULL = none): every x handed to nmx_process_batch /
+ *                          _batch_tap AFTERWARDS is u = x - d, formed by the caller in float64 BEFORE its cast;
+ *                          nmx_process_window / nmx_preprocess_window (float64 in) subtract d themselves.  The constants
+ *                          travel through the linear stages in float64 (re-reference: R d; notch: d * sum of taps), the
+ *                          features that see a constant (Raw, bin 0 of the FFT, the STFT's window share, the zero-padded
+ *                          FIR bank) get it back on the device; results are those of the recording x.
+ *                          NMX_E_INVALID for a plan that cannot carry offsets (nmx_plan_carries_offsets: a resampler, a
+ *                          raw normaliser, a preprocessing filter or a notch longer than the window is not affine in
+ *                          the window the way the split needs).
+ *   without host offsets   float32 input in front of a re-reference is split by the library: the mean of a row over the first
+ *                          window the plan ever sees is that row's constant when it exceeds four times the row's spread
+ *                          there (learned once; part of the state of nmx_state_*,
+ *                          cleared by nmx_state_reset), subtracted where the re-reference kernel loads the sample.
+ *   nmx_plan_get_offsets   d_in[n_channels_in] = host + learned constants of the input rows, d_pre[n_channels] = offset of
+ *                          the PRE-PROCESSED windows (what nmx_process_batch_tap's float32 windows have to be raised by),
+ *                          *state = bit 0 host offsets set | bit 1 constants learned; any pointer may be NULL. */
+int nmx_plan_carries_offsets(const nmx_plan* plan, int* yes);
+int nmx_plan_set_offsets(nmx_plan* plan, const double* d_in);
+int nmx_plan_get_offsets(nmx_plan* plan, double* d_in, double* d_pre, int* state);
 
 /* Batch of windows over a continuous recording x[C_in][T] (row-major, channel stride ldx),
  * window i = samples [starts[i], starts[i] + W)  (stream/generator.py:41-53).

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 7
+NMX_ABI_VERSION = 8
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -85,6 +85,7 @@ _EXPORTS = [
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
     "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free",
+    "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets",
 ]
 
 
@@ -143,6 +144,9 @@ class NmxLibrary:
         L.nmx_plan_attach_norm.argtypes = [C.c_void_p, C.c_void_p]
         L.nmx_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
         L.nmx_host_free.argtypes = [C.c_void_p]
+        L.nmx_plan_carries_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.nmx_plan_set_offsets.argtypes = [C.c_void_p, C.c_void_p]
+        L.nmx_plan_get_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         if L.nmx_abi_version() != NMX_ABI_VERSION:
             raise NmxError("libnmx ABI version mismatch")
 

@@ -311,6 +311,10 @@ static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
   if (A.b.pad_mode != 0 && n_items >= 1024 && nmx_w64q_launch_notch_rd64(&A, n_items, s)) return;
   nmx_w64_launch_rd64(&A, n_items, lds, s);
 }
+extern "C" int nmx_w64_takes_dc_rd64(const NmxBankW64Args*, int);
+static bool be_bank_w64_takes_dc(const NmxBankW64Args& A, int n_items) { return nmx_w64_takes_dc_rd64(&A, n_items) != 0; }
+extern "C" int nmx_wave_timeosc_takes_dc(const NmxTimeOscArgs* A);
+static bool be_timeosc_takes_dc(const NmxTimeOscArgs& A) { return nmx_wave_timeosc_takes_dc(&A) != 0; }
 extern "C" void nmx_wave_launch_sharp_dense(const NmxSharpArgs* A, int n_items, hipStream_t s);
 static void be_launch_sharp_dense(const NmxSharpArgs& A, int n_items, be_stream_t s) {
   be_init_once();

@@ -176,6 +176,9 @@ struct NmxTimeOscArgs {
   const float* smm_tab;    // matrix-pipe spectrum kernel (nmx_k_specmm.h): [cos even k, cos odd k, sin even k, sin odd k][n / 4][row 16][n % 4], else NULL
   int smm_k0;              // first bin of that table
   int starts_mod4;         // every window start of this launch is a multiple of 4 samples (16-byte loads of the lanes' runs)
+  const float* dcf;        // [n_channels] offset the windows were split from (nmx_engine_dc.inc), or NULL: the true window is
+                           // x + dcf[c].  Differences and variances do not see a constant; Raw, bin 0 of the FFT and the STFT's
+                           // window-DFT share (NmxOsc::wdc) do
   unsigned short* todo;    // matrix-pipe kernel: [ceil(n_windows / 16)][n_channels] masks, bit j = window 16 g + j of the channel holds
                            // a NaN / an infinity (the kernel does not clean on load) and is left to nmx_kern_timeosc_w1000_todo;
                            // NULL without that kernel

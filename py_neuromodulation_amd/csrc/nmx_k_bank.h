@@ -38,6 +38,8 @@ struct NmxBankArgs {
   const long long* starts;
   float* out;
   int n_outputs, n_channels, W, clean_on_load;
+  const float* dcf;  // [n_channels] constant ADDED to every sample on load, or NULL: the offset the engine carries next to a
+                     // split stream (nmx_engine_dc.inc) -- a zero-padded FIR does see a window's DC level (edge transients)
   int M;            // circular convolution length (even)
   int pad_mode;     // 0 zero-pad ("same"), 1 odd reflection (notch)
   int n_edge;       // reflect_limited: samples available for reflection (min(L, W) - 1)
@@ -79,9 +81,9 @@ struct NmxBankArgs {
 };
 
 // partitioned overlap-save (NmxBankArgs::ups_*), step 1: the spectra of all frames of one (window, channel)
-NMX_DEV void nmx_bank_ups_frames(const NmxBankArgs& A, const float* src, float2* S, float2* bufA, float2* bufB) {
+NMX_DEV void nmx_bank_ups_frames(const NmxBankArgs& A, const float* src, float2* S, float2* bufA, float2* bufB, float dc = 0.f) {
   const int W = A.W, B = A.ups_B, hm = A.ups_hm, ne = A.n_edge, clean = A.clean_on_load;
-  auto raw = [&](int k) -> float { const float v = src[k]; return clean ? nmx_clean(v) : v; };
+  auto raw = [&](int k) -> float { const float v = src[k]; return (clean ? nmx_clean(v) : v) + dc; };
   const float x0 = raw(0), xl = raw(W - 1);
   auto u = [&](int t) -> float {   // u[t] = x_ext[t - hm] on [0, W + 2 hm), 0 elsewhere
     if (t < 0 || t >= W + 2 * hm) return 0.f;
@@ -149,7 +151,7 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
   if (A.partitioned) {   // ---- partitioned overlap-save (see NmxBankArgs::partitioned): y in LDS, the same epilogues ----------
     float* y = smem + A.off_X;
     float2* S = A.ups_scratch + (long long)slot * A.ups_frames * (A.ups_B + 1);
-    nmx_bank_ups_frames(A, src, S, bufA, bufB);
+    nmx_bank_ups_frames(A, src, S, bufA, bufB, A.dcf ? A.dcf[c] : 0.f);
     for (int fi = 0; fi < A.n_filters; ++fi) {
       const NmxFilterDev& F = A.f[fi];
       nmx_bank_ups_filter(A, F, S, y, bufA, bufB);
@@ -188,6 +190,10 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
         v0 = nmx_clean(v0);
         v1 = nmx_clean(v1);
       }
+      if (A.dcf) {
+        if (n0 < W) v0 += A.dcf[c];
+        if (n0 + 1 < W) v1 += A.dcf[c];
+      }
       bufB[i] = make_float2(v0, v1);
     }
   } else {
@@ -195,6 +201,7 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
     for (int i = NMX_TID; i < W; i += NMX_NT) {
       float v = src[i];
       if (A.clean_on_load) v = nmx_clean(v);
+      if (A.dcf) v += A.dcf[c];
       xs[i] = v;
     }
     NMX_SYNC();

@@ -340,6 +340,14 @@ NMX_DEV void nmx_bank_w64c_item(const NmxBankW64Args& AA, int w, int c, const Nm
     NMX_UNROLL
     for (int j = 0; j < 16; ++j) v[j] = nmx_mk2(nmx_clean_bl(v[j].x), nmx_clean_bl(v[j].y));
   }
+  if (A.dcf) {   // the offset the stream was split from (nmx_engine_dc.inc), on the samples that exist (not on the zero padding)
+    const nmx_c2 dd = nmx_mk2(A.dcf[c], two ? A.dcf[c + 1] : 0.f);
+    NMX_UNROLL
+    for (int j = 0; j < 16; ++j) {
+      if (64 * j + 63 < W) v[j] += dd;
+      else if (l + 64 * j < W) v[j] += dd;
+    }
+  }
   // ---- the second channel at the first one's scale: an exact power of two -------------------------------------------
   float m1 = 0.f, m2 = 0.f;
   NMX_UNROLL

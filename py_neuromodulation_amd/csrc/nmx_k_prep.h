@@ -6,6 +6,10 @@
 //     per channel, so the channel-space map commutes and is applied once per sample here
 //     instead of once per (window, sample) (10x less work at 90 % overlap).  The row
 //     selection data[feature_idx] is folded into R by the host.
+//     Every kernel here can SUBTRACT a per-row constant on load (`sub`, NULL = none): the engine's offset split
+//     (nmx_engine_dc.inc) -- the re-referenced stream then carries the signal without the rows' DC offsets, fp32
+//     rounding is relative to the signal, and the constant R . sub travels next to it analytically.
+//     nan_to_num comes first: a NaN sample is the VALUE 0 of the recording, i.e. -sub in the split domain.
 //  nmx_nanmask_item: mask[w][j] = any(isnan(x[j][start_w : start_w + W]))
 //     (stream/data_processor.py:253), one wave per (window, input row).
 //  nmx_tap_item: y[w][c][0..W) = the pre-processed window the features read (the argument of
@@ -25,7 +29,14 @@ struct NmxRerefArgs {
   const float* R;     // [C][C_in]
   int C, C_in;
   long long T;
+  const float* sub;   // [C_in] subtracted on load, or NULL
+  const float* nanv;  // [C_in] what a NaN sample becomes: the recording's value 0 in the split domain, -(offset); NULL = 0
 };
+NMX_DEV float nmx_clean_sub(float v, const float* sub, const float* nanv, int j) {
+  if (v != v) return nanv ? nanv[j] : 0.f;
+  v = nmx_clean(v);
+  return sub ? v - sub[j] : v;
+}
 
 // block = 256 threads <-> 256 consecutive samples; blockIdx.y <-> NMX_REREF_ROWS output rows
 NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
@@ -36,7 +47,7 @@ NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
   for (int i = 0; i < NMX_REREF_ROWS; ++i) acc[i] = 0.0;
   const int nrow = (A.C - c0) < NMX_REREF_ROWS ? (A.C - c0) : NMX_REREF_ROWS;
   for (int j = 0; j < A.C_in; ++j) {
-    const float v = nmx_clean(A.x[(long long)j * A.ldx + t]);
+    const float v = nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
@@ -57,14 +68,16 @@ struct NmxCarArgs {
   int C;
   long long T;
   float diag, off;
+  const float* sub;   // [C] subtracted on load, or NULL
+  const float* nanv;  // [C] a NaN sample's value (see NmxRerefArgs), or NULL
 };
 
 NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
   if (t >= A.T) return;
   float s = 0.f;
-  for (int j = 0; j < A.C; ++j) s += nmx_clean(A.x[(long long)j * A.ldx + t]);
+  for (int j = 0; j < A.C; ++j) s += nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
   const float a = A.diag - A.off, b = A.off * s;
-  for (int j = 0; j < A.C; ++j) A.y[(long long)j * A.ldy + t] = a * nmx_clean(A.x[(long long)j * A.ldx + t]) + b;
+  for (int j = 0; j < A.C; ++j) A.y[(long long)j * A.ldy + t] = a * nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b;
 }
 
 #ifndef NMX_HOST_EMU
@@ -82,16 +95,21 @@ NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, float* red) {
     for (; j + 12 < A.C; j += 16) {   // four independent loads in flight
       const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 4) * A.ldx + t];
       const float v2 = A.x[(long long)(j + 8) * A.ldx + t], v3 = A.x[(long long)(j + 12) * A.ldx + t];
-      s += nmx_clean(v0); s += nmx_clean(v1); s += nmx_clean(v2); s += nmx_clean(v3);
+      if (A.sub || A.nanv) {
+        s += nmx_clean_sub(v0, A.sub, A.nanv, j); s += nmx_clean_sub(v1, A.sub, A.nanv, j + 4);
+        s += nmx_clean_sub(v2, A.sub, A.nanv, j + 8); s += nmx_clean_sub(v3, A.sub, A.nanv, j + 12);
+      } else {
+        s += nmx_clean(v0); s += nmx_clean(v1); s += nmx_clean(v2); s += nmx_clean(v3);
+      }
     }
-    for (; j < A.C; j += 4) s += nmx_clean(A.x[(long long)j * A.ldx + t]);
+    for (; j < A.C; j += 4) s += nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
   }
   red[q * 64 + lane] = s;
   __syncthreads();
   const float tot = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
   if (!in) return;
   const float a = A.diag - A.off, b = A.off * tot;
-  for (int j = q; j < A.C; j += 4) A.y[(long long)j * A.ldy + t] = a * nmx_clean(A.x[(long long)j * A.ldx + t]) + b;
+  for (int j = q; j < A.C; j += 4) A.y[(long long)j * A.ldy + t] = a * nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b;
 }
 #endif
 
@@ -118,6 +136,8 @@ struct NmxRerefStructArgs {
   int n_groups;
   const int* members;    // concatenated member rows of the groups
   int group_off[NMX_RS_GROUPS + 1];
+  const float* sub;      // [C_in] subtracted on load, or NULL
+  const float* nanv;     // [C_in] a NaN sample's value (see NmxRerefArgs), or NULL
 };
 
 NMX_DEV void nmx_reref_struct_sample(const NmxRerefStructArgs& A, long long t) {
@@ -126,14 +146,14 @@ NMX_DEV void nmx_reref_struct_sample(const NmxRerefStructArgs& A, long long t) {
   for (int g = 0; g < A.n_groups; ++g) {
     double s = 0.0;
     for (int m = A.group_off[g]; m < A.group_off[g + 1]; ++m)
-      s += (double)nmx_clean(A.x[(long long)A.members[m] * A.ldx + t]);
+      s += (double)nmx_clean_sub(A.x[(long long)A.members[m] * A.ldx + t], A.sub, A.nanv, A.members[m]);
     S[g] = s;
   }
   for (int r = 0; r < A.C; ++r) {
     double acc = A.row_group[r] >= 0 ? (double)A.row_b[r] * S[A.row_group[r]] : 0.0;
     for (int k = 0; k < NMX_RS_TAPS; ++k) {
       const float c = A.row_coef[r * NMX_RS_TAPS + k];
-      if (c != 0.f) acc += (double)c * (double)nmx_clean(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t]);
+      if (c != 0.f) acc += (double)c * (double)nmx_clean_sub(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t], A.sub, A.nanv, A.row_idx[r * NMX_RS_TAPS + k]);
     }
     A.y[(long long)r * A.ldy + t] = (float)acc;
   }
@@ -153,11 +173,13 @@ NMX_DEV void nmx_reref_struct_tile(const NmxRerefStructArgs& A, long long t0, do
       int m = A.group_off[g] + q;
       const int end = A.group_off[g + 1];
       for (; m + 12 < end; m += 16) {   // four independent loads in flight
-        const float v0 = A.x[(long long)A.members[m] * A.ldx + t], v1 = A.x[(long long)A.members[m + 4] * A.ldx + t];
-        const float v2 = A.x[(long long)A.members[m + 8] * A.ldx + t], v3 = A.x[(long long)A.members[m + 12] * A.ldx + t];
-        s += ((double)nmx_clean(v0) + (double)nmx_clean(v1)) + ((double)nmx_clean(v2) + (double)nmx_clean(v3));
+        const int j0 = A.members[m], j1 = A.members[m + 4], j2 = A.members[m + 8], j3 = A.members[m + 12];
+        const float v0 = A.x[(long long)j0 * A.ldx + t], v1 = A.x[(long long)j1 * A.ldx + t];
+        const float v2 = A.x[(long long)j2 * A.ldx + t], v3 = A.x[(long long)j3 * A.ldx + t];
+        s += ((double)nmx_clean_sub(v0, A.sub, A.nanv, j0) + (double)nmx_clean_sub(v1, A.sub, A.nanv, j1)) +
+             ((double)nmx_clean_sub(v2, A.sub, A.nanv, j2) + (double)nmx_clean_sub(v3, A.sub, A.nanv, j3));
       }
-      for (; m < end; m += 4) s += (double)nmx_clean(A.x[(long long)A.members[m] * A.ldx + t]);
+      for (; m < end; m += 4) s += (double)nmx_clean_sub(A.x[(long long)A.members[m] * A.ldx + t], A.sub, A.nanv, A.members[m]);
     }
     red[(g * 4 + q) * 64 + lane] = s;
   }
@@ -172,7 +194,7 @@ NMX_DEV void nmx_reref_struct_tile(const NmxRerefStructArgs& A, long long t0, do
     for (int k = 0; k < NMX_RS_GROUPS; ++k) if (k == g) acc = (double)A.row_b[r] * S[k];   // (no dynamic register indexing)
     for (int k = 0; k < NMX_RS_TAPS; ++k) {
       const float c = A.row_coef[r * NMX_RS_TAPS + k];
-      if (c != 0.f) acc += (double)c * (double)nmx_clean(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t]);
+      if (c != 0.f) acc += (double)c * (double)nmx_clean_sub(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t], A.sub, A.nanv, A.row_idx[r * NMX_RS_TAPS + k]);
     }
     A.y[(long long)r * A.ldy + t] = (float)acc;
   }
@@ -205,13 +227,16 @@ struct NmxTapArgs {
   float* y;                 // [n_windows][C][W]
   int C, W;
   int clean;                // nan_to_num while copying (no stage has cleaned the samples yet)
+  const float* add;         // [C] constant added to every sample of a row (the carried offset: a kernel that cannot
+                            // take it on load reads this copy instead), or NULL
 };
 
 NMX_DEV void nmx_tap_item(const NmxTapArgs& A, int w, int c) {
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? A.starts[w] : 0);
   float* dst = A.y + ((long long)w * A.C + c) * A.W;
   for (int i = NMX_TID; i < A.W; i += NMX_NT) {
-    const float v = src[i];
-    dst[i] = A.clean ? nmx_clean(v) : v;
+    float v = src[i];
+    v = A.clean ? nmx_clean(v) : v;
+    dst[i] = A.add ? v + A.add[c] : v;
   }
 }

@@ -12,6 +12,19 @@
 
 #include "nmx_k_timeosc.h"
 
+// NmxTimeOscArgs::dcf[c] for a wave-uniform c: through the CONSTANT address space on the device (an s_load, lgkmcnt) --
+// a vector load's s_waitcnt vmcnt(0) would also wait for every load in flight (the prefetching kernels); the table is
+// written by the host before the launch
+NMX_DEV float nmx_dc_of(const NmxTimeOscArgs& A, int c) {
+  if (!A.dcf) return 0.f;
+#ifdef NMX_HOST_EMU
+  return A.dcf[c];
+#else
+  typedef const float __attribute__((address_space(4)))* nmx_cf_p;
+  return ((nmx_cf_p)(unsigned long long)A.dcf)[c];
+#endif
+}
+
 #ifndef NMX_HOST_EMU
 // value of `v` in lane + 1; lane 63 receives `wrap` (wave-uniform)
 NMX_DEV float nmx_from_next_lane(float v, float wrap, int lane) {
@@ -151,7 +164,7 @@ NMX_DEV void nmx_scan_emit(const NmxTimeOscArgs& A, int w, int c, NmxScanRegs& R
       const float wm1 = (float)(W - 1);
       out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = p3 / wm1 / wm1;
     }
-    if (A.features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = last;
+    if (A.features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = last + nmx_dc_of(A, c);
   }
 }
 

@@ -575,7 +575,7 @@ struct NmxSmmWave {
       }
       pend.act = act; pend.mob = mob; pend.comp = comp;
       pend.ll = sa * rW1 * rW1;
-      pend.raw = T.xlast;
+      pend.raw = T.xlast + (A.dcf ? A.dcf[c] : 0.f);   // (+ the offset the stream was split from)
     }
     pend.ch = c;
     const bool mine = ks == 0 && w < n_windows;

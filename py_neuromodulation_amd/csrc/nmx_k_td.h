@@ -247,7 +247,7 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
   if (!p3_done && (features & NMXD_F_LINELENGTH)) p3 = nmx_wave_reduce(p3, 0.f, add);
   if (lane == 0) {
     if (features & NMXD_F_LINELENGTH) out_row[A.ll_cols.base + c * A.ll_cols.ch_stride] = p3 * rW1 * rW1;
-    if (features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = R.last.y;
+    if (features & NMXD_F_RAW) out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = R.last.y + nmx_dc_of(A, c);
   }
   return true;
 }

@@ -139,6 +139,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
   float* red = smem + A.off_red;
   const int W = A.W;
   float* out_row = A.out + (long long)w * A.n_outputs;
+  const float dcv = A.dcf ? A.dcf[c] : 0.f;   // the constant the window was split from: window = xs + dcv
 
   // ---- stage the window in LDS (lane-consecutive, coalesced) ---------------------------
   const float* src = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride +
@@ -201,7 +202,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     }
   }
   if ((A.features & NMXD_F_RAW) && NMX_TID == 0)
-    out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = xs[W - 1];
+    out_row[A.raw_cols.base + c * A.raw_cols.ch_stride] = xs[W - 1] + dcv;
 
   // ---- FFT band power -------------------------------------------------------------------
   if (A.fft.enabled) {
@@ -223,7 +224,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     const float2* Z = nmx_osc_fft(O, bufA, bufB);
     for (int k = O.k_lo + NMX_TID; k < O.k_hi; k += NMX_NT) {
       float2 X = nmx_osc_bin(O, Z, k);
-      if (k == 0) X = make_float2(xsum, 0.f);
+      if (k == 0) X = make_float2(xsum + (float)N * dcv, 0.f);
       float v = nmx_sqrt_fast(X.x * X.x + X.y * X.y);
       if (O.log_transform) v = nmx_log10_fast(v);
       spec[k - O.k_lo] = v;
@@ -296,7 +297,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     const int seg_padded = O.nadd ? O.nseg - 1 : -1;
     auto with_dc = [&](float2 X, int sgi, int k) -> float2 {
       const float2 t = O.wdc[(sgi == seg_padded ? O.nfreq : 0) + k];
-      return make_float2(X.x + mean * t.x, X.y + mean * t.y);
+      return make_float2(X.x + (mean + dcv) * t.x, X.y + (mean + dcv) * t.y);
     };
     int sg_first = 0;
 #ifndef NMX_HOST_EMU

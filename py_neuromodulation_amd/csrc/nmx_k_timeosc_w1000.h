@@ -138,6 +138,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 
   const bool spec1000 = fft_on || welch_on;
   float wsum;
+  const float dcv = nmx_dc_of(A, c);   // the constant the window was split from (0 without a split)
   NMX_PROF_DECL
   {
     // time domain on packed arithmetic (nmx_k_td.h); it also leaves the centred window in fb for the transform
@@ -206,7 +207,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       acc.clear();
       for (int k = O.k_lo + lane; k < O.k_hi; k += 64) {
         // (low-band forms: 0 <= k < 100, no mirrored bin)
-        const float2 X = k == 0 ? make_float2(wsum, 0.f) : (LOW ? nmx_rfft_bin(Z, twr, 500, k) : xbin(k));
+        const float2 X = k == 0 ? make_float2(wsum + 1000.f * dcv, 0.f) : (LOW ? nmx_rfft_bin(Z, twr, 500, k) : xbin(k));
         const float pw = X.x * X.x + X.y * X.y;
         const float v = fft_log ? nmx_log10_half_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
@@ -292,8 +293,9 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
         float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
         if (k < 2) {   // (all five segments are full: wdc[0]; real for the symmetric window up to the table's rounding)
           const float2 t = O.wdc[k];
-          ax += mean * t.x; ay += mean * t.y;
-          bx += mean * t.x; by += mean * t.y;
+          const float mt = mean + dcv;   // (the window's own mean + the offset it was split from)
+          ax += mt * t.x; ay += mt * t.y;
+          bx += mt * t.x; by += mt * t.y;
         }
         const float pa = ax * ax + ay * ay;
         const float va = O.log_transform ? nmx_log10_half_fast(pa) + lscale : sqrtf(pa) * O.scale;

@@ -294,6 +294,21 @@ __global__ void __launch_bounds__(64 * 8) NMX_CAT(nmx_kern_bank_w64e_, NMX_W64_N
   }
 }
 
+// Would the dispatcher of nmx_api.hip (be_launch_bank_w64) end up in a kernel that adds the carried offset on load
+// (NmxBankArgs::dcf: the channel-pair kernels of nmx_k_bank_w64c.h / nmx_k_bank_w64e.h)?  The same conditions as the
+// launchers below; anything else reads a copy of the windows with the offset added back (nmx_engine_run.inc).
+extern "C" int NMX_CAT(nmx_w64_takes_dc_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items) {
+  (void)n_items;
+  if (A->tw2 || !A->hc || A->b.pad_mode != 0 || A->b.n_filters < 1) return 0;
+  if (A->pair_m == 2048) {
+    if (A->b.W > 1024 || (A->b.bp_features & 6u) || !A->twc) return 0;
+    return (160 * 1024 / 4 - (A->b.n_filters * NMX_W64E_H_FLOATS + NMX_W64E_TWA_FLOATS)) / NMX_W64E_TILE_FLOATS >= 4;
+  }
+  if (A->pair_m == 1536)
+    return (160 * 1024 / 4 - (A->b.n_filters * NMX_W64C_H_FLOATS + NMX_W64C_TWA_FLOATS)) / NMX_W64C_TILE_FLOATS >= 6;
+  return 0;
+}
+
 // returns 0 when the configuration does not fit (caller falls back to the one-channel M = 2048 kernels)
 extern "C" int NMX_CAT(nmx_w64e_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, int n_items, int n_cu, hipStream_t s) {
   const bool pad = A->b.pad_mode != 0;

@@ -209,6 +209,16 @@ nmx_kern_timeosc_w1000_low(const NmxTimeOscArgs A0, int n_items) {
 }
 
 
+// does the kernel be_launch_timeosc (nmx_api.hip) would pick take the carried offset (NmxTimeOscArgs::dcf)?  Every one but
+// the two special-shape kernels below (they read a copy of the windows with the offset added back: nmx_engine_run.inc)
+extern "C" int nmx_wave_timeosc_takes_dc(const NmxTimeOscArgs* A) {
+  if (!A->fft.enabled && !A->welch.enabled && !A->stft.enabled) return 1;
+  if (A->w500_tab && nmx_timeosc_w1000_ok(*A)) return 1;
+  if (A->w500_tab && nmx_timeosc_stft500_ok(*A)) return 0;
+  if (A->w510_tab && nmx_timeosc_w510_ok(*A, A->w510_tab)) return 0;
+  return 1;
+}
+
 // returns 0 when the configuration needs the generic kernel
 extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
   if (!nmx_timeosc_w1000_ok(*A)) return 0;

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from collections.abc import Sequence
 
 import numpy as np
@@ -57,19 +58,23 @@ def _pool():
     return _POOL
 
 
-def parallel_cast(dst: np.ndarray, src: np.ndarray) -> None:
-    """dst[...] = src (with cast), first axis split over the conversion threads."""
+def parallel_cast(dst: np.ndarray, src: np.ndarray, sub: np.ndarray | None = None) -> None:
+    """dst[...] = src (with cast), first axis split over the conversion threads.  ``sub``: one float64 constant per row,
+    subtracted BEFORE the cast (the engine's offset split: the cast then rounds at the signal's magnitude)."""
     n = dst.shape[0]
+
+    def put(a, b):
+        if sub is None:
+            dst[a:b] = src[a:b]
+        else:
+            dst[a:b] = np.asarray(src[a:b], dtype=np.float64) - sub[a:b, None]
+
     if dst.size < (1 << 20) or n < 2:
-        dst[...] = src
+        put(0, n)
         return
     k = min(n, 8)
     edges = [(i * n) // k for i in range(k + 1)]
-
-    def job(i):
-        dst[edges[i]:edges[i + 1]] = src[edges[i]:edges[i + 1]]
-
-    list(_pool().map(job, range(k)))
+    list(_pool().map(lambda i: put(edges[i], edges[i + 1]), range(k)))
 
 
 _STAGING: dict = {}
@@ -202,6 +207,8 @@ class HotPathEngine:
         self.n_outputs = len(self.keys)
         self.C_in = int(self.desc.n_channels_in)
         self._plan = C.c_void_p()
+        self._dc = None        # host offsets in force (None: not decided yet -- `_host_offsets`)
+        self._dc_any = False
         self._pinned = None
         if not dry_run:
             self.lib.check(self.lib.lib.nmx_plan_create(C.byref(self.desc), C.byref(self._plan)))
@@ -501,8 +508,64 @@ class HotPathEngine:
         except Exception:
             pass
 
+    # ---- offset split (include/nmx.h, nmx_engine_dc.inc) -----------------------------------------------------------------
+    @property
+    def carries_offsets(self) -> bool:
+        """The plan can take a recording as (float32 residual, one float64 constant per row)."""
+        yes = C.c_int(0)
+        self.lib.check(self.lib.lib.nmx_plan_carries_offsets(self._plan, C.byref(yes)))
+        return bool(yes.value)
+
+    def set_offsets(self, d) -> None:
+        """``d[C_in]`` float64 (None: none): every recording handed over afterwards is split as x = u + d on the host --
+        in float64, before the cast to float32.  ``process_batch`` / ``process_window`` choose the constants themselves
+        from the first float64 data they see (`_host_offsets`); this is for callers who know better."""
+        if d is None:
+            self.lib.check(self.lib.lib.nmx_plan_set_offsets(self._plan, None))
+            self._dc = np.zeros(self.C_in)
+        else:
+            d = np.ascontiguousarray(d, dtype=np.float64)
+            if d.shape != (self.C_in,):
+                raise ValueError(f"expected {self.C_in} offsets, got shape {d.shape}")
+            self.lib.check(self.lib.lib.nmx_plan_set_offsets(self._plan, d.ctypes.data))
+            self._dc = d.copy()
+        self._dc_any = bool(np.any(self._dc != 0.0))
+
+    def offsets(self):
+        """(d_in[C_in], d_pre[C]): constants of the input rows (host + learned on the device) and of the pre-processed
+        windows the features read."""
+        d_in, d_pre = np.zeros(self.C_in), np.zeros(self.C)
+        self.lib.check(self.lib.lib.nmx_plan_get_offsets(self._plan, d_in.ctypes.data, d_pre.ctypes.data, None))
+        return d_in, d_pre
+
+    def _host_offsets(self, data: np.ndarray):
+        """The host constants in force (None: none).  Decided ONCE per stream, by the first data the engine sees -- a
+        result must not depend on how the hops were batched: float64 data that needs it (some row's level beyond 64 times
+        its spread: below that a float32 cast costs the features nothing) is split at the mean of each row's first
+        samples; float32 data is taken as it is (in front of a re-reference the library splits it on the device)."""
+        if self._dc is None:
+            d = None
+            if data.dtype == np.float64 and self.carries_offsets and os.environ.get("NMX_DC_HOST", "1") != "0":
+                seg = np.asarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)
+                ok = np.isfinite(seg)
+                cnt = np.maximum(ok.sum(1), 1)
+                m = np.where(ok, seg, 0.0).sum(1) / cnt
+                sd = np.sqrt(np.where(ok, (seg - m[:, None]) ** 2, 0.0).sum(1) / cnt)
+                if np.any(np.abs(m) > 64.0 * sd):
+                    d = np.where(ok.any(1), m, 0.0)
+            if d is not None:
+                self.set_offsets(d)
+            else:
+                self._dc = np.zeros(self.C_in)
+                self._dc_any = False
+        return self._dc if self._dc_any else None
+
     def reset_state(self) -> None:
         self.lib.check(self.lib.lib.nmx_state_reset(self._plan))
+        if self._dc is not None and self._dc_any:
+            self.lib.check(self.lib.lib.nmx_plan_set_offsets(self._plan, None))
+        self._dc = None
+        self._dc_any = False
 
     def export_state(self) -> bytes:
         n = C.c_int64()
@@ -513,6 +576,15 @@ class HotPathEngine:
 
     def import_state(self, blob: bytes) -> None:
         self.lib.check(self.lib.lib.nmx_state_import(self._plan, blob, len(blob)))
+        # the blob carries the offsets of the stream it came from: adopt them
+        st = C.c_int(0)
+        d_in = np.zeros(self.C_in)
+        self.lib.check(self.lib.lib.nmx_plan_get_offsets(self._plan, d_in.ctypes.data, None, C.byref(st)))
+        if st.value & 1:
+            host = d_in   # (host offsets set: nothing is learned next to them)
+            self._dc, self._dc_any = host, bool(np.any(host != 0.0))
+        else:
+            self._dc, self._dc_any = np.zeros(self.C_in), False
 
     def process_window(self, data: np.ndarray, want_nan_mask: bool = False):
         """data[C_in, W] (float64, may be a non-contiguous view) -> float32[n_outputs]."""
@@ -521,6 +593,7 @@ class HotPathEngine:
             raise ValueError(f"expected data of shape ({self.C_in}, {self.W_in}), got {data.shape}")
         if data.strides[1] != 8:
             data = np.ascontiguousarray(data)
+        self._host_offsets(data)   # (the library subtracts them from the float64 window itself)
         out = np.empty(self.n_outputs, np.float32)
         mask = np.zeros(self.C_in, np.uint8) if want_nan_mask else None
         self.lib.check(self.lib.lib.nmx_process_window(
@@ -577,11 +650,14 @@ class HotPathEngine:
             raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
         starts = np.ascontiguousarray(starts, dtype=np.int64)
         n = len(starts)
-        if data.dtype == np.float32 and data.strides[1] == 4:
+        dc = self._host_offsets(data)
+        if dc is None and data.dtype == np.float32 and data.strides[1] == 4:
             x = data
         elif data.size >= (1 << 18):
             x = self._pinned.array("x", data.shape, np.float32)
-            parallel_cast(x, data)
+            parallel_cast(x, data, dc)
+        elif dc is not None:
+            x = (np.asarray(data, dtype=np.float64) - dc[:, None]).astype(np.float32)
         else:
             x = np.ascontiguousarray(data, dtype=np.float32)
         if out is not None:
@@ -597,6 +673,9 @@ class HotPathEngine:
             self.lib.check(self.lib.lib.nmx_process_batch_tap(
                 self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
                 out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None, pre.ctypes.data))
+            d_pre = self.offsets()[1]
+            if np.any(d_pre != 0.0):   # the windows in float64 with their constants back (NMFeature.calc_feature's argument)
+                pre = pre.astype(np.float64) + d_pre[None, :, None]
             return (out, mask.astype(bool), pre) if want_nan_mask else (out, pre)
         self.lib.check(self.lib.lib.nmx_process_batch(
             self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,

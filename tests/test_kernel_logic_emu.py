@@ -34,6 +34,10 @@ def test_feature_cases_match_reference_goldens(emu_lib, case):
     pc.case_feature_cases_match_reference_goldens(emu_lib, case)
 
 
+def test_dc_offsets_1e3_and_1e5_at_stated_tolerances(emu_lib):
+    pc.case_dc_offsets(emu_lib)
+
+
 def test_sharpwave_reference_test_inputs(emu_lib):
     pc.case_sharpwave_reference_test_inputs(emu_lib)
 

@@ -234,12 +234,18 @@ def _run_two_ranks(tmp_path, backend, port, nproc=2):
     # single-process kernel: agreement to fp32 rounding of the re-referenced samples, not bit equality
     from tests import parity
     keys = list(single2.columns)[:-1]
+    from oracle import nm_oracle as orc
+    st2, en2, _ = orc.window_schedule(data2.shape[1], 1000.0, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    pv2 = parity.PipelineVerifiers(s, ch2, 1000.0, data2, st2, 1000, line_noise=50)
     for r in range(len(a2)):
         ok = ~np.isnan(b2[r, :-1])
         if loose:
             np.testing.assert_allclose(a2[r, :-1][ok], b2[r, :-1][ok], rtol=1e-3, atol=1e-4)
             continue
-        n_bad, rep, _ = parity.compare([k for k, o in zip(keys, ok) if o], a2[r, :-1][ok], b2[r, :-1][ok], s, 1000.0, 200.0, 1000)
+        # (two fp32 paths: a sharp-wave trough whose decision margin is at rounding level may flip between them -- the
+        # oracle's pre-processed window says whether a miss is one of those)
+        n_bad, rep, _ = parity.compare([k for k, o in zip(keys, ok) if o], a2[r, :-1][ok], b2[r, :-1][ok], s, 1000.0, 200.0, 1000,
+                                       verifier=pv2.row(r))
         assert n_bad == 0, f"row {r}\n{rep}"
 
     # ragged window lengths: both input forms against the one-plan stream (bursts, Kalman filters, z-score, NaN policy)
