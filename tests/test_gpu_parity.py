@@ -3,6 +3,8 @@ package's own loader -- no emulator, no fallback) against the reference-generate
 at sizes beyond the goldens, against the CPU oracle on the same seeded inputs.
 Tolerances: tests/parity.py."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -860,3 +862,37 @@ def test_abi_from_plain_c_on_the_gpu(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("OK devices="), r.stdout + r.stderr
     assert int(r.stdout.split("=")[1]) >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_gloo_ranks_share_one_gpu(scaling):
+    """bench.py under the driver's launcher with two ranks on the one GPU of the box (gloo): the weak form (256 channels
+    per rank, no collective) and the strong form (256 channels in TOTAL, jointly re-referenced: one all-reduce of the
+    column sums per step) both print ONE line that says which it is."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NMX_BENCH_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "128",
+           "--cpu-windows", "0", "--no-cold-start", "--no-mode-a", "--backend", "gloo", "--scaling", scaling]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["nan_outputs"] == 0
+    assert len(d["ms_per_step_by_rank"]) == 2
+    if scaling == "strong":
+        assert d["config"]["channels_total"] == 256 and d["config"]["channels_per_gpu"] == 128
+        assert d["exchange_ms_per_step"] is not None
+    else:
+        assert d["config"]["channels_per_gpu"] == 256

@@ -16,7 +16,7 @@ fi
 if [[ $STEPS == *all* || $STEPS == *bench* ]]; then
   timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   tail -c 2500 $O/${TAG}_bench.json
-  NMX_OVERLAP=0 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start --no-mode-a > $O/${TAG}_bench_nooverlap.json 2>/dev/null
+  NMX_OVERLAP=0 timeout 300 python bench.py --steps 40 --warmup 3 --cpu-windows 0 --no-cold-start --no-mode-a > $O/${TAG}_bench_nooverlap.json 2>/dev/null
 fi
 if [[ $STEPS == *all* || $STEPS == *prof* ]]; then
   rm -rf $O/prof_$TAG $O/pmc_fetch_$TAG $O/pmc_write_$TAG
