@@ -224,6 +224,15 @@ int nmx_plan_n_outputs(const nmx_plan* plan, int64_t* n_outputs);
  *   nmx_plan_get_offsets   d_in[n_channels_in] = host + learned constants of the input rows, d_pre[n_channels] = offset of
  *                          the PRE-PROCESSED windows (what nmx_process_batch_tap's float32 windows have to be raised by),
  *                          *state = bit 0 host offsets set | bit 1 constants learned; any pointer may be NULL. */
+/* Hand-shakes of a HOST-memory batch (memspace 0) with conversion threads of the caller, so that converting the recording to
+ * float32 and the feature rows to whatever the caller wants runs NEXT TO the copies and kernels instead of around them:
+ *   in_ready_samples   (may be NULL) the caller's counter: samples [0, *in_ready) of every row of x are in place.  The call
+ *                      waits, chunk by chunk, until the samples a chunk reads are covered before it enqueues their copy.
+ *   out_done_windows   (may be NULL) the library's counter: rows [0, *out_done) of `out` (and of the NaN mask) have landed
+ *                      in the caller's buffers; n_windows when the call returns.
+ * Both are read / written with acquire / release atomics; they stay registered until replaced (NULL, NULL = off). */
+int nmx_plan_set_pipeline(nmx_plan* plan, const volatile int64_t* in_ready_samples, volatile int64_t* out_done_windows);
+
 int nmx_plan_carries_offsets(const nmx_plan* plan, int* yes);
 int nmx_plan_set_offsets(nmx_plan* plan, const double* d_in);
 int nmx_plan_get_offsets(nmx_plan* plan, double* d_in, double* d_pre, int* state);

@@ -85,7 +85,7 @@ _EXPORTS = [
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
     "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free",
-    "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets",
+    "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets", "nmx_plan_set_pipeline",
 ]
 
 
@@ -103,12 +103,22 @@ class NmxLibrary:
                 f"{self.path} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         if path is None:
-            # share ONE HIP runtime with torch when torch is used in the same process
-            # (torch ships its own libamdhip64.so with the same SONAME)
-            try:
-                import torch  # noqa: F401
-            except Exception:  # pragma: no cover - torch is optional plumbing
-                pass
+            # Share ONE HIP runtime with torch when torch is (or will be) used in the same process: torch ships its own
+            # libamdhip64.so under the same SONAME, and device pointers only mean something inside one runtime.  Importing
+            # torch for that costs a second; loading its runtime library does the same job in tens of milliseconds --
+            # libnmx's DT_NEEDED entry then resolves to the copy already in the process, and so does a later `import torch`.
+            import sys
+
+            if "torch" not in sys.modules:
+                try:
+                    import importlib.util
+
+                    spec = importlib.util.find_spec("torch")
+                    hip = Path(spec.origin).parent / "lib" / "libamdhip64.so" if spec and spec.origin else None
+                    if hip is not None and hip.exists():
+                        C.CDLL(str(hip), mode=C.RTLD_GLOBAL)
+                except Exception:  # pragma: no cover - torch is optional plumbing
+                    pass
         self.lib = C.CDLL(str(self.path))
         L = self.lib
         for name in _EXPORTS:
@@ -144,6 +154,7 @@ class NmxLibrary:
         L.nmx_plan_attach_norm.argtypes = [C.c_void_p, C.c_void_p]
         L.nmx_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
         L.nmx_host_free.argtypes = [C.c_void_p]
+        L.nmx_plan_set_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nmx_plan_carries_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.nmx_plan_set_offsets.argtypes = [C.c_void_p, C.c_void_p]
         L.nmx_plan_get_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]

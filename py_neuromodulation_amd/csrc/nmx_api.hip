@@ -175,6 +175,8 @@ static void be_d2h_2d_async(void* d, size_t dpitch, const void* s, size_t spitch
   BE_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyDeviceToHost, st));
 }
 static void be_memset_async(void* d, int v, size_t n, be_stream_t st) { BE_TRY(hipMemsetAsync(d, v, n, st)); }
+// a host function in stream order (runs once everything enqueued on `st` before it has completed)
+static void be_host_fn(be_stream_t st, void (*fn)(void*), void* arg) { BE_TRY(hipLaunchHostFunc(st, fn, arg)); }
 static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
 static be_stream_t be_stream_create() {
   hipStream_t s = nullptr;

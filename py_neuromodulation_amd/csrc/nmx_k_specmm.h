@@ -103,6 +103,23 @@ NMX_DEV void nmx_smm_dma8(const char* g0, const char* g1, const char* g2, const 
       : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7), "s"(lds_base)
       : "memory", "scc");
 }
+// a quarter of it (two instructions: both halves of one stream), for issue points spread over a step
+NMX_DEV void nmx_smm_dma2(const char* g0, const char* g1, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_add_u32 m0, %3, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g0), "v"(g1), "s"(lds_base)
+      : "memory", "scc");
+}
 template <int N>
 NMX_DEV void nmx_smm_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -249,6 +266,12 @@ struct NmxSmmWave {
                  (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + slot * NMX_SMM_STEP_BYTES)));
   }
 
+  // stream Q (0 .. 3 = a, b, c, d) of step C alone
+  template <int C, int Q>
+  NMX_DEV void dma_q(unsigned slot, const char* s0, const char* s1) {
+    constexpr int o = Q == 0 ? 128 * C : Q == 1 ? 1872 - 128 * C : Q == 2 ? 2000 + 128 * C : 3872 - 128 * C;
+    nmx_smm_dma2(s0 + o, s1 + o, (unsigned)__builtin_amdgcn_readfirstlane((int)(ring + slot * NMX_SMM_STEP_BYTES + 2048u * Q)));
+  }
   NMX_DEV static float cl(float v) { return CLEAN ? nmx_clean_bl(v) : v; }
   NMX_DEV nmx_v4 ld4(unsigned addr) const {
     nmx_v4 v = *(__attribute__((address_space(3))) const nmx_v4*)(unsigned long)addr;
@@ -409,9 +432,9 @@ struct NmxSmmWave {
       }
     }
   }
-  template <int C>
-  NMX_DEV void time_domain(Tile& T, const NmxSmmRegs& Rg, const nmx_c2 (&U)[4][4]) {
-    if (!TD) return;
+  template <int C, class Issue>
+  NMX_DEV void time_domain(Tile& T, const NmxSmmRegs& Rg, const nmx_c2 (&U)[4][4], Issue issue) {
+    if (!TD) { issue(0); issue(1); issue(2); issue(3); return; }
     constexpr bool FIRST = C == 0, LAST = C == 7;
 #ifdef NMX_SMM_SCALAR
     constexpr bool MASKED = true;
@@ -425,9 +448,13 @@ struct NmxSmmWave {
         va[i] = Rg.a0[i]; va[4 + i] = Rg.a1[i]; vb[i] = Rg.b0[i]; vb[4 + i] = Rg.b1[i];
         vc[i] = Rg.c0[i]; vc[4 + i] = Rg.c1[i]; vd[i] = Rg.d0[i]; vd[4 + i] = Rg.d1[i];
       }
+      issue(0);
       td_edge<true, FIRST, LAST>(T, va, Rg.ha.x, Rg.ha.y);
+      issue(1);
       td_edge<false, false, LAST>(T, vb, Rg.hb.x, Rg.hb.y);
+      issue(2);
       td_edge<true, FIRST, LAST>(T, vc, Rg.hc.x, Rg.hc.y);
+      issue(3);
       td_edge<false, FIRST, LAST>(T, vd, Rg.hd.x, Rg.hd.y);
       if (FIRST) {   // lanes ks = 0 hold x[0], x[1] (stream a) and x[998], x[999] (stream d)
         T.u0 = va[0] - T.pilot; T.u1 = va[1] - T.pilot;
@@ -441,9 +468,13 @@ struct NmxSmmWave {
         for (int k = 0; k < 4; ++k) T.q0[st & 1] = nmx_c2_fma(U[st][k], U[st][k], T.q0[st & 1]);
       const nmx_c2 XA[4] = {Rg.a0.xy, Rg.a0.zw, Rg.a1.xy, Rg.a1.zw}, XB[4] = {Rg.b0.xy, Rg.b0.zw, Rg.b1.xy, Rg.b1.zw};
       const nmx_c2 XC[4] = {Rg.c0.xy, Rg.c0.zw, Rg.c1.xy, Rg.c1.zw}, XD[4] = {Rg.d0.xy, Rg.d0.zw, Rg.d1.xy, Rg.d1.zw};
+      issue(0);
       td_mid<true, 0>(T, XA, Rg.ha);
+      issue(1);
       td_mid<false, 1>(T, XB, Rg.hb);
+      issue(2);
       td_mid<true, 0>(T, XC, Rg.hc);
+      issue(3);
       td_mid<false, 1>(T, XD, Rg.hd);
       // (the sums are only READ at the end of the tile: left alone, the optimiser sinks every step's time-domain
       // arithmetic down there and parks the samples in scratch until then.  Pin the values here.)
@@ -474,10 +505,26 @@ struct NmxSmmWave {
     T.acc[0][0] += Cu.a0.x + Cu.b0.y + Cu.c1.z + Cu.d1.w + tab[C][C & 3][C];   // (experiment: the DMA pipeline alone)
 #endif
     // the step R ahead, into the slot this step leaves (its last readers were the halo reads above)
+#if defined(NMX_SMM_DMA_SPREAD) && !defined(NMX_SMM_DEBUG_NOCOMP)
+    // (two instructions at a time between the blocks of the time domain: an LDS-DMA instruction among VALU work costs a
+    // fraction of one in a burst behind MFMAs)
+    const bool here = C + R <= 7, there = !here && more;
+    const char* q0 = here ? src0 : nsrc0;
+    const char* q1 = here ? src1 : nsrc1;
+    const unsigned slot_now = r;
+    time_domain<C>(T, Cu, U, [&](int k) {
+      if (!(here || there)) return;
+      if (k == 0) dma_q<(C + R) & 7, 0>(slot_now, q0, q1);
+      else if (k == 1) dma_q<(C + R) & 7, 1>(slot_now, q0, q1);
+      else if (k == 2) dma_q<(C + R) & 7, 2>(slot_now, q0, q1);
+      else dma_q<(C + R) & 7, 3>(slot_now, q0, q1);
+    });
+#else
     if (C + R <= 7) dma<(C + R) & 7>(r, src0, src1);
     else if (more) dma<(C + R) & 7>(r, nsrc0, nsrc1);
 #ifndef NMX_SMM_DEBUG_NOCOMP
-    time_domain<C>(T, Cu, U);
+    time_domain<C>(T, Cu, U, [](int) {});
+#endif
 #endif
     r = rn;
     if (have_next) Cu = Nx;

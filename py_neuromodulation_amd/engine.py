@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import time
 from collections.abc import Sequence
 
 import numpy as np
@@ -683,16 +684,84 @@ class HotPathEngine:
         return (out, mask.astype(bool)) if want_nan_mask else out
 
     def process_batch_f64(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False):
-        """``process_batch`` returning the float64 table the reference's consumers expect: float32 rows in the
-        library's page-locked staging array, widened on the conversion threads.  (Measured on the MI355X box, 256 ch x
-        120 s: converting the recording 1.9 ms, the batch from page-locked memory 11.7 ms, widening 0.6 ms.  Cutting the
-        recording into slices so that conversions overlap the device was tried and is SLOWER -- 17.6 ms against 13.9:
-        every libnmx call drains its copy / compute pipeline before it returns.)"""
-        res = self.process_batch(data, starts, want_nan_mask=want_nan_mask, staged_output=True)
-        out = res[0] if want_nan_mask else res
-        o64 = np.empty(out.shape, np.float64)
-        parallel_cast(o64, out)
-        return (o64, res[1]) if want_nan_mask else o64
+        """``process_batch`` returning the float64 table the reference's consumers expect, with BOTH conversions next to
+        the device work instead of around it (nmx_plan_set_pipeline): a thread converts the recording to float32 slice
+        by slice into the page-locked staging array and publishes how far it got -- the library enqueues a chunk's copy
+        as soon as the samples it reads are there --, another widens the feature rows to float64 as the chunks land
+        (their first touch of a fresh 75 MB table costs more than the arithmetic: it, too, hides under the kernels).
+        (Measured round 4, 256 ch x 120 s: conversion 1.9 ms + batch 11.7 ms + widening and first touch 4 - 8 ms in a
+        row.)"""
+        data = np.asarray(data)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        n = len(starts)
+        if data.ndim != 2 or data.shape[0] != self.C_in:
+            raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
+        small = data.size < (1 << 20) or n < 64 or os.environ.get("NMX_PIPELINE", "1") == "0"
+        if small or (data.dtype == np.float32 and data.strides[1] == 4 and self._host_offsets(data) is None):
+            res = self.process_batch(data, starts, want_nan_mask=want_nan_mask, staged_output=True)
+            out = res[0] if want_nan_mask else res
+            o64 = np.empty(out.shape, np.float64)
+            parallel_cast(o64, out)
+            return (o64, res[1]) if want_nan_mask else o64
+        dc = self._host_offsets(data)
+        T = data.shape[1]
+        x = self._pinned.array("x", data.shape, np.float32)
+        out = self._pinned.array("out", (n, self.n_outputs), np.float32)
+        o64 = np.empty((n, self.n_outputs), np.float64)
+        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        ctr = self._pinned.array("ctr", (16,), np.int64)   # [0] samples in place, [8] rows landed (own cache lines)
+        ctr[:] = 0
+        W_in = self.W_in
+        # slices: what the library's first chunks read (nmx_engine_run.inc: a short first chunk -- 128 hops, or the fill
+        # phase of the burst history, ~320 --, then 1024 hops at a time), each converted by the pool's threads in row blocks
+        hops = [h for h in (128, 320) if h < n] + list(range(320 + 1024, n, 1024)) + [n]
+        edges = sorted(set([0] + [int(min(T, starts[h - 1] + W_in)) for h in hops] + [T]))
+        failed: list = []
+
+        def convert():   # (row blocks of a slice over the conversion pool)
+            try:
+                for a, b in zip(edges[:-1], edges[1:]):
+                    parallel_cast(x[:, a:b], data[:, a:b], dc)
+                    ctr[0] = b
+            except BaseException as e:   # noqa: BLE001 -- reported by the caller's thread
+                failed.append(e)
+                ctr[0] = T
+
+        def widen():
+            done = 0
+            try:
+                while done < n and not failed:
+                    d = int(ctr[8])
+                    if d > done:
+                        parallel_cast(o64[done:d], out[done:d])
+                        done = d
+                    else:
+                        time.sleep(0.0001)
+            except BaseException as e:   # noqa: BLE001
+                failed.append(e)
+
+        import threading
+
+        lib = self.lib
+        lib.check(lib.lib.nmx_plan_set_pipeline(self._plan, ctr.ctypes.data, ctr.ctypes.data + 64))
+        jobs = [threading.Thread(target=convert, daemon=True), threading.Thread(target=widen, daemon=True)]
+        for j in jobs:
+            j.start()
+        try:
+            lib.check(lib.lib.nmx_process_batch(
+                self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
+                out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
+        except BaseException:
+            ctr[0] = T   # (let the threads run out)
+            ctr[8] = n
+            raise
+        finally:
+            lib.lib.nmx_plan_set_pipeline(self._plan, None, None)
+            for j in jobs:
+                j.join()
+        if failed:
+            raise failed[0]
+        return (o64, mask.astype(bool)) if want_nan_mask else o64
 
     def process_batch_device(self, x_ptr: int, ldx: int, n_samples: int, starts: np.ndarray,
                              out_ptr: int, mask_ptr: int | None = None, stream: int | None = None) -> None:

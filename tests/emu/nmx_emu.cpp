@@ -48,6 +48,7 @@ static void be_d2h_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t
   for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
 }
 static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v, n); }
+static void be_host_fn(be_stream_t, void (*fn)(void*), void* arg) { fn(arg); }
 static int be_sync(be_stream_t) { return 0; }
 static be_stream_t be_stream_create() { return nullptr; }
 static be_stream_t be_stream_create_high() { return nullptr; }

@@ -64,6 +64,36 @@ def case_dc_offsets(lib):
             assert n_bad == 0, f"offset / signal = {tag}, row {r} (bursts)\n{rep}"
 
 
+def case_pipelined_f64_batch(lib):
+    """engine.process_batch_f64 with its two conversions on threads next to the copies and kernels (nmx_plan_set_pipeline:
+    input published slice by slice, rows widened as the chunks land) == the plain batch, bit for bit, NaN mask included;
+    with and without host offsets (a row far off zero: the split subtracts before the cast)."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+    C, T = 12, 90000          # > 2^20 samples, 891 hops: several chunks
+    rng = np.random.default_rng(5)
+    for level in (0.0, 1e6):
+        data = rng.standard_normal((C, T)) * 30 + rng.uniform(-100, 100, (C, 1)) + level
+        data[3, 40000:40007] = np.nan
+        starts = np.arange(0, T - 1000 + 1, 100)
+        ch = [f"ch{i}" for i in range(C)]
+        a = HotPathEngine(s, ch, 1000.0, lib=lib)
+        want, wmask = a.process_batch(data, starts, want_nan_mask=True)
+        a.close()
+        b = HotPathEngine(s, ch, 1000.0, lib=lib)
+        got, gmask = b.process_batch_f64(data, starts, want_nan_mask=True)
+        assert (b._dc is not None and b._dc_any) == (level != 0.0)
+        b.close()
+        assert got.dtype == np.float64 and got.shape == want.shape
+        np.testing.assert_array_equal(got, want.astype(np.float64))
+        np.testing.assert_array_equal(gmask, wmask)
+        assert wmask.any()
+
+
 def case_sharpwave_reference_test_inputs(lib):
     """Impulse / sine / plateau inputs of the reference's tests/test_sharpwave.py."""
     from py_neuromodulation_amd.engine import HotPathEngine

@@ -33,6 +33,10 @@ def test_dc_offsets_1e3_and_1e5_at_stated_tolerances(gpu_lib):
     pc.case_dc_offsets(gpu_lib)
 
 
+def test_pipelined_f64_batch_equals_plain_batch(gpu_lib):
+    pc.case_pipelined_f64_batch(gpu_lib)
+
+
 def test_sharpwave_reference_test_inputs(gpu_lib):
     pc.case_sharpwave_reference_test_inputs(gpu_lib)
 

@@ -38,6 +38,10 @@ def test_dc_offsets_1e3_and_1e5_at_stated_tolerances(emu_lib):
     pc.case_dc_offsets(emu_lib)
 
 
+def test_pipelined_f64_batch_equals_plain_batch(emu_lib):
+    pc.case_pipelined_f64_batch(emu_lib)
+
+
 def test_sharpwave_reference_test_inputs(emu_lib):
     pc.case_sharpwave_reference_test_inputs(emu_lib)
 

@@ -19,12 +19,14 @@ cols = [r[1] for r in cur.execute(f"pragma table_info({mc})")]
 for r in cur.execute(f"select start, end, size from {mc}"):
     ev.append((r[0], r[1], f"copy {r[2] / 1e6:.2f} MB"))
 ev.sort()
-# the last run: find the last 'nmx_kern_burst_fill' and start 3 ms before it
-fills = [i for i, e in enumerate(ev) if 'burst_fill' in e[2]]
-i0 = fills[-1]
-t_fill = ev[i0][0]
-start = [e for e in ev if e[0] > t_fill - 12e6 and 'copy' in e[2] and float(e[2].split()[1]) > 1.0]
-t0 = start[0][0] if start else t_fill
+# the last run: its first input copy = the first copy above 1 MB behind the last gap of more than 5 ms between events
+big = [e for e in ev if e[2].startswith('copy ') and float(e[2].split()[1]) > 1.0]
+t0 = big[0][0]
+for a, b in zip(ev[:-1], ev[1:]):
+    if b[0] - a[1] > 5e6:
+        nxt = [e for e in big if e[0] >= b[0]]
+        if nxt:
+            t0 = nxt[0][0]
 for e in ev:
     if e[0] >= t0 - 1e6 and e[0] < t0 + 40e6 and (e[1] - e[0] > 30e3):
         print(f"{(e[0] - t0) / 1e6:8.3f} {(e[1] - t0) / 1e6:8.3f} {(e[1] - e[0]) / 1e6:7.3f}  {e[2]}")
