@@ -132,6 +132,9 @@ def split_hi_lo(v: np.ndarray) -> np.ndarray:
     """float64 [T] -> float32 [2, T]: hi = float32(v), lo = float32(v - hi); hi + lo carries ~48 bits of v.  The group
     sums of a channel shard travel this way (sharding.py): a float32 sum of 256 channels with +-500 offsets would add a
     rounding step the single-device kernel does not have."""
-    v = np.asarray(v, np.float64)
+    fmax = float(np.finfo(np.float32).max)
+    # (a sum beyond float32's range -- several members at +-inf, which nan_to_num turns into +-3.4e38 each -- would
+    # give hi = +inf, lo = -inf: the device cleans those to +-FLT_MAX and the pair cancels to 0)
+    v = np.clip(np.asarray(v, np.float64), -fmax, fmax)
     hi = v.astype(np.float32)
     return np.stack([hi, (v - hi.astype(np.float64)).astype(np.float32)])

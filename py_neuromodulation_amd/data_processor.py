@@ -344,6 +344,9 @@ class DataProcessor:
         """Engine rows, NaN mask and the user-feature rows of the same hops; the hops go through the engine in chunks
         of ``_user_chunk`` so that the tapped windows stay small."""
         starts = np.asarray(starts, dtype=np.int64)
+        if len(starts) == 0:   # (an empty batch is an empty table, as without plugins)
+            return (np.empty((0, self.engine.n_outputs), np.float32), np.zeros((0, self.engine.C_in), bool),
+                    np.empty((0, len(self._user.user_keys or [])), np.float64))
         outs, masks, users = [], [], []
         for i in range(0, len(starts), self._user_chunk):
             o, m, wins = self.process_batch_tapped(data, starts[i:i + self._user_chunk])

@@ -277,6 +277,28 @@ class NMSettings(_Node):
 
     __hash__ = object.__hash__   # identity: the WeakSet of live instances
 
+    # copies (copy.copy / copy.deepcopy / pickle) are live objects too: add_custom_feature / remove_custom_feature flip
+    # their flags like everybody else's (the reference's class-level registry sees every instance: settings.py:129-150)
+    def __copy__(self):
+        new = type(self).__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        NMSettings._instances.add(new)
+        return new
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = type(self).__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        NMSettings._instances.add(new)
+        return new
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        NMSettings._instances.add(self)
+
     @classmethod
     def _add_feature(cls, feature: str) -> None:
         """stream/settings.py:140-143."""

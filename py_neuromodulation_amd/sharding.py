@@ -340,7 +340,7 @@ class MultiDeviceProcessor:
         def sum_block(i):
             a, b = edges[i], edges[i + 1]
             for out, g in zip(sums, self._groups):
-                rows = data[:, a:b] if (len(g) == data.shape[0] and g[0] == 0 and g[-1] == len(g) - 1) else data[g][:, a:b]
+                rows = data[:, a:b] if (len(g) == data.shape[0] and g[0] == 0 and g[-1] == len(g) - 1) else data[g, a:b]
                 blk = np.asarray(rows, np.float32)
                 sb = blk.sum(axis=0, dtype=np.float64)
                 if not np.isfinite(sb).all():      # a NaN / infinity somewhere in the block: clean first, like the kernels
@@ -378,9 +378,19 @@ class MultiDeviceProcessor:
                 lambda p: p.engine.process_batch(data, starts, want_nan_mask=True), self.parts)]
         xs = self._local_inputs(data)
 
+        W_in = self.parts[0].engine.W_in
+        # nothing between the incoming rows and the features on any part (no re-reference, channel pick or filter): the
+        # plugins get the exact float64 window, as the one-plan stream gives them (DataProcessor._host_windows)
+        identity = all(p.engine.preprocessing_is_identity for p in self.parts)
+
         def job(px):
             p, x = px
-            if tapped:   # (a local-input part always has a matrix: never the identity shortcut)
+            if tapped and identity:
+                o, m = p.engine.process_batch(x, starts, want_nan_mask=True)
+                rows = list(p.local_rows)   # (identity: exactly the part's channels, no group-sum rows)
+                wins = np.stack([np.nan_to_num(np.asarray(data[rows, int(a):int(a) + W_in], dtype=np.float64)) for a in starts])
+                return o, m, wins
+            if tapped:
                 o, m, pre = p.engine.process_batch(x, starts, want_nan_mask=True, tap=True)
                 return o, m, pre.astype(np.float64)
             o, m = p.engine.process_batch(x, starts, want_nan_mask=True)

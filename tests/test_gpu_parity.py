@@ -117,6 +117,12 @@ def test_matrix_pipe_spectrum_kernel(gpu_lib, monkeypatch):
     assert "nmx_kern_specmm_w1000" in eng.kernels(2), eng.kernels(2)
     one = np.stack([eng.process_window(x[:, a:a + 1000].astype(np.float64)) for a in starts[:3]])
     np.testing.assert_array_equal(got[:3], one)     # one window == the batch, bit for bit
+    # window starts of every residue mod 4 (an odd hop): the same kernel, the same values as window by window
+    odd = np.arange(1, T - 1000, 101)
+    got_odd = eng.process_batch(x, odd)
+    assert "nmx_kern_specmm_w1000" in eng.kernels(2), eng.kernels(2)
+    one_odd = np.stack([eng.process_window(x[:, a:a + 1000].astype(np.float64)) for a in odd[:4]])
+    np.testing.assert_array_equal(got_odd[:4], one_odd)
     eng.close()
     monkeypatch.setenv("NMX_SPECMM", "0")
     eng0 = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
