@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(256) nmx_kern_reref_struct(const NmxRerefStruc
   __shared__ double red[NMX_RS_GROUPS * 256];
   nmx_reref_struct_tile(A, (long long)blockIdx.x * 64, red);
 }
+__global__ void __launch_bounds__(256) nmx_kern_shift(const NmxShiftArgs A) {
+  nmx_shift_sample(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y);
+}
 __global__ void __launch_bounds__(64) nmx_kern_nanmask(const NmxNanMaskArgs A) {
   const int item = blockIdx.x;
   nmx_nanmask_item(A, item / A.C_in, item % A.C_in, nmx_smem);
@@ -265,9 +268,7 @@ static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size
   if (A.w500_tab && nmx_wave_launch_timeosc_stft500(&A, n_items, s)) return;
   // 510-sample FFT / STFT segments (17 ms at 30 kHz): one wave per item, in-place prime-factor transforms
   if (A.w510_tab && nmx_wave_launch_timeosc_w510(&A, n_items, s)) return;
-  static int fixed_ok = -1;
-  if (fixed_ok < 0) { const char* v = getenv("NMX_TIMEOSC_FIXED"); fixed_ok = !(v && v[0] == '0'); }
-  if (fixed_ok && nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return; }
+  if (nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_timeosc, dim3(n_items), dim3(nt), lds, s, A);
   nmxi_note_kernel("nmx_kern_timeosc");
 }
@@ -334,9 +335,7 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt
   if (w500 < 0) { const char* v = getenv("NMX_HILBERT_W500"); w500 = !(v && v[0] == '0'); }
   if (w500 && A.W == 1000 && !A.hil_full) { nmx_wave_launch_hilbert_w500(&A, n_items, s); return; }
   if (w500 && A.W == 2000 && A.w1000_tab) { nmx_wave_launch_hilbert_w1000(&A, n_items, s); return; }
-  static int fixed_ok = -1;
-  if (fixed_ok < 0) { const char* v = getenv("NMX_HILBERT_FIXED"); fixed_ok = !(v && v[0] == '0'); }
-  if (fixed_ok && nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }
+  if (nt == 128) { nmx_hilbert_fixed_launch128(&A, n_items, lds, s); return; }
   hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
   nmxi_note_kernel("nmx_kern_hilbert");
 }
@@ -418,6 +417,10 @@ static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
 static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_reref_struct, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
   nmxi_note_kernel("nmx_kern_reref_struct");
+}
+static void be_launch_shift(const NmxShiftArgs& A, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_shift, dim3((unsigned)((A.T + 255) / 256), (unsigned)A.C), dim3(256), 0, s, A);
+  nmxi_note_kernel("nmx_kern_shift");
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);

@@ -201,6 +201,22 @@ NMX_DEV void nmx_reref_struct_tile(const NmxRerefStructArgs& A, long long t0, do
 }
 #endif
 
+// The split without a re-reference in front (a notch reads the recording's rows directly): y[c][t] = nan_to_num(x[c][t]) -
+// sub[c] on the sample range of a chunk, once per sample like the re-reference kernels (nmx_engine_dc.inc).
+struct NmxShiftArgs {
+  const float* x;
+  long long ldx;
+  float* y;
+  long long ldy;
+  int C;
+  long long T;
+  const float* sub;
+  const float* nanv;
+};
+NMX_DEV void nmx_shift_sample(const NmxShiftArgs& A, long long t, int c) {
+  if (t < A.T) A.y[(long long)c * A.ldy + t] = nmx_clean_sub(A.x[(long long)c * A.ldx + t], A.sub, A.nanv, c);
+}
+
 struct NmxNanMaskArgs {
   const float* x;
   long long ldx;

@@ -166,7 +166,7 @@ extern "C" int NMX_CAT(nmx_w64x2_launch_, NMX_W64_NAME)(const NmxBankW64Args* A,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   static int nw_env = 0;
-  if (!nw_env) { const char* v = getenv("NMX_W64X2_WAVES"); nw_env = (v && atoi(v) >= 1 && atoi(v) <= 8) ? atoi(v) : 8; }
+  if (!nw_env) nw_env = 8;
   const int nw = nw_env, x_floats = A->lds_floats;
   int n_tab = (160 * 1024 / 4 - NMX_W64_TWL_FLOATS - 2048 - nw * x_floats) / 4096;
   if (n_tab > A->b.n_filters) n_tab = A->b.n_filters;
@@ -241,7 +241,7 @@ extern "C" int NMX_CAT(nmx_w64d_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   int nw = (160 * 1024 / 4 - fixed) / x_floats;
   if (nw < 6) return 0;
   static int want = 0;
-  if (!want) { const char* v = getenv("NMX_W64D_WAVES"); want = (v && atoi(v) >= 1 && atoi(v) <= 12) ? atoi(v) : 12; }
+  if (!want) want = 12;
   const int cap = A->b.W <= 512 ? want : (want < 8 ? want : 8);   // W <= 512: 114 VGPRs, three waves per SIMD fit
   if (nw > cap) nw = cap;
   if (n_pairs < 2048) nw = 2;
@@ -325,7 +325,7 @@ extern "C" int NMX_CAT(nmx_w64e_launch_, NMX_W64_NAME)(const NmxBankW64Args* A, 
   int nw = (160 * 1024 / 4 - fixed) / NMX_W64E_TILE_FLOATS;
   if (nw < 4) return 0;
   static int want = 0;
-  if (!want) { const char* v = getenv("NMX_W64E_WAVES"); want = (v && atoi(v) >= 1 && atoi(v) <= 8) ? atoi(v) : 8; }
+  if (!want) want = 8;
   if (nw > want) nw = want;
   if (n_pairs < 2048) nw = 2;   // a hop or two: spread the few items over many CUs
   const size_t lds = (size_t)(fixed + nw * NMX_W64E_TILE_FLOATS) * 4;

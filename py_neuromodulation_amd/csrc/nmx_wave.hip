@@ -133,21 +133,6 @@ __global__ void __launch_bounds__(256) nmx_kern_timeosc_w1000(const NmxTimeOscAr
   nmx_timeosc_w1000_body<NB, false, NmxW500TwReg, false, SPEC>(A, w, c, R, T, smem);
 }
 
-// low bands, no STFT, ONE item per workgroup at 5 waves per SIMD (96 VGPRs: compact twiddles, no prefetch registers):
-// the per-item critical path (three LDS round trips of the transform, DPP chains) is what bounds a wave, so resident
-// waves are what buys throughput
-template <int NB>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
-nmx_kern_timeosc_w1000_low1(const NmxTimeOscArgs A) {
-  const int item = blockIdx.x;
-  const int w = nmx_uniform_i(item / A.n_channels), c = nmx_uniform_i(item % A.n_channels);
-  NmxW500TwRegC T;
-  T.load(A.w500_tab, (int)(threadIdx.x & 63));
-  NmxTdRegs R;
-  nmx_td_load<1000>(A, w, c, R);
-  nmx_timeosc_w1000_body<NB, true, NmxW500TwRegC, true>(A, w, c, R, T, nmx_smem_wave);
-}
-
 // The same without an STFT and with low bands only (nmx_timeosc_w1000_low_ok: the default 4 - 35 Hz bands, BASELINE
 // config[1]): PERSISTENT waves (one-wave workgroups, grid = what the chip holds at once) walk the items with stride
 // gridDim, and the 16-byte loads of a wave's NEXT window are issued before it works on the current one -- the HBM
@@ -227,23 +212,9 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     hipDeviceProp_t prop;
     int dev = 0;
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    const char* v = getenv("NMX_TOW_WAVES");
-    want = (v && atoi(v) >= 1 && atoi(v) <= 16) ? atoi(v) : 12;
+    want = 12;
     const char* u = getenv("NMX_TOW_PERSISTENT");
     low_ok = !(u && u[0] == '0');
-  }
-  static int low1 = -1;
-  if (low1 < 0) { const char* v = getenv("NMX_TOW_LOW1"); low1 = (v && v[0] == '1') ? 1 : 0; }
-  if (low1 && nmx_timeosc_w1000_low_ok(*A)) {
-    const size_t lds1 = (size_t)1008 * 4;   // (one transform buffer: in place)
-    if (A->n_bands <= 4) {
-      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low1<4>, dim3(n_items), dim3(64), lds1, s, *A);
-      nmxi_note_kernel("nmx_kern_timeosc_w1000_low1<4>");
-    } else {
-      hipLaunchKernelGGL(nmx_kern_timeosc_w1000_low1<8>, dim3(n_items), dim3(64), lds1, s, *A);
-      nmxi_note_kernel("nmx_kern_timeosc_w1000_low1<8>");
-    }
-    return 1;
   }
   if (low_ok && nmx_timeosc_w1000_low_ok(*A)) {
     // resident waves per CU: 3 per SIMD (168 VGPRs).  The channel of a wave's items stays fixed -- and with it the XCD
@@ -253,9 +224,7 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     if (grid > C && grid % C) grid -= grid % C;
     if (grid > n_items) grid = n_items;
     const size_t lds = (size_t)NMX_TOW_LOW_LDS_FLOATS * 4;
-    static int spec_ok = -1;
-    if (spec_ok < 0) { const char* v = getenv("NMX_TOW_SPEC"); spec_ok = !(v && v[0] == '0'); }
-    const unsigned spec = spec_ok ? nmx_tow_spec(*A) : 0u;
+    const unsigned spec = nmx_tow_spec(*A);
     if (A->n_bands <= 4 && spec == NMX_TOW_SPEC_C2) {
       hipLaunchKernelGGL((nmx_kern_timeosc_w1000_low<4, NMX_TOW_SPEC_C2>), dim3(grid), dim3(64), lds, s, *A, n_items);
       nmxi_note_kernel("nmx_kern_timeosc_w1000_low<4, 65809u>");
@@ -272,12 +241,10 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
     return 1;
   }
   const size_t lds = (size_t)(A->stft.enabled ? NMX_TOW_LDS_FLOATS : NMX_TOW_LDS_FLOATS_NOSTFT) * 4;
-  static int spec_full = -1;
-  if (spec_full < 0) { const char* v = getenv("NMX_TOW_SPEC"); spec_full = !(v && v[0] == '0'); }
   const int k = waves_per_wg(lds);
   const dim3 grid((unsigned)((n_items + k - 1) / k)), block(64 * k);
   const int slice = (int)(lds / 4);
-  if (A->n_bands <= 4 && spec_full && nmx_tow_spec(*A) == NMX_TOW_SPEC_ALL) {   // the headline set: feature tests folded
+  if (A->n_bands <= 4 && nmx_tow_spec(*A) == NMX_TOW_SPEC_ALL) {   // the headline set: feature tests folded
     hipLaunchKernelGGL((nmx_kern_timeosc_w1000<4, NMX_TOW_SPEC_ALL>), grid, block, lds * k, s, *A, n_items, slice);
     nmxi_note_kernel("nmx_kern_timeosc_w1000<4, 196923u>");
   } else if (A->n_bands <= 4) {
@@ -395,8 +362,7 @@ __global__ void __launch_bounds__(256) nmx_kern_scan(const NmxTimeOscArgs A, int
 }
 
 extern "C" void nmx_wave_launch_scan(const NmxTimeOscArgs* A, int n_items, hipStream_t s) {
-  static int order = -1;
-  if (order < 0) { const char* v = getenv("NMX_SCAN_ORDER"); order = (v && v[0] == '1') ? 1 : 0; }
+  const int order = 0;
   hipLaunchKernelGGL(nmx_kern_scan, dim3((n_items + 3) / 4), dim3(256), 0, s, *A, n_items, n_items / A->n_channels, order);
   nmxi_note_kernel("nmx_kern_scan");
 }

@@ -546,7 +546,7 @@ class HotPathEngine:
         samples; float32 data is taken as it is (in front of a re-reference the library splits it on the device)."""
         if self._dc is None:
             d = None
-            if data.dtype == np.float64 and self.carries_offsets and os.environ.get("NMX_DC_HOST", "1") != "0":
+            if data.dtype == np.float64 and self.carries_offsets and True:
                 seg = np.asarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)
                 ok = np.isfinite(seg)
                 cnt = np.maximum(ok.sum(1), 1)

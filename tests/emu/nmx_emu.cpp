@@ -150,6 +150,10 @@ static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be
   for (int r = 0; r < P.n_rows; ++r)
     for (int j = 0; j < P.n_cols; ++j) nmx_power_ring_at(P, r, j);
 }
+static void be_launch_shift(const NmxShiftArgs& A, be_stream_t) {
+  for (int c = 0; c < A.C; ++c)
+    for (long long t = 0; t < A.T; ++t) nmx_shift_sample(A, t, c);
+}
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
   float sm[64];
   for (int it = 0; it < n_items; ++it) nmx_nanmask_item(A, it / A.C_in, it % A.C_in, sm);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build variants of ONE translation unit here (no GPU needed) and link each into py_neuromodulation_amd/libnmx_v<k>.so next
-# to the product library; the GPU-box script copies a variant over libnmx.so in its scratch copy (tools/exp_variants.sh).
+# to the product library; the GPU-box script copies a variant over libnmx.so in its scratch copy (tools/exp_lib_variants.sh).
 #   tools/build_variants.sh nmx_specmm.hip nmx_specmm.o "" "-DNMX_SMM_DEBUG_NOCOMP" ...
 set -e
 cd "$(dirname "$0")/../py_neuromodulation_amd/csrc"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Mode A with prebuilt variants of the library (tools/build_variants.sh -> py_neuromodulation_amd/libnmx_v<k>.so), same lease.
-#   gpurun -- 'bash tools/exp_specmm2.sh'       (the scratch copy's libnmx.so is overwritten variant by variant)
+#   gpurun -- 'bash tools/exp_lib_variants.sh'       (the scratch copy's libnmx.so is overwritten variant by variant)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 P=py_neuromodulation_amd
