@@ -713,8 +713,8 @@ class HotPathEngine:
         ctr[:] = 0
         W_in = self.W_in
         # slices: what the library's first chunks read (nmx_engine_run.inc: a short first chunk -- 128 hops, or the fill
-        # phase of the burst history, ~320 --, then 1024 hops at a time), each converted by the pool's threads in row blocks
-        hops = [h for h in (128, 320) if h < n] + list(range(320 + 1024, n, 1024)) + [n]
+        # phase of the burst history, ~320 --, then 512 hops at a time), each converted by the pool's threads in row blocks
+        hops = [h for h in (128, 320) if h < n] + list(range(320 + 512, n, 512)) + [n]
         edges = sorted(set([0] + [int(min(T, starts[h - 1] + W_in)) for h in hops] + [T]))
         failed: list = []
 
