@@ -339,13 +339,13 @@ static void be_launch_hilbert(const NmxHilbertArgs& A, long long n_items, int nt
   hipLaunchKernelGGL(nmx_kern_hilbert, dim3((unsigned)n_items), dim3(nt), lds, s, A);
   nmxi_note_kernel("nmx_kern_hilbert");
 }
-extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s);
+extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s, long long windows_seen);
 // windows_seen: hops every sequence has absorbed before this batch (-1: always the workgroup kernel)
 static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, size_t lds, be_stream_t s,
                                 long long windows_seen = -1) {
   be_init_once();
   // ring already full at the first hop: the barrier-free one-wave walk over the list in L2
-  if (windows_seen > 0 && nmx_burst_thr_wave_ok(A, windows_seen)) { nmx_wave_launch_burst_thr(&A, n_items, s); return; }
+  if (windows_seen > 0 && nmx_burst_thr_wave_ok(A, windows_seen)) { nmx_wave_launch_burst_thr(&A, n_items, s, windows_seen); return; }
   const int chunk = (A.K + nt - 1) / nt;
   if (nt > 256) { hipLaunchKernelGGL(nmx_kern_burst_thr_wide, dim3(n_items), dim3(1024), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr_wide"); }
   else if (chunk <= 32) { hipLaunchKernelGGL(nmx_kern_burst_thr<32>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<32>"); }

@@ -394,7 +394,11 @@ static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long win
 #else
 #define NMX_TP(i)
 #endif
-template <int NR>
+// LL: the top-K list itself lives in LDS for the duration of the launch (copied in at entry, out at exit) whenever it fits
+// next to the working set twice per CU (K <= ~13 500: the default 30 s history at 1 kHz is 7 500 entries, 30 KB).  A flush
+// then merges at LDS speed: through the L2-resident array it was 104 k cycles of dependent global round trips per flush
+// (profiles/r04_stream_trace.txt: 53 % of a young stream's walk, which flushes every ~15 hops).
+template <int NR, bool LL>
 NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, float* smem) {
   const int lane = (int)(threadIdx.x & 63);
   // fringe capacity scales with the samples a hop brings: a stationary signal accepts ~(1 - q) of them, each
@@ -417,7 +421,18 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
   int* cb = (int*)(stage + PF * 64 * NR);   // [K / 64 + 2] pending samples above each 64-entry block (flush)
   const int K = A.K, W = A.W, ov = A.overlap;
   const long long sidx = (long long)c * A.n_bands + bi;
-  float* L = A.top + sidx * K;              // descending top-K list (global, L2 resident)
+  float* Lg = A.top + sidx * K;             // descending top-K list (global, L2 resident)
+  float* L = LL ? (float*)(cb + (K / 64 + 4)) : Lg;
+  if (LL) {
+    for (int j0 = 0; j0 < K; j0 += 64 * 8) {   // eight independent loads in flight
+      float t8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int j = j0 + 64 * q + lane; t8[q] = j < K ? Lg[j] : 0.f; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int j = j0 + 64 * q + lane; if (j < K) L[j] = t8[q]; }
+    }
+    NMX_WAVE_FENCE();
+  }
   long long total = A.counts[2 * sidx];
   long long nwin = A.counts[2 * sidx + 1];
   const long long m_ring = A.n_ring;
@@ -670,7 +685,8 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
         Lm += nP;
         for (int j = lane; j < nF; j += 64) L[Lm + j] = F[fh + nF - 1 - j];
         // (Lm + nF == K by construction)
-        __threadfence();   // the re-cut below reads what this wave just stored
+        if (!LL) __threadfence();   // the re-cut below reads what this wave just stored
+        else NMX_WAVE_FENCE();
         nF = TREFILL;
         fh = 0;
         Lm = K - nF;
@@ -691,6 +707,10 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
     printf("[thrw %lld] hops %d inserts %d flushes %d | cycles: top %lld classify %lld fringe %lld store %lld sort %lld stream %lld recut %lld\n",
            sidx, A.n_windows, n_ins, n_flush, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
 #endif
+  if (LL) {   // the list goes back to the state array (every launch ends in a flush: L is complete)
+    NMX_WAVE_FENCE();
+    for (int j = lane; j < K; j += 64) Lg[j] = L[j];
+  }
   if (lane == 0) {
     A.counts[2 * sidx] = total;
     A.counts[2 * sidx + 1] = nwin;

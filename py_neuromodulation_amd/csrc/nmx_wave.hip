@@ -69,26 +69,41 @@ __global__ void __launch_bounds__(256) nmx_kern_sharp(const NmxSharpArgs A, int 
   nmx_sharp_item(A, r / A.n_channels, r % A.n_channels, fi, nmx_smem_wave + wave * slice);
 }
 
-// threshold walk, steady regime: one wave per (channel, band); NR = registers per lane for a hop's new samples
-template <int NR>
+// threshold walk, steady regime: one wave per (channel, band); NR = registers per lane for a hop's new samples, LL = the
+// top-K list in LDS for the launch (nmx_k_bursts.h)
+template <int NR, bool LL>
 __global__ void __launch_bounds__(64) nmx_kern_burst_thr_wave(const NmxBurstThrArgs A) {
   __builtin_amdgcn_s_setprio(3);   // sequential and on the critical path: win issue arbitration
   const int item = blockIdx.x;
-  nmx_burst_thr_wave_item<NR>(A, item / A.n_bands, item % A.n_bands, nmx_smem_wave);
+  nmx_burst_thr_wave_item<NR, LL>(A, item / A.n_bands, item % A.n_bands, nmx_smem_wave);
 }
 
-extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s) {
-  if (A->overlap <= 128) {
-    const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS_NR(2) + A->K / 64 + 4) * 4;
-    hipLaunchKernelGGL(nmx_kern_burst_thr_wave<2>, dim3(n_items), dim3(64), lds, s, *A);
-    nmxi_note_kernel("nmx_kern_burst_thr_wave<2>");
+extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items, hipStream_t s, long long windows_seen) {
+  const char* v_ll = getenv("NMX_THR_LIST_LDS");   // (read per launch: the tests run both forms in one process)
+  const bool lds_list = !(v_ll && v_ll[0] == '0');
+  static unsigned long long seen = 0;
+  if (nmx_first_on_device(seen)) {
+    (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int nr = A->overlap <= 128 ? 2 : 4;
+  const size_t base = (size_t)((nr == 2 ? NMX_THRW_LDS_FLOATS_NR(2) : NMX_THRW_LDS_FLOATS_NR(4)) + A->K / 64 + 4) * 4;
+  const size_t with_list = base + (size_t)A->K * 4;
+  // The list in LDS pays while the stream is YOUNG: the ring has just filled, a quarter of every hop's samples still enters
+  // the list and a flush is due every ~15 hops (a fresh 120 s stream: 25.4 -> 22.2 ms end to end).  After thousands of hops
+  // the kept minimum has risen, flushes are rare, and 56 KB of LDS per walk only take occupancy from the throughput
+  // kernels running next to it (the bench's steady state: 6.59 -> 6.87 ms per step) -- then the list stays in L2.
+  const bool ll = lds_list && with_list <= 80 * 1024 && windows_seen < 4096;   // (two walks per CU: 512 series in one round)
+  const size_t lds = ll ? with_list : base;
+  if (nr == 2) {
+    if (ll) hipLaunchKernelGGL((nmx_kern_burst_thr_wave<2, true>), dim3(n_items), dim3(64), lds, s, *A);
+    else hipLaunchKernelGGL((nmx_kern_burst_thr_wave<2, false>), dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel(ll ? "nmx_kern_burst_thr_wave<2, true>" : "nmx_kern_burst_thr_wave<2, false>");
   } else {
-    static unsigned long long seen = 0;
-    if (nmx_first_on_device(seen))
-      (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const size_t lds = (size_t)(NMX_THRW_LDS_FLOATS_NR(4) + A->K / 64 + 4) * 4;
-    hipLaunchKernelGGL(nmx_kern_burst_thr_wave<4>, dim3(n_items), dim3(64), lds, s, *A);
-    nmxi_note_kernel("nmx_kern_burst_thr_wave<4>");
+    if (ll) hipLaunchKernelGGL((nmx_kern_burst_thr_wave<4, true>), dim3(n_items), dim3(64), lds, s, *A);
+    else hipLaunchKernelGGL((nmx_kern_burst_thr_wave<4, false>), dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel(ll ? "nmx_kern_burst_thr_wave<4, true>" : "nmx_kern_burst_thr_wave<4, false>");
   }
 }
 

@@ -158,6 +158,13 @@ def test_bursts_steady_state_vs_oracle(gpu_lib):
     pc.case_bursts_steady_state_vs_oracle(gpu_lib)
 
 
+def test_bursts_steady_state_list_in_l2(gpu_lib, monkeypatch):
+    """The one-wave threshold walk with its top-K list in the L2-resident state array (what a stream of more than 4096 hops
+    runs; a young stream keeps the list in LDS for the launch): the same case, the same thresholds."""
+    monkeypatch.setenv("NMX_THR_LIST_LDS", "0")
+    pc.case_bursts_steady_state_vs_oracle(gpu_lib)
+
+
 def _bench_like_engine(gpu_lib, C, scale=1.0, pre=True, device=0):
     from py_neuromodulation_amd import NMSettings, fir_design
     from py_neuromodulation_amd.engine import HotPathEngine
