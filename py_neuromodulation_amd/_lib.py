@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 8
+NMX_ABI_VERSION = 9
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -86,6 +86,7 @@ _EXPORTS = [
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
     "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free",
     "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets", "nmx_plan_set_pipeline",
+    "nmx_host_stage_rows", "nmx_host_group_sums", "nmx_host_widen_rows",
 ]
 
 
@@ -158,6 +159,12 @@ class NmxLibrary:
         L.nmx_plan_carries_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.nmx_plan_set_offsets.argtypes = [C.c_void_p, C.c_void_p]
         L.nmx_plan_get_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.nmx_host_stage_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int32,
+                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
+        L.nmx_host_group_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
+                                          C.c_int64, C.c_int32]
+        L.nmx_host_widen_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                          C.c_int32, C.c_int32]
         if L.nmx_abi_version() != NMX_ABI_VERSION:
             raise NmxError("libnmx ABI version mismatch")
 

@@ -222,6 +222,108 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
   // paid two dependent global-memory round trips -- 3 us per row, 0.8 ms per 256-hop chunk of the default stream for
   // 124 waves of work.  (The slot a row trims was written cap - 1 rows earlier: before the block when cap - 1 >= PF.)
   const bool pf_o = cap - 1 >= NMX_NORM_PF;
+  if (!med) {
+    // "mean" / "zscore" (the default): the walk splits into what IS sequential -- the sliding sums, a handful of float64
+    // additions per hop -- and what is not: a hop's mean, standard deviation and quotient (float64 divisions and a square
+    // root: ~150 dependent instructions) only read that hop's sums.  Per block of NMX_NORM_PF hops the sums are advanced
+    // first (snapshots in registers), then the block's outputs are formed side by side: one thread per column keeps eight
+    // division chains in flight instead of one (the kernel is 156 waves of pure latency; measured in profiles/README.md, round 5).
+    for (int r0 = 0; r0 < A.n_rows; r0 += NMX_NORM_PF) {
+      float xb[NMX_NORM_PF], ob[NMX_NORM_PF];
+      double S1[NMX_NORM_PF], S2[NMX_NORM_PF], VO[NMX_NORM_PF];   // sums after the hop's value entered; two-pass variance or < 0
+      int CN[NMX_NORM_PF], NI[NMX_NORM_PF];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int i = 0; i < NMX_NORM_PF; ++i) {
+        const int rr = r0 + i < A.n_rows ? r0 + i : A.n_rows - 1;
+        xb[i] = A.rows[(long long)rr * A.ld + j];
+        const long long qo = A.seq0 + rr - (cap - 1);
+        ob[i] = (pf_o && qo >= 0) ? A.ring[(qo % cap) * A.n_cols + j] : 0.f;
+      }
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int bi = 0; bi < NMX_NORM_PF; ++bi) {
+        S1[bi] = 0.0; S2[bi] = 0.0; VO[bi] = -1.0; CN[bi] = 0; NI[bi] = 0;
+        if (r0 + bi >= A.n_rows) continue;
+        const long long q = A.seq0 + r0 + bi;
+        const float x = xb[bi];
+        if (len == cap) {  // cannot happen with the trim below; kept for safety
+          const float o = A.ring[((q - cap) % cap) * A.n_cols + j];
+          if (o == o) {
+            if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
+          }
+          --len;
+        }
+        A.ring[(q % cap) * A.n_cols + j] = x;
+        if (nmx_norm_finite(x)) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
+        else if (x == x) ++ninf;
+        ++len;
+        S1[bi] = s1; S2[bi] = s2; CN[bi] = cnt; NI[bi] = ninf;
+        // cancellation (one-pass error ~ eps mean^2 / var; var < 1e-8 mean^2 without a division: x cnt^2): two-pass
+        // over the ring NOW, while it holds this hop's window (rare)
+        if (A.method == NMX_NORM_ZSCORE && q > 0 && cnt > 0 && ninf == 0 && s2 * (double)cnt - s1 * s1 < 1e-8 * s1 * s1) {
+          const double mean = s1 / (double)cnt;
+          double acc = 0.0;
+          for (long long t = q - len + 1; t <= q; ++t) {
+            const float h = A.ring[(t % cap) * A.n_cols + j];
+            if (h == h) { const double d = (double)h - mean; acc += d * d; }
+          }
+          VO[bi] = acc / (double)cnt;
+        }
+        // history keeps its last N - 1 rows (normalization.py:107)
+        if (len > cap - 1) {
+          const float o = pf_o ? ob[bi] : A.ring[((q - (cap - 1)) % cap) * A.n_cols + j];
+          if (o == o) {
+            if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
+          }
+          --len;
+          // (a value far larger than what stays behind leaves the sums with ITS rounding: rebuild them -- see the general
+          // walk below for the measure)
+          const double spread = cnt > 0 ? s2 - s1 * s1 / (double)cnt : 0.0;
+          const double mabs = cnt > 0 ? fabs(s1) / (double)cnt : 0.0, oabs = fabs((double)o);
+          if (nmx_norm_finite(o) && (!(oabs * oabs <= 1e4 * s2) || !(oabs * (oabs + 2.0 * mabs) <= 1e5 * spread))) {
+            s1 = 0.0; s2 = 0.0; cnt = 0; ninf = 0;
+            for (long long t = q - len + 1; t <= q; ++t) {
+              const float h = A.ring[(t % cap) * A.n_cols + j];
+              if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+              else if (h == h) ++ninf;
+            }
+          }
+        }
+      }
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int bi = 0; bi < NMX_NORM_PF; ++bi) {   // the block's outputs: independent of each other
+        if (r0 + bi >= A.n_rows) continue;
+        const long long q = A.seq0 + r0 + bi;
+        if (q == 0) continue;   // the first row ever is returned as it came
+        const double x = (double)xb[bi];
+        double out;
+        if (CN[bi] + NI[bi] == 0 || NI[bi] > 0) {
+          out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
+        } else {
+          const double mean = S1[bi] / (double)CN[bi];
+          if (A.method == NMX_NORM_MEAN) {
+            out = (x - mean) / mean;
+          } else {
+            const double var = VO[bi] >= 0.0 ? VO[bi] : S2[bi] / (double)CN[bi] - mean * mean;
+            double sd = var > 0.0 ? sqrt(var) : 0.0;
+            if (sd == 0.0) sd = 1.0;
+            out = (x - mean) / sd;
+          }
+        }
+        if (A.clip > 0.f) {  // ndarray.clip: NaN stays NaN
+          if (out < -(double)A.clip) out = -(double)A.clip;
+          if (out > (double)A.clip) out = (double)A.clip;
+        }
+        A.rows[(long long)(r0 + bi) * A.ld + j] = nmx_clean((float)out);
+      }
+    }
+    return;
+  }
   for (int r0 = 0; r0 < A.n_rows; r0 += NMX_NORM_PF) {
   float xb[NMX_NORM_PF], ob[NMX_NORM_PF];
 #ifndef NMX_HOST_EMU

@@ -440,7 +440,7 @@ class DataProcessor:
         if self.device_normalizer is not None and not normalised:
             out = self.device_normalizer.process_batch(out)
         o64 = np.empty(out.shape, np.float64)
-        parallel_cast(o64, out)
+        parallel_cast(o64, out, None, self.engine.lib)
         out = o64
         if self.feature_normalizer is None and not mask.any():
             return out

@@ -2,8 +2,6 @@
 
 from __future__ import annotations
 
-import math
-
 import numpy as np
 
 
@@ -20,20 +18,18 @@ def window_schedule(n_samples: int, sfreq: float, sampling_rate_features_hz: flo
     """
     seg = segment_length_features_ms / 1000 * sfreq
     stride = sfreq / sampling_rate_features_hz
-    starts, lens, times = [], [], []
-    k = 0
-    while True:
-        start = stride * k
-        end = start + seg
-        k += 1
-        if int(end) > n_samples:
-            break
-        # np.arange(start, end)[-1] without building the array: ceil((end - start) / 1) elements, the i-th is start + i
-        ts_last = (start + (math.ceil(end - start) - 1)) / sfreq
-        starts.append(int(start))
-        lens.append(int(end) - int(start))
-        times.append(math.ceil(ts_last * 1000 + 1))
-    return (np.asarray(starts, np.int64), np.asarray(lens, np.int64), np.asarray(times, np.float64))
+    # every hop at once, in the same IEEE operations as the generator's loop (k * stride, + seg, truncation): the
+    # window ends grow with k, so the hops that fit are a prefix of a generous range
+    n_max = max(int((n_samples - seg) / stride) + 3, 0) if stride > 0 else 0
+    start = stride * np.arange(n_max, dtype=np.float64)
+    end = start + seg
+    fits = end.astype(np.int64) <= n_samples
+    n = int(n_max if fits.all() else np.argmin(fits))
+    start, end = start[:n], end[:n]
+    # np.arange(start, end)[-1] without building the array: ceil((end - start) / 1) elements, the i-th is start + i
+    ts_last = (start + (np.ceil(end - start) - 1)) / sfreq
+    starts = start.astype(np.int64)
+    return starts, end.astype(np.int64) - starts, np.ceil(ts_last * 1000 + 1)
 
 
 class RawDataGenerator:

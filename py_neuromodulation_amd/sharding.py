@@ -325,41 +325,59 @@ class MultiDeviceProcessor:
         list(_pool().map(job, range(len(edges) - 1)))
         return out
 
+    def _merge_widen(self, outs) -> np.ndarray:
+        """The parts' float32 rows (engine order) -> the float64 table in the global column order, ONE pass
+        (nmx_host_widen_rows): widening each part on its own and gathering the joined table afterwards wrote the
+        82 MB of a 1024-hop table twice and read it once more.  The reference's keys run feature by feature, channel by
+        channel: a part's columns land in a few dozen contiguous runs."""
+        lib = self.parts[0].engine.lib
+        n, F = outs[0].shape[0], len(self.keys)
+        if getattr(self, "_runs", None) is None:
+            self._runs = []
+            for cols in self._cols:
+                cut = np.flatnonzero(np.diff(cols) != 1) + 1
+                first = np.concatenate([[0], cut]).astype(np.int64)
+                length = np.diff(np.concatenate([first, [len(cols)]]))
+                self._runs.append(np.ascontiguousarray(np.stack([cols[first], first, length], axis=1), dtype=np.int64)
+                                  if len(cols) else np.zeros((0, 3), np.int64))
+        n_builtin = int(sum(len(c) for c in self._cols))
+        table = np.full((n, F), np.nan) if F != n_builtin else np.empty((n, F))
+        for o, runs in zip(outs, self._runs):
+            o = o if (o.dtype == np.float32 and o.ndim == 2 and o.strides[1] == 4 and o.strides[0] % 4 == 0
+                      and o.strides[0] > 0) else np.ascontiguousarray(o, dtype=np.float32)
+            if n and len(runs):
+                lib.check(lib.lib.nmx_host_widen_rows(table.ctypes.data, F, o.ctypes.data, o.strides[0] // 4, 0, n,
+                                                      runs.ctypes.data, len(runs), 0))
+        return table
+
     # -- local input: what every device is handed ------------------------------------------------------
     def _local_inputs(self, data: np.ndarray):
-        """-> per part float32 [rows of the part + its group-sum rows, T]; the group sums are formed once in float64
-        from nan_to_num(x) (the reference cleans before it re-references, stream/data_processor.py:255)."""
-        from .engine import _pool
-
+        """-> per part float32 [rows of the part + its group-sum rows, T] in the part's page-locked staging array; the
+        group sums are formed once in float64 from nan_to_num(x) (the reference cleans before it re-references,
+        stream/data_processor.py:255) by libnmx's staging helpers: one pass over the recording for the sums, one for the
+        rows (the NumPy reduction along the channel axis ran at ~3 GB/s and set the rate of the whole stream)."""
         data = np.asarray(data)
-        T = data.shape[1]
+        if not (data.dtype in (np.float32, np.float64) and data.strides[1] == data.itemsize and data.strides[0] > 0
+                and data.strides[0] % data.itemsize == 0):
+            data = np.ascontiguousarray(data, dtype=np.float32 if data.dtype == np.float32 else np.float64)
+        lib = self.parts[0].engine.lib
+        T, f64, ld = data.shape[1], int(data.dtype == np.float64), data.strides[0] // data.itemsize
         # (the float32-ROUNDED samples are summed: that is what a device that holds the rows itself adds up)
-        edges = [(i * T) // 8 for i in range(9)] if T >= 4096 else [0, T]
-        sums = [np.empty(T) for _ in self._groups]
-
-        def sum_block(i):
-            a, b = edges[i], edges[i + 1]
-            for out, g in zip(sums, self._groups):
-                rows = data[:, a:b] if (len(g) == data.shape[0] and g[0] == 0 and g[-1] == len(g) - 1) else data[g, a:b]
-                blk = np.asarray(rows, np.float32)
-                sb = blk.sum(axis=0, dtype=np.float64)
-                if not np.isfinite(sb).all():      # a NaN / infinity somewhere in the block: clean first, like the kernels
-                    sb = np.nan_to_num(blk).sum(axis=0, dtype=np.float64)
-                out[a:b] = sb
-
-        list(_pool().map(sum_block, range(len(edges) - 1)))
-        hilo = [chmod.split_hi_lo(v) for v in sums]
-        xs = [np.empty((len(p.local_rows) + 2 * len(ids), T), np.float32) for p, ids in zip(self.parts, self._part_groups)]
-
-        def fill(k):
-            p, ids, x = self.parts[k], self._part_groups[k], xs[k]
+        hilo = []
+        for g in self._groups:
+            v, rows = np.empty(T), np.ascontiguousarray(g, dtype=np.int32)
+            lib.check(lib.lib.nmx_host_group_sums(v.ctypes.data, data.ctypes.data, f64, ld, rows.ctypes.data, len(rows), 0, T, 0))
+            hilo.append(chmod.split_hi_lo(v))
+        xs = []
+        for p, ids in zip(self.parts, self._part_groups):
             nl = len(p.local_rows)
-            r = p.local_rows
-            x[:nl] = data[r[0]:r[-1] + 1] if r == list(range(r[0], r[0] + nl)) else data[r]
+            x = p.engine._pinned.array("x_local", (nl + 2 * len(ids), T), np.float32)
+            rows = np.ascontiguousarray(p.local_rows, dtype=np.int32)
+            lib.check(lib.lib.nmx_host_stage_rows(x.ctypes.data, x.strides[0] // 4, data.ctypes.data, f64, ld,
+                                                  rows.ctypes.data, nl, 0, T, None, 0))
             for q, gi in enumerate(ids):
                 x[nl + 2 * q:nl + 2 * q + 2] = hilo[gi]
-
-        list(_pool().map(fill, range(len(self.parts))))
+            xs.append(x)
         return xs
 
     def _full_mask(self, masks, n_all: int) -> np.ndarray:
@@ -369,13 +387,14 @@ class MultiDeviceProcessor:
             full[:, p.local_rows] |= m[:, :len(p.local_rows)]
         return full
 
-    def _run_parts(self, data, starts, tapped: bool):
-        """Every part on its own thread -> [(float32 rows, mask over ALL input rows, windows or None)]."""
+    def _run_parts(self, data, starts, tapped: bool, staged: bool = False):
+        """Every part on its own thread -> [(float32 rows, mask over ALL input rows, windows or None)].  ``staged``: the
+        rows are views of the parts' page-locked output staging (valid until their next call)."""
         if not self.local_input:
             if tapped:
                 return list(self._pool.map(lambda p: p.process_batch_tapped(data, starts), self.parts))
             return [(o, m, None) for o, m in self._pool.map(
-                lambda p: p.engine.process_batch(data, starts, want_nan_mask=True), self.parts)]
+                lambda p: p.engine.process_batch(data, starts, want_nan_mask=True, staged_output=staged), self.parts)]
         xs = self._local_inputs(data)
 
         W_in = self.parts[0].engine.W_in
@@ -393,7 +412,7 @@ class MultiDeviceProcessor:
             if tapped:
                 o, m, pre = p.engine.process_batch(x, starts, want_nan_mask=True, tap=True)
                 return o, m, pre.astype(np.float64)
-            o, m = p.engine.process_batch(x, starts, want_nan_mask=True)
+            o, m = p.engine.process_batch(x, starts, want_nan_mask=True, staged_output=staged)
             return o, m, None
 
         got = list(self._pool.map(job, zip(self.parts, xs)))
@@ -402,6 +421,19 @@ class MultiDeviceProcessor:
 
     def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
         starts = np.asarray(starts, dtype=np.int64)
+        if self._user is None and all(p.feature_normalizer is None and (p.device_normalizer is None or p._norm_in_engine)
+                                      for p in self.parts):
+            # nothing between the engines' rows and the table but the widening and the NaN policy
+            got = self._run_parts(data, starts, False, staged=True)
+            table = self._merge_widen([o for o, _, _ in got])
+            mask = got[0][1]   # over ALL incoming rows, the same for every part
+            if mask.any():     # every key that contains the name of a channel whose window held a NaN := NaN (:297-306)
+                if mask.shape[1] != len(self.ch_names_used):
+                    raise IndexError("boolean index did not match: NaN handling needs every channel used")
+                nan_cols = _LazyNanCols(self.keys, self.ch_names_used)
+                for ci in np.where(mask.any(axis=0))[0]:
+                    table[np.ix_(mask[:, ci], nan_cols[ci])] = np.nan
+            return table
         if self._user is None:
             got = self._run_parts(data, starts, False)
             rows = [p.postprocess_batch(o, m, normalised=p._norm_in_engine) for p, (o, m, _) in zip(self.parts, got)]

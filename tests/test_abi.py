@@ -135,3 +135,64 @@ def test_bench_refuses_missing_gpus():
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "!= WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+def test_host_staging_helpers_equal_numpy():
+    """nmx_host_stage_rows / nmx_host_group_sums / nmx_host_widen_rows (host passes, no device): bit for bit what the
+    NumPy expressions they replace give -- cast after the float64 subtraction, nan_to_num before the float64 sum in row
+    order, widening into column runs -- on strided views, row subsets, and sizes on both sides of the threading cut."""
+    import numpy as np
+
+    from py_neuromodulation_amd import _lib
+    from py_neuromodulation_amd.engine import parallel_cast
+
+    lib = _lib.NmxLibrary()
+    rng = np.random.default_rng(5)
+    for (R, T) in ((3, 50), (9, 4000), (40, 30011)):
+        big = rng.standard_normal((R + 2, T + 7)) * 1e3 + rng.uniform(-1e6, 1e6, (R + 2, 1))
+        big[1, 3] = np.nan
+        big[2, 5] = np.inf
+        big[0, 6] = -np.inf
+        for dtype in (np.float64, np.float32):
+            src = big.astype(dtype)[1:R + 1, 2:T + 2]           # a strided view
+            sub = rng.uniform(-1e6, 1e6, R) * (rng.random(R) < 0.7)
+            want = (np.asarray(src, np.float64) - sub[:, None]).astype(np.float32)
+            got = np.full((R, T + 5), -7.0, np.float32)
+            parallel_cast(got[:, :T], src, sub, lib)
+            np.testing.assert_array_equal(got[:, :T], want)
+            assert (got[:, T:] == -7.0).all()
+            got2 = np.empty((R, T), np.float32)
+            parallel_cast(got2, src, None, lib)
+            np.testing.assert_array_equal(got2, src.astype(np.float32))
+            # a row subset, a column range
+            rows = np.ascontiguousarray(rng.permutation(R)[:max(1, R // 2)], dtype=np.int32)
+            t0, t1 = T // 5, T - 3
+            dst = np.zeros((len(rows), T), np.float32)
+            lib.check(lib.lib.nmx_host_stage_rows(dst.ctypes.data, T, src.ctypes.data, int(dtype == np.float64),
+                                                  src.strides[0] // src.itemsize, rows.ctypes.data, len(rows), t0, t1,
+                                                  sub.ctypes.data, 3))
+            np.testing.assert_array_equal(dst[:, t0:t1], want[rows][:, t0:t1])
+            assert (dst[:, :t0] == 0).all() and (dst[:, t1:] == 0).all()
+            # group sums: nan_to_num of the float32-rounded samples, float64, rows in order
+            s = np.full(T, -1.0)
+            lib.check(lib.lib.nmx_host_group_sums(s.ctypes.data, src.ctypes.data, int(dtype == np.float64),
+                                                  src.strides[0] // src.itemsize, rows.ctypes.data, len(rows), t0, t1, 0))
+            ref = np.zeros(T)
+            for r in rows:
+                ref += np.nan_to_num(src[r].astype(np.float32)).astype(np.float64)
+            np.testing.assert_array_equal(s[t0:t1], ref[t0:t1])
+            assert (s[:t0] == -1.0).all() and (s[t1:] == -1.0).all()
+        # widening into column runs
+        f = rng.standard_normal((R, T)).astype(np.float32)
+        f[0, 0] = np.nan
+        table = np.full((R, 2 * T + 3), -3.0)
+        cut = T // 3
+        runs = np.array([[T + 3, 0, cut], [1, cut, T - cut]], dtype=np.int64)
+        lib.check(lib.lib.nmx_host_widen_rows(table.ctypes.data, table.shape[1], f.ctypes.data, T, 0, R, runs.ctypes.data, 2, 0))
+        np.testing.assert_array_equal(table[:, T + 3:T + 3 + cut], f[:, :cut].astype(np.float64))
+        np.testing.assert_array_equal(table[:, 1:1 + T - cut], f[:, cut:].astype(np.float64))
+        assert (table[:, 0] == -3.0).all() and (table[:, 1 + T - cut:T + 3] == -3.0).all() and (table[:, T + 3 + cut:] == -3.0).all()
+        o64 = np.empty((R, T))
+        parallel_cast(o64, f, None, lib)
+        np.testing.assert_array_equal(o64, f.astype(np.float64))
+    assert lib.lib.nmx_host_widen_rows(None, 0, None, 0, 0, 0, None, 0, 0) != 0   # argument validation, no crash
