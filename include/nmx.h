@@ -340,7 +340,7 @@ int nmx_plan_attach_norm(nmx_plan* plan, nmx_norm* norm);
 int nmx_host_alloc(int64_t n_bytes, void** out);
 int nmx_host_free(void* p);
 
-/* Host-side staging passes of the boundary (no device work; a few threads of their own, n_threads <= 0: up to 8).  They
+/* Host-side staging passes of the boundary (no device work; a few threads of their own, n_threads <= 0: an eighth of the machine, 4 .. 16).  They
  * replace what a NumPy host does at 1 - 3 GB/s around a batch call -- the reference hands float64 rows
  * (stream/stream.py:298-310) and expects a float64 table in its own column order (stream/stream.py:319-343):
  *   nmx_host_stage_rows   dst[r][t] = (float)(src[rows[r]][t] - sub[rows[r]])  for r < n_rows, t in [t0, t1)
@@ -349,6 +349,9 @@ int nmx_host_free(void* p);
  *   nmx_host_group_sums   sum[t] = sum over r of nan_to_num((float)src[rows[r]][t]) in float64, rows in order, t in
  *                         [t0, t1): the channel sum of a re-reference group (processing/rereference.py:52-100) for the
  *                         parts of a multi-device stream, which each hold some of the group's rows;
+ *   nmx_host_stage_parts  both of the above in ONE pass over src rows 0 .. n_src_rows - 1, samples [t0, t1), block by
+ *                         block: row j goes to dst_rows[j] (pointer to sample 0 of its destination row; NULL: nowhere),
+ *                         group g = source rows group_rows[group_ptr[g] .. group_ptr[g + 1]) is summed into sum_rows[g];
  *   nmx_host_widen_rows   dst[r][runs[k][0] + i] = (double)src[r][runs[k][1] + i],  i < runs[k][2], r in [r0, r1): the
  *                         float32 rows of one part into the float64 table, runs[n_runs][3] = (first column in dst, first
  *                         column in src, length). */
@@ -356,6 +359,9 @@ int nmx_host_stage_rows(float* dst, int64_t ld_dst, const void* src, int src_is_
                         int32_t n_rows, int64_t t0, int64_t t1, const double* sub, int32_t n_threads);
 int nmx_host_group_sums(double* sum, const void* src, int src_is_f64, int64_t ld_src, const int32_t* rows, int32_t n_rows,
                         int64_t t0, int64_t t1, int32_t n_threads);
+int nmx_host_stage_parts(const void* src, int src_is_f64, int64_t ld_src, int32_t n_src_rows, int64_t t0, int64_t t1,
+                         float* const* dst_rows, int32_t n_groups, const int32_t* group_ptr, const int32_t* group_rows,
+                         double* const* sum_rows, int32_t n_threads);
 int nmx_host_widen_rows(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t r0, int64_t r1,
                         const int64_t* runs, int32_t n_runs, int32_t n_threads);
 

@@ -86,7 +86,7 @@ _EXPORTS = [
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
     "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free",
     "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets", "nmx_plan_set_pipeline",
-    "nmx_host_stage_rows", "nmx_host_group_sums", "nmx_host_widen_rows",
+    "nmx_host_stage_rows", "nmx_host_group_sums", "nmx_host_stage_parts", "nmx_host_widen_rows",
 ]
 
 
@@ -163,6 +163,8 @@ class NmxLibrary:
                                           C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
         L.nmx_host_group_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                           C.c_int64, C.c_int32]
+        L.nmx_host_stage_parts.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.nmx_host_widen_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                           C.c_int32, C.c_int32]
         if L.nmx_abi_version() != NMX_ABI_VERSION:

@@ -435,11 +435,11 @@ class DataProcessor:
     def postprocess_batch(self, out: np.ndarray, mask: np.ndarray, normalised: bool = False) -> np.ndarray:
         """Normalisation + NaN policy for engine rows ``out[n, F]`` (hop order); ``normalised``: the
         attached device normaliser already ran inside the engine."""
-        from .engine import parallel_cast
+        from .engine import parallel_cast, table_empty
 
         if self.device_normalizer is not None and not normalised:
             out = self.device_normalizer.process_batch(out)
-        o64 = np.empty(out.shape, np.float64)
+        o64 = table_empty(out.shape)
         parallel_cast(o64, out, None, self.engine.lib)
         out = o64
         if self.feature_normalizer is None and not mask.any():

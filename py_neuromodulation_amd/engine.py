@@ -97,6 +97,78 @@ def parallel_cast(dst: np.ndarray, src: np.ndarray, sub: np.ndarray | None = Non
     list(_pool().map(lambda i: put(edges[i], edges[i + 1]), range(k)))
 
 
+class _TableLease:
+    """Owner of a result table's memory: hands its buffer back to the pool when the last array on it is gone."""
+
+    def __init__(self, raw: np.ndarray, pool: "_TablePool") -> None:
+        self._raw, self._pool = raw, pool
+        self.__array_interface__ = raw.__array_interface__
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self._raw)
+        except Exception:   # (interpreter shutdown)
+            pass
+
+
+class _TablePool:
+    """Recycled float64 result tables.  A stream of the reference's shape hands a fresh [hops, features] float64 table to
+    its caller per run (stream/stream.py:319-343): 75 - 80 MB whose first touch is ~20 000 page faults and whose release
+    another ~3 ms of munmap (measured on the GPU box: touch 4 - 85 ms depending on what the kernel finds for its huge
+    pages, free 2.8 - 3.2 ms), per run, on the caller's thread.  The tables here are ordinary ndarrays whose memory goes
+    back to this pool instead of the system when the caller drops them (DataFrame included) -- the next run finds its pages
+    mapped.  At most ``keep`` idle buffers are held (``release_tables()`` frees them); small tables are not pooled."""
+
+    MIN_BYTES = 1 << 22
+
+    def __init__(self, keep: int = 2) -> None:
+        import threading
+
+        self.keep, self._free, self._lock = keep, [], threading.Lock()
+
+    def empty(self, shape, fill=None) -> np.ndarray:
+        n = int(np.prod(shape))
+        if n * 8 < self.MIN_BYTES:
+            return np.empty(shape) if fill is None else np.full(shape, fill)
+        raw = None
+        with self._lock:
+            for i, b in enumerate(self._free):
+                if n <= b.size <= n + n // 4:
+                    raw = self._free.pop(i)
+                    break
+        if raw is None:
+            raw = np.empty(n)
+        arr = np.asarray(_TableLease(raw, self))[:n].reshape(shape)
+        if fill is not None:
+            arr.fill(fill)
+        return arr
+
+    def _give_back(self, raw: np.ndarray) -> None:
+        with self._lock:
+            self._free.append(raw)
+            while len(self._free) > self.keep:
+                self._free.pop(0)
+
+    def clear(self) -> int:
+        with self._lock:
+            n = len(self._free)
+            self._free.clear()
+        return n
+
+
+_TABLES = _TablePool()
+
+
+def table_empty(shape, fill=None) -> np.ndarray:
+    """A float64 result table from the recycling pool (``_TablePool``)."""
+    return _TABLES.empty(shape, fill)
+
+
+def release_tables() -> int:
+    """Free the idle result-table buffers of the pool; returns how many."""
+    return _TABLES.clear()
+
+
 _STAGING: dict = {}
 
 
@@ -719,28 +791,60 @@ class HotPathEngine:
         if small or (data.dtype == np.float32 and data.strides[1] == 4 and self._host_offsets(data) is None):
             res = self.process_batch(data, starts, want_nan_mask=want_nan_mask, staged_output=True)
             out = res[0] if want_nan_mask else res
-            o64 = np.empty(out.shape, np.float64)
+            o64 = table_empty(out.shape)
             parallel_cast(o64, out, None, self.lib)
             return (o64, res[1]) if want_nan_mask else o64
         dc = self._host_offsets(data)
-        T = data.shape[1]
         x = self._pinned.array("x", data.shape, np.float32)
-        out = self._pinned.array("out", (n, self.n_outputs), np.float32)
-        o64 = np.empty((n, self.n_outputs), np.float64)
-        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
-        ctr = self._pinned.array("ctr", (16,), np.int64)   # [0] samples in place, [8] rows landed (own cache lines)
-        ctr[:] = 0
-        W_in = self.W_in
-        # slices: what the library's first chunks read (nmx_engine_run.inc: a short first chunk -- 128 hops, or the fill
-        # phase of the burst history, ~320 --, then 512 hops at a time), each converted by the pool's threads in row blocks
-        hops = [h for h in (128, 320) if h < n] + list(range(320 + 512, n, 512)) + [n]
-        edges = sorted(set([0] + [int(min(T, starts[h - 1] + W_in)) for h in hops] + [T]))
-        failed: list = []
+        o64 = table_empty((n, self.n_outputs))
+        mask = self.run_pipelined(x, starts, o64, stage=lambda a, b: parallel_cast(x[:, a:b], data[:, a:b], dc, self.lib),
+                                  want_nan_mask=want_nan_mask)
+        return (o64, mask) if want_nan_mask else o64
 
-        def convert():   # (row blocks of a slice over the conversion pool)
+    def pipeline_counters(self) -> np.ndarray:
+        """The int64 counters of ``nmx_plan_set_pipeline`` in page-locked memory, zeroed: [0] samples of the staging array
+        in place (written by whoever stages), [8] feature rows landed (written by the library) -- own cache lines."""
+        ctr = self._pinned.array("ctr", (16,), np.int64)
+        ctr[:] = 0
+        return ctr
+
+    def pipeline_edges(self, starts: np.ndarray, T: int) -> list[int]:
+        """Sample counts at which to publish progress while staging a recording: what the library's chunks read
+        (nmx_engine_run.inc: a short first chunk -- 128 hops, or the fill phase of the burst history, ~320 --, then 512
+        hops at a time)."""
+        n = len(starts)
+        hops = [h for h in (128, 320) if h < n] + list(range(320 + 512, n, 512)) + [n]
+        return sorted(set([0] + [int(min(T, starts[h - 1] + self.W_in)) for h in hops] + [T]))
+
+    def run_pipelined(self, x: np.ndarray, starts: np.ndarray, table: np.ndarray, runs: np.ndarray | None = None,
+                      stage=None, ctr: np.ndarray | None = None, want_nan_mask: bool = False):
+        """One batch with staging and widening NEXT to the device work.  ``x`` float32 [C_in, T]: the (page-locked)
+        staging array the library copies from; it is filled either by ``stage(a, b)`` -- called here, on a thread of
+        this call, for consecutive sample ranges -- or by the caller, who then owns ``ctr`` (``pipeline_counters()``) and
+        publishes in ``ctr[0]`` how many samples of EVERY row are in place (a multi-device stream stages all its parts
+        from one thread).  The rows are widened as the chunks land into the float64 ``table``: columns
+        ``runs[k] = (first column in table, first column of the engine's row, length)``, None: the whole row from column
+        0.  -> the NaN mask (bool [n, C_in]) or None."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        n, T = len(starts), x.shape[1]
+        if not (_rows_ok(x, np.float32) and x.shape[0] == self.C_in and _rows_ok(table, np.float64) and table.shape[0] == n):
+            raise ValueError("run_pipelined: float32 staging rows and a float64 table with one row per window")
+        if runs is None:
+            runs = np.array([[0, 0, self.n_outputs]], dtype=np.int64)
+        runs = np.ascontiguousarray(runs, dtype=np.int64).reshape(-1, 3)
+        out = self._pinned.array("out", (n, self.n_outputs), np.float32)
+        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        own = ctr is None
+        if own:
+            ctr = self.pipeline_counters()
+        failed: list = []
+        lib = self.lib
+
+        def convert():
             try:
+                edges = self.pipeline_edges(starts, T)
                 for a, b in zip(edges[:-1], edges[1:]):
-                    parallel_cast(x[:, a:b], data[:, a:b], dc, self.lib)
+                    stage(a, b)
                     ctr[0] = b
             except BaseException as e:   # noqa: BLE001 -- reported by the caller's thread
                 failed.append(e)
@@ -752,7 +856,8 @@ class HotPathEngine:
                 while done < n and not failed:
                     d = int(ctr[8])
                     if d > done:
-                        parallel_cast(o64[done:d], out[done:d], None, self.lib)
+                        lib.check(lib.lib.nmx_host_widen_rows(table.ctypes.data, table.strides[0] // 8, out.ctypes.data,
+                                                              self.n_outputs, done, d, runs.ctypes.data, len(runs), 0))
                         done = d
                     else:
                         time.sleep(0.0001)
@@ -761,18 +866,23 @@ class HotPathEngine:
 
         import threading
 
-        lib = self.lib
         lib.check(lib.lib.nmx_plan_set_pipeline(self._plan, ctr.ctypes.data, ctr.ctypes.data + 64))
-        jobs = [threading.Thread(target=convert, daemon=True), threading.Thread(target=widen, daemon=True)]
+        jobs = [threading.Thread(target=widen, daemon=True)]
+        if stage is not None:
+            jobs.append(threading.Thread(target=convert, daemon=True))
+        elif own:
+            ctr[0] = T   # (nobody stages: the array is complete)
         for j in jobs:
             j.start()
         try:
             lib.check(lib.lib.nmx_process_batch(
-                self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
+                self._plan, x.ctypes.data, x.strides[0] // 4, T, starts.ctypes.data, n,
                 out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
         except BaseException:
-            ctr[0] = T   # (let the threads run out)
+            if own:
+                ctr[0] = T   # (let the threads run out)
             ctr[8] = n
+            failed.append(None)
             raise
         finally:
             lib.lib.nmx_plan_set_pipeline(self._plan, None, None)
@@ -780,7 +890,7 @@ class HotPathEngine:
                 j.join()
         if failed:
             raise failed[0]
-        return (o64, mask.astype(bool)) if want_nan_mask else o64
+        return mask.astype(bool) if want_nan_mask else None
 
     def process_batch_device(self, x_ptr: int, ldx: int, n_samples: int, starts: np.ndarray,
                              out_ptr: int, mask_ptr: int | None = None, stream: int | None = None) -> None:

@@ -19,10 +19,13 @@ The final gather of the small feature table to rank 0 is control plane (``gather
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import channels as chmod
 from .data_processor import DataProcessor, UserColumns, _LazyNanCols
+from .engine import table_empty
 from .generator import window_schedule
 from .settings import NMSettings
 
@@ -277,6 +280,8 @@ class MultiDeviceProcessor:
             self._user = UserColumns(self.settings, self.ch_names_used, self.sfreq_raw, self.keys,
                                      device=self.devices[0], lib=lib)
         self._user_chunk = 64
+        self.stage_threads = 0              # of libnmx's staging passes (0: its default)
+        self.pipeline_min = (64, 1 << 20)   # hops, samples: below, staging and widening are not worth their threads
 
     @property
     def engine(self):
@@ -325,13 +330,8 @@ class MultiDeviceProcessor:
         list(_pool().map(job, range(len(edges) - 1)))
         return out
 
-    def _merge_widen(self, outs) -> np.ndarray:
-        """The parts' float32 rows (engine order) -> the float64 table in the global column order, ONE pass
-        (nmx_host_widen_rows): widening each part on its own and gathering the joined table afterwards wrote the
-        82 MB of a 1024-hop table twice and read it once more.  The reference's keys run feature by feature, channel by
-        channel: a part's columns land in a few dozen contiguous runs."""
-        lib = self.parts[0].engine.lib
-        n, F = outs[0].shape[0], len(self.keys)
+    def _column_runs(self):
+        """Per part: (first column in the table, first column of the part's row, length) of every contiguous run."""
         if getattr(self, "_runs", None) is None:
             self._runs = []
             for cols in self._cols:
@@ -340,8 +340,18 @@ class MultiDeviceProcessor:
                 length = np.diff(np.concatenate([first, [len(cols)]]))
                 self._runs.append(np.ascontiguousarray(np.stack([cols[first], first, length], axis=1), dtype=np.int64)
                                   if len(cols) else np.zeros((0, 3), np.int64))
+        return self._runs
+
+    def _merge_widen(self, outs) -> np.ndarray:
+        """The parts' float32 rows (engine order) -> the float64 table in the global column order, ONE pass
+        (nmx_host_widen_rows): widening each part on its own and gathering the joined table afterwards wrote the
+        82 MB of a 1024-hop table twice and read it once more.  The reference's keys run feature by feature, channel by
+        channel: a part's columns land in a few dozen contiguous runs."""
+        lib = self.parts[0].engine.lib
+        n, F = outs[0].shape[0], len(self.keys)
+        self._column_runs()
         n_builtin = int(sum(len(c) for c in self._cols))
-        table = np.full((n, F), np.nan) if F != n_builtin else np.empty((n, F))
+        table = table_empty((n, F), np.nan if F != n_builtin else None)
         for o, runs in zip(outs, self._runs):
             o = o if (o.dtype == np.float32 and o.ndim == 2 and o.strides[1] == 4 and o.strides[0] % 4 == 0
                       and o.strides[0] > 0) else np.ascontiguousarray(o, dtype=np.float32)
@@ -380,11 +390,102 @@ class MultiDeviceProcessor:
             xs.append(x)
         return xs
 
+    def _stage_local_slice(self, data, f64, ld, a, b, xs, plan):
+        """Samples [a, b) of every part's staging array: its rows, and the hi / lo rows of its group sums -- the
+        recording is read once (nmx_host_stage_parts: rows out and group sums block by block)."""
+        lib = self.parts[0].engine.lib
+        dst, gptr, grows, sums, sum_ptrs = plan
+        lib.check(lib.lib.nmx_host_stage_parts(data.ctypes.data, f64, ld, data.shape[0], a, b, dst.ctypes.data, len(sums),
+                                               gptr.ctypes.data, grows.ctypes.data, sum_ptrs.ctypes.data, self.stage_threads))
+        hilo = [chmod.split_hi_lo(v[a:b]) for v in sums]
+        for ids, rows, x in zip(self._part_groups, self._rows_i32, xs):
+            nl = len(rows)
+            for q, gi in enumerate(ids):
+                x[nl + 2 * q:nl + 2 * q + 2, a:b] = hilo[gi]
+
+    def _process_pipelined(self, data, starts):
+        """The whole batch with the coordinator's passes NEXT to the device work (HotPathEngine.run_pipelined): one
+        thread stages the recording slice by slice for every part -- group sums and the part's rows with local input,
+        one shared float32 copy otherwise -- and publishes its progress to every plan; every part widens its rows into
+        its columns of the table as its chunks land."""
+        import threading
+
+        from .engine import parallel_cast
+
+        data = np.asarray(data)
+        if not (data.dtype in (np.float32, np.float64) and data.strides[1] == data.itemsize and data.strides[0] > 0
+                and data.strides[0] % data.itemsize == 0):
+            data = np.ascontiguousarray(data, dtype=np.float32 if data.dtype == np.float32 else np.float64)
+        engines = [p.engine for p in self.parts]
+        lib = engines[0].lib
+        n, F, T = len(starts), len(self.keys), data.shape[1]
+        f64, ld = int(data.dtype == np.float64), data.strides[0] // data.itemsize
+        runs = self._column_runs()
+        n_builtin = int(sum(len(c) for c in self._cols))
+        table = table_empty((n, F), np.nan if F != n_builtin else None)
+        if self.local_input:
+            if getattr(self, "_rows_i32", None) is None:
+                self._rows_i32 = [np.ascontiguousarray(p.local_rows, dtype=np.int32) for p in self.parts]
+                self._groups_i32 = [np.ascontiguousarray(g, dtype=np.int32) for g in self._groups]
+            xs = [e._pinned.array("x_local", (len(r) + 2 * len(ids), T), np.float32)
+                  for e, r, ids in zip(engines, self._rows_i32, self._part_groups)]
+
+            # where every source row goes (pointer to sample 0 of its destination row), the groups as CSR, their sums
+            dst = np.zeros(data.shape[0], dtype=np.uint64)
+            for rows, x in zip(self._rows_i32, xs):
+                dst[rows] = x.ctypes.data + np.arange(len(rows), dtype=np.uint64) * np.uint64(x.strides[0])
+            gptr = np.concatenate([[0], np.cumsum([len(g) for g in self._groups_i32])]).astype(np.int32)
+            grows = (np.concatenate(self._groups_i32) if self._groups_i32 else np.zeros(0)).astype(np.int32)
+            sums = [np.empty(T) for _ in self._groups_i32]
+            sum_ptrs = np.array([v.ctypes.data for v in sums], dtype=np.uint64)
+            plan = (dst, gptr, grows, sums, sum_ptrs)
+
+            def stage(a, b):
+                self._stage_local_slice(data, f64, ld, a, b, xs, plan)
+        else:
+            dcs = [e._host_offsets(data) for e in engines]   # (every plan decides from the same rows: the same constants)
+            x = engines[0]._pinned.array("x_shared", data.shape, np.float32)
+            xs = [x] * len(engines)
+
+            def stage(a, b):
+                parallel_cast(x[:, a:b], data[:, a:b], dcs[0], lib)
+        ctrs = [e.pipeline_counters() for e in engines]
+        failed: list = []
+
+        def stage_all():
+            try:
+                edges = engines[0].pipeline_edges(starts, T)
+                for a, b in zip(edges[:-1], edges[1:]):
+                    stage(a, b)
+                    for c in ctrs:
+                        c[0] = b
+            except BaseException as e:   # noqa: BLE001 -- reported below; the plans run out on what is there
+                failed.append(e)
+                for c in ctrs:
+                    c[0] = T
+
+        th = threading.Thread(target=stage_all, daemon=True)
+        th.start()
+        try:
+            masks = list(self._pool.map(
+                lambda k: engines[k].run_pipelined(xs[k], starts, table, runs[k], ctr=ctrs[k], want_nan_mask=True),
+                range(len(engines))))
+        finally:
+            th.join()
+        if failed:
+            raise failed[0]
+        mask = self._full_mask(masks, len(self.channels)) if self.local_input else masks[0]
+        return table, mask
+
     def _full_mask(self, masks, n_all: int) -> np.ndarray:
         """NaN mask over ALL input rows from every part's local rows (a group-sum row is never NaN)."""
         full = np.zeros((masks[0].shape[0], n_all), dtype=bool)
         for p, m in zip(self.parts, masks):
-            full[:, p.local_rows] |= m[:, :len(p.local_rows)]
+            r, nl = p.local_rows, len(p.local_rows)
+            if nl and list(r) == list(range(r[0], r[0] + nl)):
+                full[:, r[0]:r[0] + nl] |= m[:, :nl]
+            else:
+                full[:, r] |= m[:, :nl]
         return full
 
     def _run_parts(self, data, starts, tapped: bool, staged: bool = False):
@@ -424,9 +525,13 @@ class MultiDeviceProcessor:
         if self._user is None and all(p.feature_normalizer is None and (p.device_normalizer is None or p._norm_in_engine)
                                       for p in self.parts):
             # nothing between the engines' rows and the table but the widening and the NaN policy
-            got = self._run_parts(data, starts, False, staged=True)
-            table = self._merge_widen([o for o, _, _ in got])
-            mask = got[0][1]   # over ALL incoming rows, the same for every part
+            if (len(starts) >= self.pipeline_min[0] and np.size(data) >= self.pipeline_min[1]
+                    and os.environ.get("NMX_PIPELINE", "1") != "0"):
+                table, mask = self._process_pipelined(data, starts)
+            else:
+                got = self._run_parts(data, starts, False, staged=True)
+                table = self._merge_widen([o for o, _, _ in got])
+                mask = got[0][1]   # over ALL incoming rows, the same for every part
             if mask.any():     # every key that contains the name of a channel whose window held a NaN := NaN (:297-306)
                 if mask.shape[1] != len(self.ch_names_used):
                     raise IndexError("boolean index did not match: NaN handling needs every channel used")

@@ -94,6 +94,51 @@ def case_pipelined_f64_batch(lib):
         assert wmask.any()
 
 
+def case_multi_device_pipelined_batch(lib, devices=(0, 0, 0)):
+    """MultiDeviceProcessor's pipelined batch (one thread stages every part slice by slice -- group sums + rows, or one
+    shared cast --, every part widens into its columns of the table as its chunks land) == the same processor with the
+    passes in a row (NMX_PIPELINE=0), bit for bit: local and replicated input, float32 and float64 recordings, NaN policy,
+    the z-score normaliser inside the plans."""
+    import os
+
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.sharding import MultiDeviceProcessor
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.raw_hjorth = s.features.fft = s.features.return_raw = True
+    s.preprocessing = ["notch_filter", "re_referencing"]
+    C, T = 7, 33000
+    rng = np.random.default_rng(12)
+    data = rng.standard_normal((C, T)) * 30 + rng.uniform(-100, 100, (C, 1))
+    data[4, 20000:20005] = np.nan
+    starts = np.arange(0, T - 1000 + 1, 100)
+    channels = chmod.get_default_channels_from_data(data)
+    for local in (True, False):
+        for dtype in (np.float64, np.float32):
+            x = data.astype(dtype)
+            tables = []
+            for pipe in ("1", "0"):
+                dp = MultiDeviceProcessor(1000.0, s, channels, line_noise=50, devices=list(devices), local_input=local, lib=lib)
+                dp.pipeline_min = (1, 0)
+                assert dp.local_input == local
+                os.environ["NMX_PIPELINE"] = pipe
+                try:
+                    dp.process_batch(-3 * x + 1000, starts)   # (another recording first: the staging arrays hold ITS samples
+                    dp.reset()                                #  when the plans look at the first window of the next one)
+                    tables.append(dp.process_batch(x, starts))
+                    again = dp.process_batch(x[:, :5000], starts[:37])   # a second batch: state carried, counters re-armed
+                finally:
+                    del os.environ["NMX_PIPELINE"]
+                    dp.close()
+                tables.append(again)
+            assert tables[0].dtype == np.float64 and tables[0].shape == (len(starts), len(dp.keys))
+            assert np.isnan(tables[0]).any() and not np.isnan(tables[0]).all(axis=0).any()
+            np.testing.assert_array_equal(tables[0], tables[2])
+            np.testing.assert_array_equal(tables[1], tables[3])
+
+
 def case_sharpwave_reference_test_inputs(lib):
     """Impulse / sine / plateau inputs of the reference's tests/test_sharpwave.py."""
     from py_neuromodulation_amd.engine import HotPathEngine

@@ -182,6 +182,34 @@ def test_host_staging_helpers_equal_numpy():
                 ref += np.nan_to_num(src[r].astype(np.float32)).astype(np.float64)
             np.testing.assert_array_equal(s[t0:t1], ref[t0:t1])
             assert (s[:t0] == -1.0).all() and (s[t1:] == -1.0).all()
+        # rows out and group sums in one pass (nmx_host_stage_parts): two parts, a row nobody takes, two groups
+        for dtype in (np.float64, np.float32):
+            src = big.astype(dtype)[1:R + 1, 2:T + 2]
+            parts = [np.full((R, T), -5.0, np.float32), np.full((R, T), -5.0, np.float32)]
+            dst = np.zeros(R, np.uint64)
+            owner = {}
+            for j in range(R - 1):           # (the last row goes nowhere)
+                k = j % 2
+                owner[j] = (k, j // 2)
+                dst[j] = parts[k].ctypes.data + (j // 2) * parts[k].strides[0]
+            groups = [np.arange(0, R, 2, dtype=np.int32), np.arange(R, dtype=np.int32)[::-1].copy()]
+            gptr = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int32)
+            grows = np.concatenate(groups).astype(np.int32)
+            sums = [np.full(T, -1.0) for _ in groups]
+            sptr = np.array([v.ctypes.data for v in sums], np.uint64)
+            t0, t1 = 3, T - 2
+            lib.check(lib.lib.nmx_host_stage_parts(src.ctypes.data, int(dtype == np.float64), src.strides[0] // src.itemsize, R,
+                                                   t0, t1, dst.ctypes.data, 2, gptr.ctypes.data, grows.ctypes.data,
+                                                   sptr.ctypes.data, 0))
+            for j, (k, r) in owner.items():
+                np.testing.assert_array_equal(parts[k][r, t0:t1], src[j, t0:t1].astype(np.float32))
+                assert (parts[k][r, :t0] == -5.0).all() and (parts[k][r, t1:] == -5.0).all()
+            for g, v in zip(groups, sums):
+                ref = np.zeros(T)
+                for r in g:
+                    ref += np.nan_to_num(src[r].astype(np.float32)).astype(np.float64)
+                np.testing.assert_array_equal(v[t0:t1], ref[t0:t1])
+                assert (v[:t0] == -1.0).all() and (v[t1:] == -1.0).all()
         # widening into column runs
         f = rng.standard_normal((R, T)).astype(np.float32)
         f[0, 0] = np.nan

@@ -37,6 +37,10 @@ def test_pipelined_f64_batch_equals_plain_batch(gpu_lib):
     pc.case_pipelined_f64_batch(gpu_lib)
 
 
+def test_multi_device_pipelined_batch_equals_passes_in_a_row(gpu_lib):
+    pc.case_multi_device_pipelined_batch(gpu_lib)
+
+
 def test_sharpwave_reference_test_inputs(gpu_lib):
     pc.case_sharpwave_reference_test_inputs(gpu_lib)
 

@@ -42,6 +42,10 @@ def test_pipelined_f64_batch_equals_plain_batch(emu_lib):
     pc.case_pipelined_f64_batch(emu_lib)
 
 
+def test_multi_device_pipelined_batch_equals_passes_in_a_row(emu_lib):
+    pc.case_multi_device_pipelined_batch(emu_lib)
+
+
 def test_sharpwave_reference_test_inputs(emu_lib):
     pc.case_sharpwave_reference_test_inputs(emu_lib)
 
