@@ -251,26 +251,35 @@ extern "C" int nmx_wave_launch_timeosc_w1000(const NmxTimeOscArgs* A, int n_item
 extern "C" int nmx_wave_launch_timeosc_w510(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_wave_launch_timeosc_stft500(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
 extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
-static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
+extern "C" void nmx_wave_launch_timeosc_w1000_todo(const NmxTimeOscArgs* A, int n_items, hipStream_t s);
+// -> 1 when the kernel launched leaves flagged windows to be_launch_timeosc_redo (the matrix-pipe kernel's dirty tiles)
+static int be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();
   static int scan_ok = -1;
   if (scan_ok < 0) { const char* v = getenv("NMX_SCAN_KERNEL"); scan_ok = !(v && v[0] == '0'); }
   // no oscillatory feature: the register-resident scan (one wave per window, no LDS)
   if (scan_ok && !A.fft.enabled && !A.welch.enabled && !A.stft.enabled && A.W <= 1024 && A.W >= 3) {
     nmx_wave_launch_scan(&A, n_items, s);
-    return;
+    return 0;
   }
   // FFT band means of 1000-sample windows whose bins fit 32 rows: the spectrum on the matrix pipe (nmx_k_specmm.h)
   // (any batch size, one window included: a result must not depend on how the hops were batched)
-  if (A.smm_tab && nmx_specmm_launch(&A, n_items, s)) return;
+  if (A.smm_tab) {
+    const int r = nmx_specmm_launch(&A, n_items, s);
+    if (r) return r == 2;
+  }
   // default shape (W = 1000, band means): one wave per item, wave-level 500-point transforms
-  if (A.w500_tab && nmx_wave_launch_timeosc_w1000(&A, n_items, s)) return;
-  if (A.w500_tab && nmx_wave_launch_timeosc_stft500(&A, n_items, s)) return;
+  if (A.w500_tab && nmx_wave_launch_timeosc_w1000(&A, n_items, s)) return 0;
+  if (A.w500_tab && nmx_wave_launch_timeosc_stft500(&A, n_items, s)) return 0;
   // 510-sample FFT / STFT segments (17 ms at 30 kHz): one wave per item, in-place prime-factor transforms
-  if (A.w510_tab && nmx_wave_launch_timeosc_w510(&A, n_items, s)) return;
-  if (nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return; }
+  if (A.w510_tab && nmx_wave_launch_timeosc_w510(&A, n_items, s)) return 0;
+  if (nt == 128) { nmx_timeosc_fixed_launch128(&A, n_items, lds, s); return 0; }
   hipLaunchKernelGGL(nmx_kern_timeosc, dim3(n_items), dim3(nt), lds, s, A);
   nmxi_note_kernel("nmx_kern_timeosc");
+  return 0;
+}
+static void be_launch_timeosc_redo(const NmxTimeOscArgs& A, int n_items, be_stream_t s) {
+  nmx_wave_launch_timeosc_w1000_todo(&A, n_items, s);
 }
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int nt, size_t lds, be_stream_t s) {
   be_init_once();

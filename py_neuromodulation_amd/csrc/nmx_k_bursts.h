@@ -364,7 +364,10 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
 #define NMX_THRW_I 256
 // + K / 64 + 2 block counters (launcher)
 // NR = registers per lane holding a hop's new samples: 2 (overlap <= 128) or 4 (overlap <= 256: 2 kHz at 10 Hz)
-#define NMX_THRW_LDS_FLOATS_NR(NR) (2 * 256 * (NR) + 3 * ((NR) == 2 ? NMX_THR_P : 512) + NMX_THRW_I + ((NR) == 2 ? NMX_THRW_PF : 4) * 64 * (NR))
+#define NMX_THRW_PF_LL 8   // with the list in LDS: 8 hops ahead (4 KB less: THREE walks per CU, 1536 series in two rounds)
+#define NMX_THRW_PF_OF(NR, LL) ((NR) == 2 ? ((LL) ? NMX_THRW_PF_LL : NMX_THRW_PF) : 4)
+#define NMX_THRW_LDS_FLOATS_OF(NR, LL) (2 * 256 * (NR) + 3 * ((NR) == 2 ? NMX_THR_P : 512) + NMX_THRW_I + NMX_THRW_PF_OF(NR, LL) * 64 * (NR))
+#define NMX_THRW_LDS_FLOATS_NR(NR) NMX_THRW_LDS_FLOATS_OF(NR, false)
 #define NMX_THRW_LDS_FLOATS NMX_THRW_LDS_FLOATS_NR(2)
 
 // number of entries of the DESCENDING list l[0..n) that are > v
@@ -406,7 +409,7 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
   constexpr int TF = 256 * NR, TREFILL = 192 * NR;
   // NR = 4 (2 kHz hops, thousands of series): a shorter pending list and a shorter prefetch group bring the wave to
   // 20 KB of LDS -- eight walks per CU, one round for 2048 series instead of two
-  constexpr int TP = NR == 2 ? NMX_THR_P : 512, PF = NR == 2 ? NMX_THRW_PF : 4;
+  constexpr int TP = NR == 2 ? NMX_THR_P : 512, PF = NMX_THRW_PF_OF(NR, LL);
 #ifdef NMX_THRW_PROFILE
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
   int n_ins = 0, n_flush = 0;

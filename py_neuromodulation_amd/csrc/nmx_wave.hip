@@ -89,12 +89,13 @@ extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items,
   }
   const int nr = A->overlap <= 128 ? 2 : 4;
   const size_t base = (size_t)((nr == 2 ? NMX_THRW_LDS_FLOATS_NR(2) : NMX_THRW_LDS_FLOATS_NR(4)) + A->K / 64 + 4) * 4;
-  const size_t with_list = base + (size_t)A->K * 4;
+  const size_t with_list = (size_t)((nr == 2 ? NMX_THRW_LDS_FLOATS_OF(2, true) : NMX_THRW_LDS_FLOATS_OF(4, true)) + A->K / 64 + 4) * 4 +
+                           (size_t)A->K * 4;
   // The list in LDS pays while the stream is YOUNG: the ring has just filled, a quarter of every hop's samples still enters
   // the list and a flush is due every ~15 hops (a fresh 120 s stream: 25.4 -> 22.2 ms end to end).  After thousands of hops
   // the kept minimum has risen, flushes are rare, and 56 KB of LDS per walk only take occupancy from the throughput
   // kernels running next to it (the bench's steady state: 6.59 -> 6.87 ms per step) -- then the list stays in L2.
-  const bool ll = lds_list && with_list <= 80 * 1024 && windows_seen < 4096;   // (two walks per CU: 512 series in one round)
+  const bool ll = lds_list && with_list <= 80 * 1024 && windows_seen < 4096;   // (the default history: 52 KB, three walks per CU)
   const size_t lds = ll ? with_list : base;
   if (nr == 2) {
     if (ll) hipLaunchKernelGGL((nmx_kern_burst_thr_wave<2, true>), dim3(n_items), dim3(64), lds, s, *A);

@@ -377,16 +377,17 @@ class DataProcessor:
             logger.info("Last batch took: %.3f seconds to process", time() - start_time)
         return dict(zip(self.keys, row.tolist()))
 
-    def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
+    def process_batch(self, data: np.ndarray, starts: np.ndarray, spare_cols: int = 0) -> np.ndarray:
         """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
-        applied hop by hop because the normaliser is sequential)."""
+        applied hop by hop because the normaliser is sequential).  ``spare_cols``: the table MAY come back with that
+        many extra columns behind the features (HotPathEngine.process_batch_f64) -- the caller checks the shape."""
         if self._user is not None:
             out, mask, user = self._process_batch_user(data, starts)
             rows = self._with_user_columns(self._finish_rows(out, mask, self._norm_in_engine), user)
             return self._apply_nan_policy(rows, mask) if mask.any() else rows
         if self.feature_normalizer is None and (self.device_normalizer is None or self._norm_in_engine):
             # nothing left to do on the host but the NaN policy: conversions pipelined against the device
-            rows, mask = self.engine.process_batch_f64(data, starts, want_nan_mask=True)
+            rows, mask = self.engine.process_batch_f64(data, starts, want_nan_mask=True, spare_cols=spare_cols)
             return self._apply_nan_policy(rows, mask) if mask.any() else rows
         out, mask = self.engine.process_batch(data, starts, want_nan_mask=True, staged_output=True)
         return self.postprocess_batch(out, mask, normalised=self._norm_in_engine)

@@ -774,29 +774,31 @@ class HotPathEngine:
             out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
         return (out, mask.astype(bool)) if want_nan_mask else out
 
-    def process_batch_f64(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False):
+    def process_batch_f64(self, data: np.ndarray, starts: np.ndarray, want_nan_mask: bool = False, spare_cols: int = 0):
         """``process_batch`` returning the float64 table the reference's consumers expect, with BOTH conversions next to
         the device work instead of around it (nmx_plan_set_pipeline): a thread converts the recording to float32 slice
         by slice into the page-locked staging array and publishes how far it got -- the library enqueues a chunk's copy
         as soon as the samples it reads are there --, another widens the feature rows to float64 as the chunks land
         (their first touch of a fresh 75 MB table costs more than the arithmetic: it, too, hides under the kernels).
         (Measured round 4, 256 ch x 120 s: conversion 1.9 ms + batch 11.7 ms + widening and first touch 4 - 8 ms in a
-        row.)"""
+        row.)  ``spare_cols``: the table gets that many extra columns behind the features for the caller to fill (the
+        reference's frame carries "time" and the target channels behind them, stream/stream.py:319-343 -- written into the
+        table they need no column insert)."""
         data = np.asarray(data)
         starts = np.ascontiguousarray(starts, dtype=np.int64)
-        n = len(starts)
+        n, F = len(starts), self.n_outputs
         if data.ndim != 2 or data.shape[0] != self.C_in:
             raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
         small = data.size < (1 << 20) or n < 64 or os.environ.get("NMX_PIPELINE", "1") == "0"
         if small or (data.dtype == np.float32 and data.strides[1] == 4 and self._host_offsets(data) is None):
             res = self.process_batch(data, starts, want_nan_mask=want_nan_mask, staged_output=True)
             out = res[0] if want_nan_mask else res
-            o64 = table_empty(out.shape)
-            parallel_cast(o64, out, None, self.lib)
+            o64 = table_empty((n, F + spare_cols))
+            parallel_cast(o64[:, :F], out, None, self.lib)
             return (o64, res[1]) if want_nan_mask else o64
         dc = self._host_offsets(data)
         x = self._pinned.array("x", data.shape, np.float32)
-        o64 = table_empty((n, self.n_outputs))
+        o64 = table_empty((n, F + spare_cols))
         mask = self.run_pipelined(x, starts, o64, stage=lambda a, b: parallel_cast(x[:, a:b], data[:, a:b], dc, self.lib),
                                   want_nan_mask=want_nan_mask)
         return (o64, mask) if want_nan_mask else o64

@@ -403,7 +403,7 @@ class MultiDeviceProcessor:
             for q, gi in enumerate(ids):
                 x[nl + 2 * q:nl + 2 * q + 2, a:b] = hilo[gi]
 
-    def _process_pipelined(self, data, starts):
+    def _process_pipelined(self, data, starts, spare_cols: int = 0):
         """The whole batch with the coordinator's passes NEXT to the device work (HotPathEngine.run_pipelined): one
         thread stages the recording slice by slice for every part -- group sums and the part's rows with local input,
         one shared float32 copy otherwise -- and publishes its progress to every plan; every part widens its rows into
@@ -422,7 +422,7 @@ class MultiDeviceProcessor:
         f64, ld = int(data.dtype == np.float64), data.strides[0] // data.itemsize
         runs = self._column_runs()
         n_builtin = int(sum(len(c) for c in self._cols))
-        table = table_empty((n, F), np.nan if F != n_builtin else None)
+        table = table_empty((n, F + spare_cols), np.nan if F != n_builtin else None)
         if self.local_input:
             if getattr(self, "_rows_i32", None) is None:
                 self._rows_i32 = [np.ascontiguousarray(p.local_rows, dtype=np.int32) for p in self.parts]
@@ -520,14 +520,15 @@ class MultiDeviceProcessor:
         full = self._full_mask([m for _, m, _ in got], len(self.channels))
         return [(o, full, w) for o, _, w in got]
 
-    def process_batch(self, data: np.ndarray, starts: np.ndarray) -> np.ndarray:
+    def process_batch(self, data: np.ndarray, starts: np.ndarray, spare_cols: int = 0) -> np.ndarray:
+        """``spare_cols``: as DataProcessor.process_batch (extra columns behind the features, pipelined path only)."""
         starts = np.asarray(starts, dtype=np.int64)
         if self._user is None and all(p.feature_normalizer is None and (p.device_normalizer is None or p._norm_in_engine)
                                       for p in self.parts):
             # nothing between the engines' rows and the table but the widening and the NaN policy
             if (len(starts) >= self.pipeline_min[0] and np.size(data) >= self.pipeline_min[1]
                     and os.environ.get("NMX_PIPELINE", "1") != "0"):
-                table, mask = self._process_pipelined(data, starts)
+                table, mask = self._process_pipelined(data, starts, spare_cols)
             else:
                 got = self._run_parts(data, starts, False, staged=True)
                 table = self._merge_widen([o for o, _, _ in got])

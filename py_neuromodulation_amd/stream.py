@@ -64,12 +64,13 @@ class Stream:
 
         return json.dumps(self.settings.to_dict(), sort_keys=True, default=str) + self.channels.to_json()
 
-    def _processor_token(self):
+    def _processor_token(self, settings_token=None):
         """Everything a DataProcessor is built from: the settings / channel table AND the stream attributes the
         reference reads afresh on every run (stream/stream.py:233-242 builds a new DataProcessor per run)."""
         from . import user_features
 
-        return (self._settings_token(), repr(self.line_noise), repr(self.sfreq), bool(self._resample_new_rate),
+        return (settings_token if settings_token is not None else self._settings_token(), repr(self.line_noise),
+                repr(self.sfreq), bool(self._resample_new_rate),
                 int(self.device), tuple(self.devices or ()), id(self._lib),
                 tuple((k, id(v)) for k, v in user_features.items()))
 
@@ -131,10 +132,13 @@ class Stream:
             raise ValueError("No data passed to run function.")
         self.is_running = True
         st = self.settings
+        settings_token = self._settings_token()   # (serialises settings and channel table: once per run)
         starts, lens, times = window_schedule(data.shape[1], self.sfreq, st.sampling_rate_features_hz,
                                               st.segment_length_features_ms)
         rows = np.empty((len(starts), 0))
         keys: list[str] = []
+        tgt = self.channels[self.channels["target"] == 1]
+        n_targets = len(tgt)
         if len(starts):
             groups = [int(g) for g in np.unique(lens)]
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
@@ -143,14 +147,15 @@ class Stream:
             procs = {}
             for w in groups:
                 dp = self.data_processor
-                if (len(groups) == 1 and dp is not None and dp.engine.W_in == w and dp.settings_token == self._processor_token()):
+                if (len(groups) == 1 and dp is not None and dp.engine.W_in == w
+                        and dp.settings_token == self._processor_token(settings_token)):
                     dp.reset()
                     procs[w] = dp
                 else:
                     procs[w] = self._make_processor(w)
             self.data_processor = dp0 = procs[groups[0]]
             if len(groups) == 1:
-                rows = dp0.process_batch(data, starts)
+                rows = dp0.process_batch(data, starts, spare_cols=1 + n_targets)   # ("time" and the targets behind the features)
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
                 # cannot run inside the per-length engines: detached, it normalises the merged rows afterwards.
@@ -170,11 +175,17 @@ class Stream:
                     state = p.ragged_state()
                 rows = dp0.ragged_finish(runs)
             keys = list(dp0.keys)   # after the first hop: user-feature keys are known once calc_feature has run
-        df = pd.DataFrame(rows, columns=keys)
-        df["time"] = times
-        tgt = self.channels[self.channels["target"] == 1]
-        for idx, name in zip(tgt.index, tgt["name"].to_list()):
-            df[name] = [float(data[idx, s + n - 1]) for s, n in zip(starts, lens)]
+        last = starts + lens - 1   # the targets' column: the last sample of every window (stream/stream.py:319-329)
+        if len(keys) and rows.shape[1] == len(keys) + 1 + n_targets:   # the table came with room for them: one block, no inserts
+            rows[:, len(keys)] = times
+            for k, idx in enumerate(tgt.index):
+                rows[:, len(keys) + 1 + k] = np.asarray(data[idx])[last]
+            df = pd.DataFrame(rows, columns=keys + ["time"] + tgt["name"].to_list())
+        else:
+            df = pd.DataFrame(rows, columns=keys)
+            df["time"] = times
+            for idx, name in zip(tgt.index, tgt["name"].to_list()):
+                df[name] = np.asarray(data[idx], dtype=np.float64)[last]
         self.is_running = False
         # ---- output files, names and layouts of the reference (stream/stream.py:229,319-343,426-453)
         writer = None
@@ -187,13 +198,13 @@ class Stream:
             out = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
             out.mkdir(parents=True, exist_ok=True)
             df.to_csv(out / f"{experiment_name}_FEATURES.csv", index=False)
-        self._save_after_stream(out_dir, experiment_name)   # always, like the reference (stream/stream.py:338)
+        self._save_after_stream(out_dir, experiment_name, settings_token)   # always, like the reference (stream/stream.py:338)
         if writer is not None and delete_ind_batch_files_after_stream:
             writer.delete_ind_files()
         return df if return_df else {}
 
     # -- stream/stream.py:426-453, stream/data_processor.py:313-337 -----------------------------
-    def _save_after_stream(self, out_dir="", experiment_name: str = "sub") -> None:
+    def _save_after_stream(self, out_dir="", experiment_name: str = "sub", settings_token=None) -> None:
         from . import file_writer as fw
 
         # stream/data_processor.py:313-337: original_fs = the rate passed in, final_fs = sfreq // 1
@@ -201,7 +212,7 @@ class Stream:
                    "sfreq": float(self.settings.sampling_rate_features_hz), "sess_right": self.sess_right}
         fw.save_sidecar(sidecar, out_dir, experiment_name)
         # the serialised settings / channel table of the previous run are re-used while both are unchanged
-        token = self._settings_token()
+        token = settings_token if settings_token is not None else self._settings_token()
         cache = getattr(self, "_after_text", None)
         if cache is None or cache[0] != token:
             cache = (token, self.settings.to_yaml_text(), fw.channels_csv_text(self.channels))

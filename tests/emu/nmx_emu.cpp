@@ -68,10 +68,12 @@ static void be_stage(int) {}
 static void be_stage_reset() {}
 static std::string be_stage_kernels(int) { return "host emulator (tests only)"; }
 
-static void be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int, size_t lds, be_stream_t) {
+static int be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_time_osc_item(A, it / A.n_channels, it % A.n_channels, sm.data());
+  return 0;
 }
+static void be_launch_timeosc_redo(const NmxTimeOscArgs&, int, be_stream_t) {}
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_bank_item(A, it / A.n_channels, it % A.n_channels, sm.data());
