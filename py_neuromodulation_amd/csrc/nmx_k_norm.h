@@ -192,6 +192,31 @@ NMX_DEV double nmx_norm_sklearn(const NmxNormArgs& A, int j, int n, double x) {
   return 0.5 * (r1 - r2);
 }
 
+// 1 / a and 1 / sqrt(a) in float64 from the hardware seeds (v_rcp_f64 / v_rsq_f64) + two Newton steps: <= 1 ulp, a dozen
+// instructions -- the IEEE division / square root sequences are ~30 quarter-rate instructions each, and the mean / z-score
+// walk is issue bound on them (one wave per 64 columns: 156 waves on 1024 SIMDs).  The outputs are rounded to float32.
+NMX_DEV double nmx_rcp_f64(double a) {
+#ifdef NMX_HOST_EMU
+  return 1.0 / a;
+#else
+  const double r0 = __builtin_amdgcn_rcp(a);
+  if (!(fabs(r0) < INFINITY) || r0 == 0.0) return r0;   // a == 0, infinite or NaN: the seed is the answer
+  double r = fma(fma(-a, r0, 1.0), r0, r0);
+  r = fma(fma(-a, r, 1.0), r, r);
+  return r;
+#endif
+}
+NMX_DEV double nmx_rsq_f64(double a) {   // a > 0, finite
+#ifdef NMX_HOST_EMU
+  return 1.0 / sqrt(a);
+#else
+  double y = __builtin_amdgcn_rsq(a);
+  y = y * fma(-0.5 * a * y, y, 1.5);
+  y = y * fma(-0.5 * a * y, y, 1.5);
+  return y;
+#endif
+}
+
 #define NMX_NORM_PF 8
 NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
   if (j >= A.n_cols) return;
@@ -228,18 +253,25 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     // root: ~150 dependent instructions) only read that hop's sums.  Per block of NMX_NORM_PF hops the sums are advanced
     // first (snapshots in registers), then the block's outputs are formed side by side: one thread per column keeps eight
     // division chains in flight instead of one (the kernel is 156 waves of pure latency; measured in profiles/README.md, round 5).
+    // (the walk itself holds no division and no 64-bit modulo: the ring slot advances with the hops -- the value a hop trims,
+    // row q - (cap - 1), sits in the slot the NEXT hop writes --, and the trim's tests are multiplied through by the count)
+    int slot = (int)(A.seq0 % cap);
     for (int r0 = 0; r0 < A.n_rows; r0 += NMX_NORM_PF) {
       float xb[NMX_NORM_PF], ob[NMX_NORM_PF];
       double S1[NMX_NORM_PF], S2[NMX_NORM_PF], VO[NMX_NORM_PF];   // sums after the hop's value entered; two-pass variance or < 0
       int CN[NMX_NORM_PF], NI[NMX_NORM_PF];
+      {
+        int so = slot;
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
-      for (int i = 0; i < NMX_NORM_PF; ++i) {
-        const int rr = r0 + i < A.n_rows ? r0 + i : A.n_rows - 1;
-        xb[i] = A.rows[(long long)rr * A.ld + j];
-        const long long qo = A.seq0 + rr - (cap - 1);
-        ob[i] = (pf_o && qo >= 0) ? A.ring[(qo % cap) * A.n_cols + j] : 0.f;
+        for (int i = 0; i < NMX_NORM_PF; ++i) {
+          const int rr = r0 + i < A.n_rows ? r0 + i : A.n_rows - 1;
+          xb[i] = A.rows[(long long)rr * A.ld + j];
+          so = so + 1 == cap ? 0 : so + 1;   // slot of hop r0 + i + 1 == slot of row (r0 + i) - (cap - 1)
+          const long long qo = A.seq0 + rr - (cap - 1);
+          ob[i] = (pf_o && qo >= 0) ? A.ring[(long long)so * A.n_cols + j] : 0.f;
+        }
       }
 #ifndef NMX_HOST_EMU
 #pragma unroll
@@ -249,14 +281,15 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         if (r0 + bi >= A.n_rows) continue;
         const long long q = A.seq0 + r0 + bi;
         const float x = xb[bi];
+        const int next = slot + 1 == cap ? 0 : slot + 1;
         if (len == cap) {  // cannot happen with the trim below; kept for safety
-          const float o = A.ring[((q - cap) % cap) * A.n_cols + j];
+          const float o = A.ring[(long long)slot * A.n_cols + j];
           if (o == o) {
             if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
           }
           --len;
         }
-        A.ring[(q % cap) * A.n_cols + j] = x;
+        A.ring[(long long)slot * A.n_cols + j] = x;
         if (nmx_norm_finite(x)) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
         else if (x == x) ++ninf;
         ++len;
@@ -274,24 +307,27 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         }
         // history keeps its last N - 1 rows (normalization.py:107)
         if (len > cap - 1) {
-          const float o = pf_o ? ob[bi] : A.ring[((q - (cap - 1)) % cap) * A.n_cols + j];
+          const float o = pf_o ? ob[bi] : A.ring[(long long)next * A.n_cols + j];
           if (o == o) {
             if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
           }
           --len;
           // (a value far larger than what stays behind leaves the sums with ITS rounding: rebuild them -- see the general
-          // walk below for the measure)
-          const double spread = cnt > 0 ? s2 - s1 * s1 / (double)cnt : 0.0;
-          const double mabs = cnt > 0 ? fabs(s1) / (double)cnt : 0.0, oabs = fabs((double)o);
-          if (nmx_norm_finite(o) && (!(oabs * oabs <= 1e4 * s2) || !(oabs * (oabs + 2.0 * mabs) <= 1e5 * spread))) {
-            s1 = 0.0; s2 = 0.0; cnt = 0; ninf = 0;
-            for (long long t = q - len + 1; t <= q; ++t) {
-              const float h = A.ring[(t % cap) * A.n_cols + j];
-              if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
-              else if (h == h) ++ninf;
+          // walk below for the measure: o^2 <= 1e4 s2 and |o| (|o| + 2 |mean|) <= 1e5 (s2 - s1^2 / cnt), times cnt)
+          if (nmx_norm_finite(o)) {
+            const double oabs = fabs((double)o), c = (double)cnt;
+            const bool keep = cnt > 0 && oabs * oabs <= 1e4 * s2 && oabs * (oabs * c + 2.0 * fabs(s1)) <= 1e5 * (s2 * c - s1 * s1);
+            if (!keep) {
+              s1 = 0.0; s2 = 0.0; cnt = 0; ninf = 0;
+              for (long long t = q - len + 1; t <= q; ++t) {
+                const float h = A.ring[(t % cap) * A.n_cols + j];
+                if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+                else if (h == h) ++ninf;
+              }
             }
           }
         }
+        slot = next;
       }
 #ifndef NMX_HOST_EMU
 #pragma unroll
@@ -305,14 +341,18 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         if (CN[bi] + NI[bi] == 0 || NI[bi] > 0) {
           out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
         } else {
-          const double mean = S1[bi] / (double)CN[bi];
+          // sums / count as CORRECTLY rounded quotients (seed product + one residual step, the tail of the IEEE division
+          // sequence): a constant column must give mean == x and variance == 0 exactly, as numpy.mean / numpy.std do
+          const double c = (double)CN[bi], rc = nmx_rcp_f64(c);
+          double mean = S1[bi] * rc;
+          mean = fma(fma(-mean, c, S1[bi]), rc, mean);
           if (A.method == NMX_NORM_MEAN) {
-            out = (x - mean) / mean;
+            out = (x - mean) * nmx_rcp_f64(mean);
           } else {
-            const double var = VO[bi] >= 0.0 ? VO[bi] : S2[bi] / (double)CN[bi] - mean * mean;
-            double sd = var > 0.0 ? sqrt(var) : 0.0;
-            if (sd == 0.0) sd = 1.0;
-            out = (x - mean) / sd;
+            double ex2 = S2[bi] * rc;
+            ex2 = fma(fma(-ex2, c, S2[bi]), rc, ex2);
+            const double var = VO[bi] >= 0.0 ? VO[bi] : ex2 - mean * mean;
+            out = (x - mean) * (var > 0.0 ? nmx_rsq_f64(var) : 1.0);   // (std 0 -> 1, normalization.py:160-164)
           }
         }
         if (A.clip > 0.f) {  // ndarray.clip: NaN stays NaN
