@@ -46,6 +46,15 @@ def main():
         out = eng.process_window(w64)
         d = dict(zip(eng.keys, out.tolist()))
         lat.append(time.perf_counter() - t1)
+    # the same batch as the float64 table a stream returns (conversion, copies, kernels and widening pipelined:
+    # HotPathEngine.process_batch_f64) -- what the multi-device numbers below compare with
+    f64_ms = {}
+    for name, xx in (("float32_recording", x), ("float64_recording", x.astype(np.float64))):
+        eng.process_batch_f64(xx, starts)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.process_batch_f64(xx, starts)
+        f64_ms[name] = (time.perf_counter() - t0) / reps * 1e3
     # single process, several plans (Stream(devices=[...])): what each device is handed -- local input (its rows + hi / lo
     # rows per group sum) against the whole recording
     from py_neuromodulation_amd import _lib
@@ -60,13 +69,13 @@ def main():
         dp = MultiDeviceProcessor(1000.0, s, channels, line_noise=50, devices=devices, window=W, local_input=local)
         dp.process_batch(x, starts)
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(reps):
             dp.process_batch(x, starts)
         md["local_input" if dp.local_input else "replicated_input"] = {
             "devices": devices, "h2d_rows_per_device": dp.h2d_rows, "h2d_MB_per_device": [r * T * 4 / 1e6 for r in dp.h2d_rows],
-            "ms_per_1024_hops": (time.perf_counter() - t0) / 3 * 1e3}
+            "ms_per_1024_hops": (time.perf_counter() - t0) / reps * 1e3}
         dp.close()
-    print(json.dumps({"multi_device_stream": md, "pcie_inclusive_windows_per_s": n / dt, "ms_per_1024_hops": dt * 1e3,
+    print(json.dumps({"multi_device_stream": md, "one_plan_float64_table_ms_per_1024_hops": f64_ms, "pcie_inclusive_windows_per_s": n / dt, "ms_per_1024_hops": dt * 1e3,
                       "pageable_buffers_windows_per_s": n / dt_pageable, "pageable_ms_per_1024_hops": dt_pageable * 1e3,
                       "h2d_MB": x.nbytes / 1e6, "d2h_MB": n * eng.n_outputs * 4 / 1e6,
                       "one_window_256ch_latency_ms_median": float(np.median(lat)) * 1e3,
