@@ -224,3 +224,51 @@ def test_host_staging_helpers_equal_numpy():
         parallel_cast(o64, f, None, lib)
         np.testing.assert_array_equal(o64, f.astype(np.float64))
     assert lib.lib.nmx_host_widen_rows(None, 0, None, 0, 0, 0, None, 0, 0) != 0   # argument validation, no crash
+
+
+def test_host_staging_helpers_from_several_threads_and_after_fork():
+    """The helpers' worker pool takes calls from several host threads at once (a multi-device stream stages on one thread
+    and widens on one per plan), and a forked child gets workers of its own."""
+    import os
+    import threading
+
+    import numpy as np
+
+    from py_neuromodulation_amd import _lib
+    from py_neuromodulation_amd.engine import parallel_cast
+
+    lib = _lib.NmxLibrary()
+    rng = np.random.default_rng(9)
+    srcs = [rng.standard_normal((40 + k, 9000)) for k in range(4)]
+    bad: list = []
+
+    def job(k):
+        try:
+            for _ in range(40):
+                dst = np.empty(srcs[k].shape, np.float32)
+                parallel_cast(dst, srcs[k], None, lib)
+                if not np.array_equal(dst, srcs[k].astype(np.float32)):
+                    bad.append(k)
+                o = np.empty(dst.shape)
+                parallel_cast(o, dst, None, lib)
+                if not np.array_equal(o, dst.astype(np.float64)):
+                    bad.append(-k - 1)
+        except BaseException as e:   # noqa: BLE001
+            bad.append(repr(e))
+
+    th = [threading.Thread(target=job, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad
+    pid = os.fork()
+    if pid == 0:   # the child: the parent's workers do not exist here
+        try:
+            dst = np.empty(srcs[0].shape, np.float32)
+            parallel_cast(dst, srcs[0], None, lib)
+            os._exit(0 if np.array_equal(dst, srcs[0].astype(np.float32)) else 3)
+        except BaseException:   # noqa: BLE001
+            os._exit(4)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
