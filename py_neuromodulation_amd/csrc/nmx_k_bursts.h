@@ -370,6 +370,15 @@ NMX_DEV void nmx_burst_thr_item(const NmxBurstThrArgs& A, int c, int bi, float* 
 #define NMX_THRW_LDS_FLOATS_NR(NR) NMX_THRW_LDS_FLOATS_OF(NR, false)
 #define NMX_THRW_LDS_FLOATS NMX_THRW_LDS_FLOATS_NR(2)
 
+// number of entries of the DESCENDING list l[0..n) that are >= v
+NMX_DEV int nmx_count_ge_lds(const float* l, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (l[mid] >= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 // number of entries of the DESCENDING list l[0..n) that are > v
 NMX_DEV int nmx_count_gt_lds(const float* l, int n, float v) {
   int lo = 0, hi = n;
@@ -645,7 +654,20 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
           for (int b = lane; b < nblk; b += 64) cb[b] = nmx_count_gt_lds(ps, nP, L[64 * b]);
           if (lane == 0) cb[nblk] = nP;
           NMX_WAVE_FENCE();
-          for (int j = lane; j < cb[0]; j += 64) ins[j] = 0;
+          if (LL) {
+            // list in LDS: every pending sample finds its place by a binary search of its own while the list is still
+            // whole (13 dependent LDS reads for 64 samples at a time), and below every list entry counts the pending
+            // samples above it by a search between its block's two counters (2 - 3 steps) -- the walk over a block's
+            // pending samples one by one (a broadcast read, a compare and a ballot each) was ~390 cycles per pending
+            // sample: two thirds of a young stream's flush
+            for (int j0 = 0; j0 < nP; j0 += 64) {
+              const int j = j0 + lane;
+              if (j < nP) ins[j] = nmx_count_ge_lds(L, Lm, ps[j]);
+            }
+            NMX_WAVE_FENCE();
+          } else {
+            for (int j = lane; j < cb[0]; j += 64) ins[j] = 0;
+          }
           // NB blocks per step, and the loads of the NEXT step are issued before this step's entries are
           // placed (they lie at lower addresses than anything stored so far)
           constexpr int NB = 8;
@@ -671,6 +693,18 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
               const int i = 64 * b + lane;
               const bool ok = i < Lm;
               const int c_lo = cb[b], c_hi = cb[b + 1];
+              if (LL) {
+                // pending samples > v[q]: all of [0, c_lo), none of [c_hi, nP).  (The eight blocks' searches in lockstep,
+                // eight LDS reads in flight per step, were measured and are slower: most ranges are empty or one
+                // entry wide, the lockstep form pays the widest one eight times.)
+                int lo2 = c_lo, hi2 = c_hi;
+                while (lo2 < hi2) {
+                  const int mid = (lo2 + hi2) >> 1;
+                  if (ps[mid] > v[q]) lo2 = mid + 1; else hi2 = mid;
+                }
+                if (ok && lo2) L[i + lo2] = v[q];
+                continue;
+              }
               int cnt = c_lo;
               for (int j = c_lo; j < c_hi; ++j) {
                 const float pj = ps[j];
