@@ -137,8 +137,22 @@ class Stream:
                                               st.segment_length_features_ms)
         rows = np.empty((len(starts), 0))
         keys: list[str] = []
-        tgt = self.channels[self.channels["target"] == 1]
-        n_targets = len(tgt)
+        tgt_rows = np.flatnonzero(self.channels["target"].to_numpy() == 1)   # (rows of `data`, in table order)
+        tgt_names = [str(v) for v in self.channels["name"].to_numpy()[tgt_rows]]
+        n_targets = len(tgt_rows)
+        # the side-car files do not depend on the features (stream/stream.py:338 writes them after the loop): written on a
+        # thread of their own while the device works
+        import threading
+
+        after_err: list = []
+
+        def write_after():
+            try:
+                self._save_after_stream(out_dir, experiment_name, settings_token)
+            except BaseException as e:   # noqa: BLE001 -- re-raised by run()
+                after_err.append(e)
+
+        after = None
         if len(starts):
             groups = [int(g) for g in np.unique(lens)]
             # a FRESH processing state per run, like the reference's new DataProcessor (:233-242), one
@@ -155,7 +169,13 @@ class Stream:
                     procs[w] = self._make_processor(w)
             self.data_processor = dp0 = procs[groups[0]]
             if len(groups) == 1:
-                rows = dp0.process_batch(data, starts, spare_cols=1 + n_targets)   # ("time" and the targets behind the features)
+                after = threading.Thread(target=write_after, daemon=True)
+                after.start()
+                try:
+                    rows = dp0.process_batch(data, starts, spare_cols=1 + n_targets)   # ("time" and the targets behind the features)
+                except BaseException:
+                    after.join()
+                    raise
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
                 # cannot run inside the per-length engines: detached, it normalises the merged rows afterwards.
@@ -178,13 +198,13 @@ class Stream:
         last = starts + lens - 1   # the targets' column: the last sample of every window (stream/stream.py:319-329)
         if len(keys) and rows.shape[1] == len(keys) + 1 + n_targets:   # the table came with room for them: one block, no inserts
             rows[:, len(keys)] = times
-            for k, idx in enumerate(tgt.index):
+            for k, idx in enumerate(tgt_rows):
                 rows[:, len(keys) + 1 + k] = np.asarray(data[idx])[last]
-            df = pd.DataFrame(rows, columns=keys + ["time"] + tgt["name"].to_list())
+            df = pd.DataFrame(rows, columns=keys + ["time"] + tgt_names)
         else:
             df = pd.DataFrame(rows, columns=keys)
             df["time"] = times
-            for idx, name in zip(tgt.index, tgt["name"].to_list()):
+            for idx, name in zip(tgt_rows, tgt_names):
                 df[name] = np.asarray(data[idx], dtype=np.float64)[last]
         self.is_running = False
         # ---- output files, names and layouts of the reference (stream/stream.py:229,319-343,426-453)
@@ -198,7 +218,12 @@ class Stream:
             out = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
             out.mkdir(parents=True, exist_ok=True)
             df.to_csv(out / f"{experiment_name}_FEATURES.csv", index=False)
-        self._save_after_stream(out_dir, experiment_name, settings_token)   # always, like the reference (stream/stream.py:338)
+        if after is not None:
+            after.join()
+            if after_err:
+                raise after_err[0]
+        else:
+            self._save_after_stream(out_dir, experiment_name, settings_token)   # always, like the reference (stream/stream.py:338)
         if writer is not None and delete_ind_batch_files_after_stream:
             writer.delete_ind_files()
         return df if return_df else {}
