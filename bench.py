@@ -426,6 +426,8 @@ def main() -> None:
     ap.add_argument("--cpu-windows", type=int, default=48, help="hops timed for cpu_baseline (0 = skip; ~0.5 s per hop on one core)")
     ap.add_argument("--cpu-procs", type=int, default=32, help="worker processes of cpu_baseline_allcores (0 = skip)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start_ms measurement")
+    ap.add_argument("--no-normalisation", action="store_true",
+                    help="skip the value_with_normalisation leg (kernel traces: its 256-hop chunks would mix with the headline's 1024-hop launches)")
     ap.add_argument("--no-mode-a", action="store_true", help="skip the roofline_modeA measurement (time / oscillatory kernel from HBM)")
     ap.add_argument("--no-preproc", action="store_true", help="skip notch + re-referencing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -533,7 +535,7 @@ def main() -> None:
     # the reference's default post-processing (z-score over the last 30 s of feature rows, default_settings.yaml:69-78)
     # inside the plan's launch sequence: the same K steps once more, reported next to `value`
     norm_dt = None
-    if world == 1:
+    if world == 1 and not args.no_normalisation:
         from py_neuromodulation_amd.processing import DeviceFeatureNormalizer
 
         sn = make_settings()

@@ -20,10 +20,10 @@ if [[ $STEPS == *all* || $STEPS == *bench* ]]; then
 fi
 if [[ $STEPS == *all* || $STEPS == *prof* ]]; then
   rm -rf $O/prof_$TAG $O/pmc_fetch_$TAG $O/pmc_write_$TAG
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o p -- python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start > $O/${TAG}_prof.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o p -- python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start --no-normalisation > $O/${TAG}_prof.log 2>&1
   python tools/rocpd_summary.py $(ls $O/prof_$TAG/*.db | head -1) $O/${TAG}_kernel_stats.csv | head -24
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$TAG -o p -- python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-cold-start > $O/${TAG}_pmc_fetch.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$TAG -o p -- python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-cold-start > $O/${TAG}_pmc_write.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$TAG -o p -- python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-cold-start --no-normalisation > $O/${TAG}_pmc_fetch.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$TAG -o p -- python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-cold-start --no-normalisation > $O/${TAG}_pmc_write.log 2>&1
   python tools/hbm_traffic.py $(ls $O/pmc_fetch_$TAG/*.db | head -1) $(ls $O/pmc_write_$TAG/*.db | head -1) $O/${TAG}_hbm_traffic.json
 fi
 if [[ $STEPS == *configs* ]]; then
