@@ -239,11 +239,13 @@ def roofline_mode_a(torch, dev, dev_index, channels=256, windows=4096, steps=5):
     stream = torch.cuda.current_stream(dev).cuda_stream
     ms = []
     for i in range(steps + 2):
-        # two launches back to back, the second one timed: an event recorded on an IDLE stream is stamped before the host
-        # has built the kernel's dispatch packet, and that host latency (~0.1 ms) is not launch duration (the rocprofv3
-        # trace of the same kernel, profiles/r03_scan_modeA_kernel_stats.csv, is the cross-check)
-        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
-        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
+        # four launches back to back, the last one timed: an event recorded on an IDLE stream is stamped before the host
+        # has built the kernel's dispatch packet (~0.1 ms that is not launch duration), and the first launches behind a
+        # host synchronisation run before the clocks have settled (tools/bench_scan.py --burst 2 / 4 / 8 / 16 on one
+        # lease: 1.038 / 0.977 / 0.998 / 0.993 ms) -- the headline loop, too, is launches back to back.  The rocprofv3
+        # trace of the same command (profiles/r05_kernel_stats.csv) holds every launch, the first of each group included.
+        for _ in range(4):
+            eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
         torch.cuda.synchronize(dev)
         if i >= 2:
             ms.append(eng.timing_ms(2))

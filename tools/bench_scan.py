@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--windows", type=int, default=4096)
     ap.add_argument("--features", default="fft,raw_hjorth,linelength")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--burst", type=int, default=4, help="launches back to back per timed sample (the last one is timed)")
     args = ap.parse_args()
     import os
 
@@ -42,11 +43,11 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     ms = []
     for i in range(args.steps + 2):
-        # two launches back to back, the second one timed: its start event is then reached while the GPU still works on
+        # --burst launches back to back, the last one timed: its start event is then reached while the GPU still works on
         # the first -- an event recorded on an IDLE stream is stamped before the host has even built the kernel's
         # dispatch packet, and that host latency (~0.1 ms) is not kernel time
-        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
-        eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
+        for _ in range(args.burst):
+            eng.process_batch_device(x.data_ptr(), T, T, starts, out.data_ptr(), None, stream)
         torch.cuda.synchronize(dev)
         if i >= 2:
             ms.append(eng.timing_ms(2))   # HIP events around the single nmx_kern_timeosc launch
