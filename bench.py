@@ -203,7 +203,10 @@ def measured_traffic(kernel: str):
         return None, None
     try:
         doc = json.loads(tfiles[-1].read_text())
-        hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == kernel.replace("void ", "")]
+        want = kernel.replace("void ", "")
+        hit = [v for k, v in doc.get("kernels", {}).items() if k.replace("void ", "") == want]
+        if not hit:   # the engine lists "name<NB>", the trace the full instantiation "name<NB, true, false>"
+            hit = [v for k, v in doc.get("kernels", {}).items() if "<" in want and k.replace("void ", "").startswith(want.rstrip(">") + ",")]
         if hit:   # only reported for the kernel that ran now
             return hit[0]["hbm_bytes_per_launch"], doc.get("measured_at_commit")
     except Exception:
