@@ -84,7 +84,6 @@ extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items,
   static unsigned long long seen = 0;
   if (nmx_first_on_device(seen)) {
     (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)nmx_kern_burst_thr_wave<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int nr = A->overlap <= 128 ? 2 : 4;
@@ -95,16 +94,19 @@ extern "C" void nmx_wave_launch_burst_thr(const NmxBurstThrArgs* A, int n_items,
   // the list and a flush is due every ~15 hops (a fresh 120 s stream: 25.4 -> 22.2 ms end to end).  After thousands of hops
   // the kept minimum has risen, flushes are rare, and 56 KB of LDS per walk only take occupancy from the throughput
   // kernels running next to it (the bench's steady state: 6.59 -> 6.87 ms per step) -- then the list stays in L2.
-  const bool ll = lds_list && with_list <= 80 * 1024 && windows_seen < 4096;   // (the default history: 52 KB, three walks per CU)
+  // ... only while the walks still fit the chip in two rounds (the default history: 52 KB, three walks per CU, 1536 series
+  // in two rounds), and only for hops of <= 128 samples: config 3 (2 kHz, 200 samples per hop, the four-register walk with
+  // its 512-entry pending list) measured 1.46 -> 2.2 ms per 256 hops with its list in LDS
+  const long long per_round = 256LL * (long long)((160 * 1024) / with_list);
+  const bool ll = lds_list && nr == 2 && with_list <= 80 * 1024 && windows_seen < 4096 && (long long)n_items <= 2 * per_round;
   const size_t lds = ll ? with_list : base;
   if (nr == 2) {
     if (ll) hipLaunchKernelGGL((nmx_kern_burst_thr_wave<2, true>), dim3(n_items), dim3(64), lds, s, *A);
     else hipLaunchKernelGGL((nmx_kern_burst_thr_wave<2, false>), dim3(n_items), dim3(64), lds, s, *A);
     nmxi_note_kernel(ll ? "nmx_kern_burst_thr_wave<2, true>" : "nmx_kern_burst_thr_wave<2, false>");
   } else {
-    if (ll) hipLaunchKernelGGL((nmx_kern_burst_thr_wave<4, true>), dim3(n_items), dim3(64), lds, s, *A);
-    else hipLaunchKernelGGL((nmx_kern_burst_thr_wave<4, false>), dim3(n_items), dim3(64), lds, s, *A);
-    nmxi_note_kernel(ll ? "nmx_kern_burst_thr_wave<4, true>" : "nmx_kern_burst_thr_wave<4, false>");
+    hipLaunchKernelGGL((nmx_kern_burst_thr_wave<4, false>), dim3(n_items), dim3(64), lds, s, *A);
+    nmxi_note_kernel("nmx_kern_burst_thr_wave<4, false>");
   }
 }
 
