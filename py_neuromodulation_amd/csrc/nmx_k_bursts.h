@@ -406,6 +406,41 @@ static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long win
 #else
 #define NMX_TP(i)
 #endif
+// Bitonic sort of 64 R values held R per lane (element e = lane + 64 r), DESCENDING in e.  Every loop is compile time:
+// a partner at distance >= 64 is another register of the same lane (a max / min pair, no predicate), a nearer one is the
+// same register of lane ^ j (one cross-lane read); the direction of a step is a lane bit below 64 and a compile-time
+// register bit above.  256 values: 36 steps, 33 of them with a cross-lane read -- ~4 k cycles where ranking by counting
+// (every value against every other) took 45 k per flush.
+template <int R>
+NMX_DEV void nmx_bitonic_desc(float (&v)[R], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r & jr) continue;
+          const bool up = ((64 * r) & k) == 0;   // (k >= 128 here: a register bit)
+          const float a = v[r], b = v[r | jr];
+          const float hi = fmaxf(a, b), lo = fminf(a, b);
+          v[r] = up ? hi : lo;
+          v[r | jr] = up ? lo : hi;
+        }
+      } else {
+        const bool lower = (lane & j) == 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool up = k < 64 ? (lane & k) == 0 : ((64 * r) & k) == 0;
+          const float a = v[r], b = __shfl_xor(a, j, 64);
+          v[r] = (lower == up) ? fmaxf(a, b) : fminf(a, b);
+        }
+      }
+    }
+  }
+}
+
 // LL: the top-K list itself lives in LDS for the duration of the launch (copied in at entry, out at exit) whenever it fits
 // next to the working set twice per CU (K <= ~13 500: the default 30 s history at 1 kHz is 7 500 entries, 30 KB).  A flush
 // then merges at LDS speed: through the L2-resident array it was 104 k cycles of dependent global round trips per flush
@@ -614,6 +649,15 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
         const int n4 = (nP + 3) & ~3;
         for (int i = nP + lane; i < n4; i += 64) Pp[i] = -INFINITY;
         NMX_WAVE_FENCE();
+        // (equal samples are the same float: their order does not show in the sorted list)
+        if (nP <= 512) {
+          float sv[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) sv[r] = (lane + 64 * r < nP) ? Pp[lane + 64 * r] : -INFINITY;
+          nmx_bitonic_desc<8>(sv, lane);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (lane + 64 * r < nP) ps[lane + 64 * r] = sv[r];
+        } else
         for (int t0 = 0; t0 < nP; t0 += 64) {
           // rank of (v, t) in the order "larger value first, equal values: lower index first".  For the
           // lanes of one round the index test is wave-uniform outside the round's own 64 entries:
@@ -694,9 +738,9 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
               const bool ok = i < Lm;
               const int c_lo = cb[b], c_hi = cb[b + 1];
               if (LL) {
-                // pending samples > v[q]: all of [0, c_lo), none of [c_hi, nP).  (The eight blocks' searches in lockstep,
-                // eight LDS reads in flight per step, were measured and are slower: most ranges are empty or one
-                // entry wide, the lockstep form pays the widest one eight times.)
+                // pending samples > v[q]: all of [0, c_lo), none of [c_hi, nP).  (Measured and slower: the eight blocks'
+                // searches in lockstep -- it pays the widest range eight times --, and reading the step's counters and
+                // the first two pending samples of every range up front.)
                 int lo2 = c_lo, hi2 = c_hi;
                 while (lo2 < hi2) {
                   const int mid = (lo2 + hi2) >> 1;
