@@ -411,6 +411,9 @@ static inline bool nmx_burst_thr_wave_ok(const NmxBurstThrArgs& A, long long win
 // same register of lane ^ j (one cross-lane read); the direction of a step is a lane bit below 64 and a compile-time
 // register bit above.  256 values: 36 steps, 33 of them with a cross-lane read -- ~4 k cycles where ranking by counting
 // (every value against every other) took 45 k per flush.
+#ifndef NMX_THRW_BITONIC_MAX
+#define NMX_THRW_BITONIC_MAX 512   // (0: rank by counting always -- A/B builds)
+#endif
 template <int R>
 NMX_DEV void nmx_bitonic_desc(float (&v)[R], int lane) {
 #pragma unroll
@@ -650,8 +653,8 @@ NMX_DEV void nmx_burst_thr_wave_item(const NmxBurstThrArgs& A, int c, int bi, fl
         for (int i = nP + lane; i < n4; i += 64) Pp[i] = -INFINITY;
         NMX_WAVE_FENCE();
         // (equal samples are the same float: their order does not show in the sorted list)
-        if (nP <= 512) {
-          float sv[8];
+        if (LL && nP > 128 && nP <= NMX_THRW_BITONIC_MAX) {   // (the network costs the same for 10 samples as for 512: a steady
+          float sv[8];                                         //  stream's short lists, and its kernel, keep the counting form)
 #pragma unroll
           for (int r = 0; r < 8; ++r) sv[r] = (lane + 64 * r < nP) ? Pp[lane + 64 * r] : -INFINITY;
           nmx_bitonic_desc<8>(sv, lane);
