@@ -226,10 +226,27 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
   const long long have = A.seq0 < (long long)(cap - 1) ? A.seq0 : (long long)(cap - 1);
   double s1 = 0.0, s2 = 0.0;
   int cnt = 0, ninf = 0, len = (int)have;   // cnt: finite values in the window, ninf: +-inf values
-  for (long long q = A.seq0 - have; q < A.seq0; ++q) {
-    const float h = A.ring[(q % cap) * A.n_cols + j];
-    if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
-    else if (h == h) ++ninf;
+  {   // (eight independent loads at a time, the slot advancing without a 64-bit modulo: the rebuild was 0.07 ms of a launch)
+    int sl = (int)((A.seq0 - have) % cap);
+    for (long long q0 = 0; q0 < have; q0 += 8) {
+      float hb[8];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int i = 0; i < 8; ++i) {
+        hb[i] = q0 + i < have ? A.ring[(long long)sl * A.n_cols + j] : NAN;
+        sl = sl + 1 == cap ? 0 : sl + 1;
+      }
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+      for (int i = 0; i < 8; ++i) {
+        const float h = hb[i];
+        if (q0 + i >= have) continue;
+        if (nmx_norm_finite(h)) { s1 += (double)h; s2 += (double)h * (double)h; ++cnt; }
+        else if (h == h) ++ninf;
+      }
+    }
   }
   const bool med = A.method >= NMX_NORM_MEDIAN;
   const bool sk = A.method >= NMX_NORM_ROBUST;   // history = nan_to_num(history): EVERY row is in the sorted copy
@@ -255,24 +272,32 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     // division chains in flight instead of one (the kernel is 156 waves of pure latency; measured in profiles/README.md, round 5).
     // (the walk itself holds no division and no 64-bit modulo: the ring slot advances with the hops -- the value a hop trims,
     // row q - (cap - 1), sits in the slot the NEXT hop writes --, and the trim's tests are multiplied through by the count)
+    // The NEXT block's cells and trimmed values are loaded while this block is computed (a block is two dependent global
+    // round trips otherwise -- 1600 cycles per hop standalone, 2 - 4 x that next to the throughput kernels of the following
+    // chunk): the rows of the next block are not written yet, and the slots its hops trim were stored cap - 1 hops ago,
+    // before this block when cap - 1 >= 2 PF.
     int slot = (int)(A.seq0 % cap);
-    for (int r0 = 0; r0 < A.n_rows; r0 += NMX_NORM_PF) {
-      float xb[NMX_NORM_PF], ob[NMX_NORM_PF];
-      double S1[NMX_NORM_PF], S2[NMX_NORM_PF], VO[NMX_NORM_PF];   // sums after the hop's value entered; two-pass variance or < 0
-      int CN[NMX_NORM_PF], NI[NMX_NORM_PF];
-      {
-        int so = slot;
+    const bool pf2 = cap - 1 >= 2 * NMX_NORM_PF;
+    float xb[NMX_NORM_PF], ob[NMX_NORM_PF], xn[NMX_NORM_PF], on[NMX_NORM_PF];
+    auto load_block = [&](int rb, int slot0, float (&xv)[NMX_NORM_PF], float (&ov)[NMX_NORM_PF]) {
+      int so = slot0;
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
-        for (int i = 0; i < NMX_NORM_PF; ++i) {
-          const int rr = r0 + i < A.n_rows ? r0 + i : A.n_rows - 1;
-          xb[i] = A.rows[(long long)rr * A.ld + j];
-          so = so + 1 == cap ? 0 : so + 1;   // slot of hop r0 + i + 1 == slot of row (r0 + i) - (cap - 1)
-          const long long qo = A.seq0 + rr - (cap - 1);
-          ob[i] = (pf_o && qo >= 0) ? A.ring[(long long)so * A.n_cols + j] : 0.f;
-        }
+      for (int i = 0; i < NMX_NORM_PF; ++i) {
+        const int rr = rb + i < A.n_rows ? rb + i : A.n_rows - 1;
+        xv[i] = A.rows[(long long)rr * A.ld + j];
+        so = so + 1 == cap ? 0 : so + 1;   // slot of hop rb + i + 1 == slot of row (rb + i) - (cap - 1)
+        const long long qo = A.seq0 + rr - (cap - 1);
+        ov[i] = (pf_o && qo >= 0) ? A.ring[(long long)so * A.n_cols + j] : 0.f;
       }
+    };
+    load_block(0, slot, xb, ob);
+    for (int r0 = 0; r0 < A.n_rows; r0 += NMX_NORM_PF) {
+      double S1[NMX_NORM_PF], S2[NMX_NORM_PF], VO[NMX_NORM_PF];   // sums after the hop's value entered; two-pass variance or < 0
+      int CN[NMX_NORM_PF], NI[NMX_NORM_PF];
+      const bool more = r0 + NMX_NORM_PF < A.n_rows;
+      if (more && pf2) load_block(r0 + NMX_NORM_PF, slot + NMX_NORM_PF >= cap ? slot + NMX_NORM_PF - cap : slot + NMX_NORM_PF, xn, on);
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
@@ -360,6 +385,16 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
           if (out > (double)A.clip) out = (double)A.clip;
         }
         A.rows[(long long)(r0 + bi) * A.ld + j] = nmx_clean((float)out);
+      }
+      if (more) {
+        if (pf2) {
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+          for (int i = 0; i < NMX_NORM_PF; ++i) { xb[i] = xn[i]; ob[i] = on[i]; }
+        } else {
+          load_block(r0 + NMX_NORM_PF, slot, xb, ob);
+        }
       }
     }
     return;
