@@ -315,8 +315,14 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
           --len;
         }
         A.ring[(long long)slot * A.n_cols + j] = x;
-        if (nmx_norm_finite(x)) { s1 += (double)x; s2 += (double)x * (double)x; ++cnt; }
-        else if (x == x) ++ninf;
+        {   // (selects, not branches: the walk is a chain of a few dozen dependent instructions per hop, a skipped branch
+            //  costs as much as what it skips)
+          const bool fx = nmx_norm_finite(x);
+          const double xd = fx ? (double)x : 0.0;
+          s1 += xd; s2 += xd * xd;
+          cnt += fx ? 1 : 0;
+          ninf += (!fx && x == x) ? 1 : 0;
+        }
         ++len;
         S1[bi] = s1; S2[bi] = s2; CN[bi] = cnt; NI[bi] = ninf;
         // cancellation (one-pass error ~ eps mean^2 / var; var < 1e-8 mean^2 without a division: x cnt^2): two-pass
@@ -333,8 +339,12 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         // history keeps its last N - 1 rows (normalization.py:107)
         if (len > cap - 1) {
           const float o = pf_o ? ob[bi] : A.ring[(long long)next * A.n_cols + j];
-          if (o == o) {
-            if (nmx_norm_finite(o)) { s1 -= (double)o; s2 -= (double)o * (double)o; --cnt; } else --ninf;
+          {
+            const bool fo = nmx_norm_finite(o);
+            const double od = fo ? (double)o : 0.0;
+            s1 -= od; s2 -= od * od;
+            cnt -= fo ? 1 : 0;
+            ninf -= (!fo && o == o) ? 1 : 0;
           }
           --len;
           // (a value far larger than what stays behind leaves the sums with ITS rounding: rebuild them -- see the general
