@@ -272,13 +272,11 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
     // division chains in flight instead of one (the kernel is 156 waves of pure latency; measured in profiles/README.md, round 5).
     // (the walk itself holds no division and no 64-bit modulo: the ring slot advances with the hops -- the value a hop trims,
     // row q - (cap - 1), sits in the slot the NEXT hop writes --, and the trim's tests are multiplied through by the count)
-    // The NEXT block's cells and trimmed values are loaded while this block is computed (a block is two dependent global
-    // round trips otherwise -- 1600 cycles per hop standalone, 2 - 4 x that next to the throughput kernels of the following
-    // chunk): the rows of the next block are not written yet, and the slots its hops trim were stored cap - 1 hops ago,
-    // before this block when cap - 1 >= 2 PF.
+    // (Loading the NEXT block's cells while this block is computed was measured: nothing standalone -- the walk is a chain
+    // of dependent float64 instructions, ~1600 cycles per hop, not load latency -- and worse inside the plan, 8.02 -> 8.40 ms
+    // per 1024 hops with the z-score: the loads in flight compete with the next chunk's kernels.)
     int slot = (int)(A.seq0 % cap);
-    const bool pf2 = cap - 1 >= 2 * NMX_NORM_PF;
-    float xb[NMX_NORM_PF], ob[NMX_NORM_PF], xn[NMX_NORM_PF], on[NMX_NORM_PF];
+    float xb[NMX_NORM_PF], ob[NMX_NORM_PF];
     auto load_block = [&](int rb, int slot0, float (&xv)[NMX_NORM_PF], float (&ov)[NMX_NORM_PF]) {
       int so = slot0;
 #ifndef NMX_HOST_EMU
@@ -297,7 +295,6 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
       double S1[NMX_NORM_PF], S2[NMX_NORM_PF], VO[NMX_NORM_PF];   // sums after the hop's value entered; two-pass variance or < 0
       int CN[NMX_NORM_PF], NI[NMX_NORM_PF];
       const bool more = r0 + NMX_NORM_PF < A.n_rows;
-      if (more && pf2) load_block(r0 + NMX_NORM_PF, slot + NMX_NORM_PF >= cap ? slot + NMX_NORM_PF - cap : slot + NMX_NORM_PF, xn, on);
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
@@ -396,16 +393,7 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
         }
         A.rows[(long long)(r0 + bi) * A.ld + j] = nmx_clean((float)out);
       }
-      if (more) {
-        if (pf2) {
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-          for (int i = 0; i < NMX_NORM_PF; ++i) { xb[i] = xn[i]; ob[i] = on[i]; }
-        } else {
-          load_block(r0 + NMX_NORM_PF, slot, xb, ob);
-        }
-      }
+      if (more) load_block(r0 + NMX_NORM_PF, slot, xb, ob);
     }
     return;
   }
