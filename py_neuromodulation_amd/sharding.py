@@ -105,9 +105,22 @@ class ShardedStream:
         pos = {j: i for i, j in enumerate(self.local_rows)}
         own = set(self.owned_rows)
         part = np.zeros((len(dp.local_groups), local_data.shape[1]))
+        local_data = np.asarray(local_data)
+        from . import _lib as _libmod
+
+        lib = self._lib if self._lib is not None else _libmod.get_library()   # (host passes only: no device needed)
+        native = (local_data.ndim == 2 and local_data.dtype in (np.float32, np.float64) and local_data.strides[1] == local_data.itemsize
+                  and local_data.strides[0] > 0 and local_data.strides[0] % local_data.itemsize == 0)
         for g, members in enumerate(dp.local_groups):
             idx = [pos[int(j)] for j in members if int(j) in own]
-            if idx:
+            if not idx:
+                continue
+            if native:   # one pass of libnmx's staging helper: nan_to_num of the float32-rounded samples, float64 sum in row order
+                rows = np.ascontiguousarray(idx, dtype=np.int32)
+                lib.check(lib.lib.nmx_host_group_sums(part[g].ctypes.data, local_data.ctypes.data, int(local_data.dtype == np.float64),
+                                                      local_data.strides[0] // local_data.itemsize, rows.ctypes.data, len(rows), 0,
+                                                      local_data.shape[1], 0))
+            else:
                 part[g] = np.nan_to_num(np.asarray(local_data[idx], np.float32)).astype(np.float64).sum(axis=0)   # the float32 samples the devices see
         if dist.is_available() and dist.is_initialized() and part.size and (
                 dist.get_world_size(group) > 1 or _force_collectives()):
