@@ -272,3 +272,39 @@ def test_host_staging_helpers_from_several_threads_and_after_fork():
             os._exit(4)
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
+def test_result_tables_are_recycled_but_never_shared():
+    """engine.table_empty: a dropped table's memory serves the next one of its size; a table still referenced (directly,
+    through a view, or inside a DataFrame) is never handed out again; small tables bypass the pool."""
+    import gc
+
+    import numpy as np
+    import pandas as pd
+
+    from py_neuromodulation_amd.engine import _TABLES, release_tables, table_empty
+
+    release_tables()
+    shape = (700, 1000)   # 5.6 MB: pooled
+    a = table_empty(shape)
+    a[:] = 1.0
+    addr = a.ctypes.data
+    b = table_empty(shape)
+    assert b.ctypes.data != addr and not np.shares_memory(a, b)
+    view = a[10:20]
+    df = pd.DataFrame(a, columns=[str(i) for i in range(shape[1])])
+    del a
+    gc.collect()
+    c = table_empty(shape)
+    assert c.ctypes.data != addr          # the view and the frame still hold it
+    assert float(view[0, 0]) == 1.0 and float(df.iloc[5, 5]) == 1.0
+    del view, df
+    gc.collect()
+    d = table_empty(shape, np.nan)
+    assert d.ctypes.data == addr and np.isnan(d).all() and d.flags.writeable and d.flags.c_contiguous
+    small = table_empty((4, 4))
+    assert small.base is None or not isinstance(small.base, type(d.base))
+    del b, c, d
+    gc.collect()
+    assert len(_TABLES._free) <= _TABLES.keep
+    assert release_tables() >= 1 and len(_TABLES._free) == 0
