@@ -17,6 +17,8 @@
 #include "nmx_k_timeosc.h"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 
 // ---- kernels: one workgroup per item, dynamic LDS carved by the host plan -----------------
@@ -148,12 +150,70 @@ static int be_device_count() {
   return n;
 }
 static int be_set_device(int dev) { return be_hip(hipSetDevice(dev), "hipSetDevice"); }
+// Device allocations are recycled across plans.  The reference builds a fresh DataProcessor per Stream and per run
+// (stream/stream.py:130, 233-242): a plan's ~50 hipMalloc and its owner's ~35 hipFree (each an unmap and a device
+// synchronisation, ~0.1 ms) were 10 of the 39 ms a fresh Stream on a warm process costs.  A freed block goes to a
+// per-device list keyed by its exact size -- identical streams ask for identical sizes -- after the SAME device-wide
+// synchronisation hipFree implies (the engine leans on it: a hand-off buffer regrown in mid-batch may still be read by
+// kernels in flight).  At most NMX_DEVICE_POOL_MB (default 8192; 0: off) stay cached; a failed hipMalloc empties the lists
+// and tries again.  Blocks come back with their old contents, as hipMalloc's may.
+struct NmxDevPool {
+  std::mutex m;
+  std::multimap<std::pair<int, size_t>, void*> idle;
+  std::map<void*, std::pair<int, size_t>> live;
+  size_t cached = 0, cap = 0;
+  bool cap_read = false;
+};
+static NmxDevPool& be_dev_pool() { static NmxDevPool* p = new NmxDevPool(); return *p; }   // (leaked: outlives static destruction)
+static void be_dev_pool_flush(NmxDevPool& D) {   // (caller holds the lock)
+  for (auto& kv : D.idle) (void)hipFree(kv.second);
+  D.idle.clear();
+  D.cached = 0;
+}
 static void* be_alloc(size_t n) {
+  NmxDevPool& D = be_dev_pool();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const size_t want = ((n ? n : 4) + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> lk(D.m);
+  if (!D.cap_read) {
+    const char* v = getenv("NMX_DEVICE_POOL_MB");
+    D.cap = (size_t)((v && v[0] >= '0' && v[0] <= '9') ? atoll(v) : 8192) << 20;
+    D.cap_read = true;
+  }
+  auto it = D.idle.find(std::make_pair(dev, want));
+  if (it != D.idle.end()) {
+    void* p = it->second;
+    D.idle.erase(it);
+    D.cached -= want;
+    D.live[p] = std::make_pair(dev, want);
+    return p;
+  }
   void* p = nullptr;
-  if (hipMalloc(&p, n) != hipSuccess) return nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    be_dev_pool_flush(D);
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  }
+  D.live[p] = std::make_pair(dev, want);
   return p;
 }
-static void be_free(void* p) { (void)hipFree(p); }
+static void be_free(void* p) {
+  if (!p) return;
+  NmxDevPool& D = be_dev_pool();
+  (void)hipDeviceSynchronize();   // what hipFree did: nothing in flight reads the block any more
+  std::lock_guard<std::mutex> lk(D.m);
+  auto it = D.live.find(p);
+  if (it == D.live.end()) { (void)hipFree(p); return; }
+  const std::pair<int, size_t> key = it->second;
+  D.live.erase(it);
+  if (D.cap && D.cached + key.second <= D.cap) {
+    D.idle.emplace(key, p);
+    D.cached += key.second;
+    return;
+  }
+  (void)hipFree(p);
+}
 static void* be_host_alloc(size_t n) {
   void* p = nullptr;
   if (hipHostMalloc(&p, n, hipHostMallocPortable)   /* every device of a multi-device stream copies from it */ != hipSuccess) return nullptr;
