@@ -35,7 +35,7 @@ class Stream:
         if channels is None and data is None:
             raise ValueError("Either `channels` or `data` must be passed to `Stream`.")
         self.channels = chmod.load_channels(channels)
-        if self.channels.query("used == 1 and target == 0").shape[0] == 0:
+        if not np.any((self.channels["used"].to_numpy() == 1) & (self.channels["target"].to_numpy() == 0)):   # (DataFrame.query: 2 ms)
             raise ValueError("No channels selected for analysis that have column 'used' = 1 and "
                              "'target' = 0. Please check your channels")
         if any(f in _FREQ_FEATURES for f in self.settings.features.get_enabled()):
