@@ -64,6 +64,13 @@ def _rows_ok(a: np.ndarray, dtype) -> bool:
             and a.strides[0] % a.itemsize == 0)
 
 
+def _ld(a: np.ndarray) -> int:
+    """Row pitch of a row-contiguous 2-D array in elements.  (NumPy is free to report ANY stride along an axis of
+    length one -- the transpose of a (samples, 1) array has a row "pitch" of one element: a single row's pitch is its
+    length.)"""
+    return a.strides[0] // a.itemsize if a.shape[0] > 1 else max(a.shape[1], 1)
+
+
 def parallel_cast(dst: np.ndarray, src: np.ndarray, sub: np.ndarray | None = None, lib=None) -> None:
     """dst[...] = src (with cast), first axis split over the conversion threads.  ``sub``: one float64 constant per row,
     subtracted BEFORE the cast (the engine's offset split: the cast then rounds at the signal's magnitude).  With the
@@ -638,7 +645,7 @@ class HotPathEngine:
         if self._dc is None:
             d = None
             if data.dtype == np.float64 and self.carries_offsets and True:
-                seg = np.asarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)
+                seg = np.ascontiguousarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)   # (C order: NumPy's sums follow the memory layout, the constants must not)
                 ok = np.isfinite(seg)
                 cnt = np.maximum(ok.sum(1), 1)
                 m = np.where(ok, seg, 0.0).sum(1) / cnt
@@ -689,7 +696,7 @@ class HotPathEngine:
         out = np.empty(self.n_outputs, np.float32)
         mask = np.zeros(self.C_in, np.uint8) if want_nan_mask else None
         self.lib.check(self.lib.lib.nmx_process_window(
-            self._plan, data.ctypes.data, data.strides[0] // 8, out.ctypes.data,
+            self._plan, data.ctypes.data, _ld(data), out.ctypes.data,
             mask.ctypes.data if mask is not None else None))
         return (out, mask.astype(bool)) if want_nan_mask else out
 
@@ -743,13 +750,15 @@ class HotPathEngine:
         starts = np.ascontiguousarray(starts, dtype=np.int64)
         n = len(starts)
         dc = self._host_offsets(data)
-        if dc is None and data.dtype == np.float32 and data.strides[1] == 4:
-            x = data
+        if dc is None and _rows_ok(data, np.float32) and _ld(data) >= data.shape[1]:
+            x = data   # (rows of a C-ordered float32 array or a view with longer rows: handed over as it is)
         elif data.size >= (1 << 18):
             x = self._pinned.array("x", data.shape, np.float32)
             parallel_cast(x, data, dc, self.lib)
         elif dc is not None:
-            x = (np.asarray(data, dtype=np.float64) - dc[:, None]).astype(np.float32)
+            # any layout comes in (a transposed (samples, channels) array, a DataFrame's ``to_numpy().T``: the reference
+            # takes them all, stream/stream.py:108); the library reads C-ordered float32 rows
+            x = np.ascontiguousarray(np.asarray(data, dtype=np.float64) - dc[:, None], dtype=np.float32)
         else:
             x = np.ascontiguousarray(data, dtype=np.float32)
         if out is not None:
@@ -763,14 +772,14 @@ class HotPathEngine:
         if tap:
             pre = np.empty((n, self.C, self.W), np.float32)
             self.lib.check(self.lib.lib.nmx_process_batch_tap(
-                self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
+                self._plan, x.ctypes.data, _ld(x), x.shape[1], starts.ctypes.data, n,
                 out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None, pre.ctypes.data))
             d_pre = self.offsets()[1]
             if np.any(d_pre != 0.0):   # the windows in float64 with their constants back (NMFeature.calc_feature's argument)
                 pre = pre.astype(np.float64) + d_pre[None, :, None]
             return (out, mask.astype(bool), pre) if want_nan_mask else (out, pre)
         self.lib.check(self.lib.lib.nmx_process_batch(
-            self._plan, x.ctypes.data, x.strides[0] // 4, x.shape[1], starts.ctypes.data, n,
+            self._plan, x.ctypes.data, _ld(x), x.shape[1], starts.ctypes.data, n,
             out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
         return (out, mask.astype(bool)) if want_nan_mask else out
 
@@ -790,7 +799,7 @@ class HotPathEngine:
         if data.ndim != 2 or data.shape[0] != self.C_in:
             raise ValueError(f"expected data with {self.C_in} rows, got {data.shape}")
         small = data.size < (1 << 20) or n < 64 or os.environ.get("NMX_PIPELINE", "1") == "0"
-        if small or (data.dtype == np.float32 and data.strides[1] == 4 and self._host_offsets(data) is None):
+        if small or (_rows_ok(data, np.float32) and _ld(data) >= data.shape[1] and self._host_offsets(data) is None):
             res = self.process_batch(data, starts, want_nan_mask=want_nan_mask, staged_output=True)
             out = res[0] if want_nan_mask else res
             o64 = table_empty((n, F + spare_cols))
@@ -880,7 +889,7 @@ class HotPathEngine:
             j.start()
         try:
             lib.check(lib.lib.nmx_process_batch(
-                self._plan, x.ctypes.data, x.strides[0] // 4, T, starts.ctypes.data, n,
+                self._plan, x.ctypes.data, _ld(x), T, starts.ctypes.data, n,
                 out.ctypes.data, mask.ctypes.data if mask is not None else None, 0, None))
         except BaseException:
             if own:

@@ -2198,3 +2198,109 @@ def case_ragged_rawnorm(lib):
         oth = [j for j, c in enumerate(cols[:-1]) if not c.endswith("_raw")]
         np.testing.assert_allclose(got[:, raw], want[:, raw], rtol=2e-5, atol=5e-6, err_msg=tag)
         np.testing.assert_allclose(got[:, oth], want[:, oth], rtol=5e-5, atol=2e-5, err_msg=tag)
+
+
+# ---- input layouts: the reference takes whatever NumPy / pandas hand it (stream/stream.py:95-108: a DataFrame
+# becomes ``to_numpy().transpose()``, a Fortran-ordered view) ---------------------------------------------------
+def _layout_variants(base_tc: np.ndarray):
+    """``base_tc`` is (samples, channels), C-ordered.  -> {name: (channels, samples) array of the SAME values}."""
+    C_ord = np.ascontiguousarray(base_tc.T)
+    T, C = base_tc.shape
+    wide = np.empty((C, 2 * T), base_tc.dtype)
+    wide[:, ::2] = C_ord
+    wide[:, 1::2] = -7.0
+    tall = np.full((2 * C, T + 5), 3.0, base_tc.dtype)
+    tall[::2, :T] = C_ord
+    return {"c_order": C_ord, "transposed_view": base_tc.T, "strided_columns": wide[:, ::2],
+            "strided_rows": tall[::2, :T]}
+
+
+def case_input_layouts(lib, large: bool = False):
+    """{C order, ``.T`` view of a (samples, channels) array, strided columns, strided rows, pd.DataFrame} x {float32,
+    float64} x {no offset, one row 1e5 spreads off zero} through `Stream.run`, `DataProcessor.process_batch`,
+    `HotPathEngine.process_batch` and `DataProcessor.process` (one window): every layout returns what the C-ordered
+    array returns, bit for bit.  ``large``: T x C above the 2**18 elements from which the cast runs on the staging
+    threads (the small sizes take the in-line conversions)."""
+    import pandas as pd
+
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.data_processor import DataProcessor
+    from py_neuromodulation_amd.engine import HotPathEngine
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.raw_hjorth = s.features.fft = s.features.linelength = s.features.return_raw = True
+    s.postprocessing.feature_normalization = False
+    C, T = 6, (48000 if large else 3000)
+    assert (C * T >= (1 << 18)) == large
+    rng = np.random.default_rng(77)
+    for dtype in (np.float64, np.float32):
+        for level in (0.0, 1e5):
+            base = rng.standard_normal((T, C)) * 50
+            base[:, 2] += level * 50
+            base = base.astype(dtype)
+            variants = _layout_variants(base)
+            want_df = None
+            channels = chmod.get_default_channels_from_data(variants["c_order"])
+            names = channels["name"].to_list()
+            for name, arr in list(variants.items()) + [("dataframe", pd.DataFrame(base, columns=names))]:
+                what = f"{np.dtype(dtype).name}, level {level:g}, {name}"
+                if name != "dataframe":
+                    np.testing.assert_array_equal(arr, variants["c_order"])
+                df = Stream(sfreq=1000.0, data=arr, channels=channels, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+                if want_df is None:
+                    want_df = df
+                    assert np.isfinite(df.to_numpy()).all() and len(df) == (T - 1000) // 100 + 1
+                else:
+                    assert list(df.columns) == list(want_df.columns)
+                    np.testing.assert_array_equal(df.to_numpy(), want_df.to_numpy(), err_msg="Stream.run: " + what)
+                if name == "dataframe":
+                    continue
+                if not large:   # the same recording on two plans (sharding.MultiDeviceProcessor stages the rows itself)
+                    two = Stream(sfreq=1000.0, data=arr, channels=channels, settings=s, line_noise=50, lib=lib,
+                                 devices=[0, 0]).run(save_csv=False).to_numpy()
+                    if name == "c_order":
+                        want_two = two
+                    else:
+                        np.testing.assert_array_equal(two, want_two, err_msg="Stream(devices=[0, 0]).run: " + what)
+                starts = np.arange(0, T - 1000 + 1, 100)[:12]
+                dp = DataProcessor(sfreq=1000.0, settings=s, channels=channels, line_noise=50, lib=lib)
+                rows = dp.process_batch(arr, starts)
+                np.testing.assert_array_equal(rows[:, :len(dp.keys)], want_df.to_numpy()[:12, :len(dp.keys)],
+                                              err_msg="DataProcessor.process_batch: " + what)
+                dp.reset()
+                one = dp.process(arr[:, :1000])
+                if name == "c_order":
+                    want_one = one
+                else:
+                    assert one == want_one, "DataProcessor.process: " + what
+                eng = HotPathEngine(s, names, 1000.0, lib=lib)
+                o = eng.process_batch(arr, starts)
+                eng.close()
+                if name == "c_order":
+                    want_o = o
+                else:
+                    np.testing.assert_array_equal(o, want_o, err_msg="HotPathEngine.process_batch: " + what)
+
+
+def case_input_layouts_single_channel(lib):
+    """One channel: NumPy reports an arbitrary row stride for a (1, T) array (the transpose of a (T, 1) column has a
+    row "pitch" of one element) -- the reference's real-time demo streams exactly one channel
+    (examples/plot_6_real_time_demo.py:54-106)."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.raw_hjorth = s.features.fft = True
+    s.postprocessing.feature_normalization = False
+    s.preprocessing = ["notch_filter"]
+    rng = np.random.default_rng(78)
+    for dtype in (np.float64, np.float32):
+        for level in (0.0, 1e7):
+            col = (rng.standard_normal((2500, 1)) * 50 + level).astype(dtype)
+            a = Stream(sfreq=1000.0, data=np.ascontiguousarray(col.T), settings=s, line_noise=50, lib=lib).run(save_csv=False)
+            b = Stream(sfreq=1000.0, data=col.T, settings=s, line_noise=50, lib=lib).run(save_csv=False)
+            np.testing.assert_array_equal(a.to_numpy(), b.to_numpy())

@@ -866,6 +866,15 @@ def test_stream_output_files(gpu_lib, tmp_path):
     pc.case_stream_output_files(gpu_lib, tmp_path)
 
 
+@pytest.mark.parametrize("large", [False, True])
+def test_input_layouts_give_identical_results(gpu_lib, large):
+    pc.case_input_layouts(gpu_lib, large=large)
+
+
+def test_input_layouts_single_channel(gpu_lib):
+    pc.case_input_layouts_single_channel(gpu_lib)
+
+
 def test_abi_from_plain_c_on_the_gpu(tmp_path):
     """tests/c_abi/abi_smoke.c on a box WITH a device: its `ndev > 0` branch creates a plan and computes one
     feature through the C ABI from plain C (the CPU tier only reaches the argument checks)."""

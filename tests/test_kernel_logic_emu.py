@@ -241,3 +241,12 @@ def test_raw_normalisation_with_ragged_window_lengths(emu_lib):
 def test_raw_order_normalisers_with_lists_in_device_memory(emu_lib, monkeypatch):
     monkeypatch.setenv("NMX_RAWNORM_GLOBAL_LISTS", "1")
     pc.case_raw_normalizer_order_methods(emu_lib)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_input_layouts_give_identical_results(emu_lib, large):
+    pc.case_input_layouts(emu_lib, large=large)
+
+
+def test_input_layouts_single_channel(emu_lib):
+    pc.case_input_layouts_single_channel(emu_lib)
