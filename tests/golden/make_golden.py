@@ -810,6 +810,63 @@ def case_dc_offsets():
     np.savez_compressed(HERE / "pipeline_dc_offsets.npz", **out)
 
 
+def _read_brainvision(vhdr: Path):
+    """Minimal BrainVision reader for the reference's own test recording (binary, multiplexed IEEE_FLOAT_32): ->
+    (float32 [n_samples, n_channels] as stored, names, resolution * unit scale per channel, sfreq).  MNE's reader
+    (`mne.io.read_raw_brainvision`, behind `nm.io.read_BIDS_data`, io.py) returns `stored * resolution * 1e-6` (micro-volt
+    units -> volt) as float64; MNE itself is not installable in this image."""
+    import configparser
+
+    text = vhdr.read_text(encoding="utf-8")
+    cp = configparser.ConfigParser(allow_no_value=True, delimiters=("=",), comment_prefixes=(";",), interpolation=None)
+    cp.optionxform = str
+    cp.read_string(text[text.index("[Common Infos]"):])
+    assert cp["Common Infos"]["DataOrientation"] == "MULTIPLEXED" and cp["Binary Infos"]["BinaryFormat"] == "IEEE_FLOAT_32"
+    n_ch = int(cp["Common Infos"]["NumberOfChannels"])
+    sfreq = 1e6 / float(cp["Common Infos"]["SamplingInterval"])
+    names, scale = [], []
+    for i in range(n_ch):
+        name, _, res, unit = cp["Channel Infos"][f"Ch{i + 1}"].split(",")[:4]
+        assert unit == "\u00b5V"
+        names.append(name)
+        scale.append(float(res) * 1e-6)
+    stored = np.fromfile(vhdr.parent / cp["Common Infos"]["DataFile"], dtype="<f4").reshape(-1, n_ch)
+    return stored, names, np.array(scale), sfreq
+
+
+def case_real_recording():
+    """The recording the reference's own tests run on (tests/conftest.py:8-69: `nm.io.read_BIDS_data` of
+    py_neuromodulation/data/sub-testsub/ses-EphysMedOff/ieeg/*_ieeg.vhdr -- 10 channels, 1 kHz, 19 s), the channel table
+    its fixtures build (`nm.utils.set_channels(reference="default", ..., target_keywords=...)`, utils/channels.py:13-22:
+    ECoG to the common average, the three LFP contacts bipolar, MOV_RIGHT the target), all nine hot-path feature
+    families behind the default pre-processing (notch + re-reference), 10 Hz, with the default z-score and without."""
+    import pandas as pd
+
+    ieeg = Path(ref_shim.REFERENCE_ROOT) / "py_neuromodulation/data/sub-testsub/ses-EphysMedOff/ieeg"
+    stored, names, scale, sfreq = _read_brainvision(next(ieeg.glob("*_ieeg.vhdr")))
+    data = stored.T.astype(np.float64) * scale[:, None]
+    tsv = pd.read_csv(next(ieeg.glob("*_channels.tsv")), sep="\t")
+    assert tsv["name"].to_list() == names
+    to_mne = {"DBS": "dbs", "ECOG": "ecog", "MISC": "misc", "SEEG": "seeg"}   # (raw.get_channel_types(): lower case)
+    channels = nm.utils.set_channels(ch_names=names, ch_types=[to_mne[t] for t in tsv["type"]], reference="default",
+                                     bads=[], new_names="default", used_types=("ecog", "dbs", "seeg"),
+                                     target_keywords=("MOV_RIGHT",))
+    out = {"sfreq": sfreq, "stored": stored, "scale": scale, "channels_json": json.dumps(channels.to_dict("list"))}
+    for tag, norm in (("nonorm", False), ("zscore", True)):
+        s = nm.NMSettings.get_default()
+        s.features.enable_all()
+        for f in ("fooof", "nolds", "coherence", "mne_connectivity", "bispectrum"):
+            setattr(s.features, f, False)
+        s.postprocessing.feature_normalization = norm
+        s.sampling_rate_features_hz = 10
+        st, df = _run_stream(data, sfreq, s, channels=channels, line_noise=50)
+        out[f"{tag}_settings_json"] = dump(st.settings)
+        out[f"{tag}_columns"] = np.array(list(df.columns))
+        out[f"{tag}_values"] = df.to_numpy(dtype=np.float64)
+        print("real_recording", tag, df.shape)
+    np.savez_compressed(HERE / "real_recording.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -837,3 +894,4 @@ if __name__ == "__main__":
     case_user_features()
     case_ragged_bursts()
     case_dc_offsets()
+    case_real_recording()

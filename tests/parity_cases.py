@@ -2304,3 +2304,56 @@ def case_input_layouts_single_channel(lib):
             a = Stream(sfreq=1000.0, data=np.ascontiguousarray(col.T), settings=s, line_noise=50, lib=lib).run(save_csv=False)
             b = Stream(sfreq=1000.0, data=col.T, settings=s, line_noise=50, lib=lib).run(save_csv=False)
             np.testing.assert_array_equal(a.to_numpy(), b.to_numpy())
+
+
+# ---- the recording the reference's own tests run on (tests/conftest.py:8-69) --------------------------------------
+def real_recording():
+    """-> (golden, data [10, 19001] float64 in volt, channel table dict, sfreq): tests/golden/real_recording.npz holds the
+    samples as the reference's BrainVision file stores them (float32, multiplexed) and MNE's scale per channel."""
+    import json
+
+    from tests.helpers import load_golden
+
+    g = load_golden("real_recording")
+    data = g["stored"].T.astype(np.float64) * g["scale"][:, None]
+    return g, data, json.loads(str(g["channels_json"])), float(g["sfreq"])
+
+
+def case_real_recording(lib, devices=None):
+    """`Stream.run` on sub-testsub's iEEG run with the channel table of the reference's fixtures (ECoG against the common
+    average, LFP contacts bipolar, MOV_RIGHT the target), the default pre-processing and all nine feature families at
+    10 Hz: 181 hops x 353 columns against the reference's own DataFrame under the standard policy (tests/parity.py);
+    then the default z-score on top, checked as a composition (case_pipeline_readme_default_zscore)."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import settings_from_json
+
+    g, data, ch, sfreq = real_recording()
+    s = settings_from_json(g["nonorm_settings_json"])
+    kw = {"devices": list(devices)} if devices else {}
+    df = Stream(sfreq=sfreq, channels=ch, settings=s, line_noise=50, lib=lib, **kw).run(data, save_csv=False)
+    cols = [str(c) for c in g["nonorm_columns"]]
+    assert list(df.columns) == cols, "DataFrame columns / order differ from the reference"
+    got, want = df.to_numpy(dtype=np.float64), g["nonorm_values"]
+    assert got.shape == want.shape == (181, 353)
+    nf = cols.index("time")
+    np.testing.assert_array_equal(got[:, nf:], want[:, nf:])   # time and the target channel's samples: exact
+    starts, ends, _ = orc.window_schedule(data.shape[1], sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    pv = parity.PipelineVerifiers(s, ch, sfreq, data, starts, 1000, line_noise=50)
+    used = [i for i, (u, t) in enumerate(zip(ch["used"], ch["target"])) if u == 1 and t == 0]
+    amp = float(np.abs(data[used] - data[used].mean(axis=1, keepdims=True)).max())
+    for r in range(len(got)):
+        n_bad, rep, _ = parity.compare(cols[:nf], got[r, :nf], want[r, :nf], s, sfreq, amp, 1000, verifier=pv.row(r))
+        assert n_bad == 0, f"row {r}\n{rep}"
+    # the default z-score (default_settings.yaml:69-78) inside the plan: the engine's normalised rows == the float64 oracle
+    # normaliser applied to the engine's OWN un-normalised rows (a z-score amplifies fp32 rounding by value / spread)
+    sz = settings_from_json(g["zscore_settings_json"])
+    dz = Stream(sfreq=sfreq, channels=ch, settings=sz, line_noise=50, lib=lib, **kw).run(data, save_csv=False)
+    assert list(dz.columns) == [str(c) for c in g["zscore_columns"]] == cols
+    gz, wz = dz.to_numpy(dtype=np.float64), g["zscore_values"]
+    norm = orc.FeatureNormalizer(sz)
+    want_n = np.stack([norm.process(r.copy()) for r in got[:, :nf]])
+    np.testing.assert_array_equal(gz[0, :nf], got[0, :nf])
+    np.testing.assert_allclose(gz[:, :nf], want_n, rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(gz[:, nf:], wz[:, nf:])
+    assert np.nanmedian(np.abs(gz[1:, :nf] - wz[1:, :nf])) < 1e-4

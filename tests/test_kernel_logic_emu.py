@@ -250,3 +250,8 @@ def test_input_layouts_give_identical_results(emu_lib, large):
 
 def test_input_layouts_single_channel(emu_lib):
     pc.case_input_layouts_single_channel(emu_lib)
+
+
+@pytest.mark.parametrize("devices", [None, (0, 0)])
+def test_real_recording_of_the_reference_tests(emu_lib, devices):
+    pc.case_real_recording(emu_lib, devices=devices)
