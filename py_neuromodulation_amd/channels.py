@@ -133,8 +133,11 @@ def split_hi_lo(v: np.ndarray) -> np.ndarray:
     sums of a channel shard travel this way (sharding.py): a float32 sum of 256 channels with +-500 offsets would add a
     rounding step the single-device kernel does not have."""
     fmax = float(np.finfo(np.float32).max)
-    # (a sum beyond float32's range -- several members at +-inf, which nan_to_num turns into +-3.4e38 each -- would
-    # give hi = +inf, lo = -inf: the device cleans those to +-FLT_MAX and the pair cancels to 0)
-    v = np.clip(np.asarray(v, np.float64), -fmax, fmax)
-    hi = v.astype(np.float32)
-    return np.stack([hi, (v - hi.astype(np.float64)).astype(np.float32)])
+    # (a sum beyond float32's range -- several members at +-inf, which nan_to_num turns into +-3.4e38 each -- would give
+    # hi = +inf, lo = -inf: the device cleans those to +-FLT_MAX and the pair cancels to 0.  Both halves saturate instead:
+    # two members on the rail travel exactly, as (FLT_MAX, FLT_MAX) -- the kernels add the halves in float64 --, more
+    # than two as a huge value of the right sign.)
+    v = np.asarray(v, np.float64)
+    hi = np.clip(v, -fmax, fmax).astype(np.float32)
+    lo = np.clip(v - hi.astype(np.float64), -fmax, fmax).astype(np.float32)
+    return np.stack([hi, lo])

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) nmx_kern_power_ring(const NmxPowerPrepArg
   nmx_power_ring_at(P, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
-  __shared__ float red[256];
+  __shared__ double red[256];
   nmx_car_tile(A, (long long)blockIdx.x * 64, red);
 }
 __global__ void __launch_bounds__(256) nmx_kern_reref_struct(const NmxRerefStructArgs A) {

@@ -38,6 +38,15 @@ NMX_DEV float nmx_clean_sub(float v, const float* sub, const float* nanv, int j)
   return sub ? v - sub[j] : v;
 }
 
+NMX_DEV float nmx_reref_store(double v) {
+  // a member on the rail whose row sums to (1 + 1e-8) FLT_MAX through the rounding of the fp32 coefficients is ON the rail
+  // (the reference: DBL_MAX - small = DBL_MAX), not beyond it; a true overflow exceeds it by 1 / (n - 1) of itself
+  const double fmax = 3.402823466e+38;
+  if (v > fmax && v < fmax * (1.0 + 1e-6)) return 3.402823466e+38f;
+  if (v < -fmax && v > -fmax * (1.0 + 1e-6)) return -3.402823466e+38f;
+  return (float)v;
+}
+
 // block = 256 threads <-> 256 consecutive samples; blockIdx.y <-> NMX_REREF_ROWS output rows
 NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
   if (t >= A.T) return;
@@ -54,7 +63,7 @@ NMX_DEV void nmx_reref_tile(const NmxRerefArgs& A, long long t, int c0) {
     for (int i = 0; i < NMX_REREF_ROWS; ++i)
       if (i < nrow) acc[i] += (double)A.R[(long long)(c0 + i) * A.C_in + j] * (double)v;
   }
-  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = (float)acc[i];
+  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = nmx_reref_store(acc[i]);
 }
 
 // Common-average style matrices R = (d - o) I + o 1 1^T (the reference's DEFAULT channel table,
@@ -72,12 +81,19 @@ struct NmxCarArgs {
   const float* nanv;  // [C] a NaN sample's value (see NmxRerefArgs), or NULL
 };
 
+// float64 sums, the scale INSIDE the sum: the reference multiplies before it adds (`ref_matrix @ data`,
+// processing/rereference.py:99-100), so two members at +-inf (nan_to_num: +-FLT_MAX each here, +-DBL_MAX there) leave the
+// finite huge value 2 off FLT_MAX on the other channels where FLT_MAX + FLT_MAX is inf in fp32 (and off * inf = -inf on
+// every channel), a pair of opposite signs cancels, and only a row whose exact value lies beyond the format's range
+// comes out as inf -- on one plan, on several (sharding.py: float64 group sums from the host) and in the reference.
+// The kernel waits on its loads either way (0.2 ms for 105 MB in + 105 MB out).
 NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
   if (t >= A.T) return;
-  float s = 0.f;
-  for (int j = 0; j < A.C; ++j) s += nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
-  const float a = A.diag - A.off, b = A.off * s;
-  for (int j = 0; j < A.C; ++j) A.y[(long long)j * A.ldy + t] = a * nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b;
+  const double o = (double)A.off, a = (double)A.diag - (double)A.off;
+  double b = 0.0;
+  for (int j = 0; j < A.C; ++j) b += o * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
+  for (int j = 0; j < A.C; ++j)
+    A.y[(long long)j * A.ldy + t] = nmx_reref_store(a * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b);
 }
 
 #ifndef NMX_HOST_EMU
@@ -85,31 +101,34 @@ NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
 // (a quarter of the column), the four partial sums meet in LDS, then every wave writes its own channels.
 // Four times the waves of the one-thread-per-sample form and loops a quarter as long: the kernel was
 // latency bound at 1.6 waves per SIMD (0.21 ms for 105 MB in + 105 MB out).
-NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, float* red) {
+NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, double* red) {
   const int lane = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
   const long long t = t0 + lane;
   const bool in = t < A.T;
-  float s = 0.f;
+  const double o = (double)A.off;
+  double s = 0.0;
   if (in) {
     int j = q;
     for (; j + 12 < A.C; j += 16) {   // four independent loads in flight
       const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 4) * A.ldx + t];
       const float v2 = A.x[(long long)(j + 8) * A.ldx + t], v3 = A.x[(long long)(j + 12) * A.ldx + t];
       if (A.sub || A.nanv) {
-        s += nmx_clean_sub(v0, A.sub, A.nanv, j); s += nmx_clean_sub(v1, A.sub, A.nanv, j + 4);
-        s += nmx_clean_sub(v2, A.sub, A.nanv, j + 8); s += nmx_clean_sub(v3, A.sub, A.nanv, j + 12);
+        s += o * (double)nmx_clean_sub(v0, A.sub, A.nanv, j); s += o * (double)nmx_clean_sub(v1, A.sub, A.nanv, j + 4);
+        s += o * (double)nmx_clean_sub(v2, A.sub, A.nanv, j + 8); s += o * (double)nmx_clean_sub(v3, A.sub, A.nanv, j + 12);
       } else {
-        s += nmx_clean(v0); s += nmx_clean(v1); s += nmx_clean(v2); s += nmx_clean(v3);
+        s += o * (double)nmx_clean(v0); s += o * (double)nmx_clean(v1);
+        s += o * (double)nmx_clean(v2); s += o * (double)nmx_clean(v3);
       }
     }
-    for (; j < A.C; j += 4) s += nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
+    for (; j < A.C; j += 4) s += o * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
   }
   red[q * 64 + lane] = s;
   __syncthreads();
-  const float tot = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  const double b = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
   if (!in) return;
-  const float a = A.diag - A.off, b = A.off * tot;
-  for (int j = q; j < A.C; j += 4) A.y[(long long)j * A.ldy + t] = a * nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b;
+  const double a = (double)A.diag - (double)A.off;
+  for (int j = q; j < A.C; j += 4)
+    A.y[(long long)j * A.ldy + t] = nmx_reref_store(a * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b);
 }
 #endif
 
@@ -155,7 +174,7 @@ NMX_DEV void nmx_reref_struct_sample(const NmxRerefStructArgs& A, long long t) {
       const float c = A.row_coef[r * NMX_RS_TAPS + k];
       if (c != 0.f) acc += (double)c * (double)nmx_clean_sub(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t], A.sub, A.nanv, A.row_idx[r * NMX_RS_TAPS + k]);
     }
-    A.y[(long long)r * A.ldy + t] = (float)acc;
+    A.y[(long long)r * A.ldy + t] = nmx_reref_store(acc);
   }
 }
 
@@ -196,7 +215,7 @@ NMX_DEV void nmx_reref_struct_tile(const NmxRerefStructArgs& A, long long t0, do
       const float c = A.row_coef[r * NMX_RS_TAPS + k];
       if (c != 0.f) acc += (double)c * (double)nmx_clean_sub(A.x[(long long)A.row_idx[r * NMX_RS_TAPS + k] * A.ldx + t], A.sub, A.nanv, A.row_idx[r * NMX_RS_TAPS + k]);
     }
-    A.y[(long long)r * A.ldy + t] = (float)acc;
+    A.y[(long long)r * A.ldy + t] = nmx_reref_store(acc);
   }
 }
 #endif

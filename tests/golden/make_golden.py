@@ -867,6 +867,32 @@ def case_real_recording():
     np.savez_compressed(HERE / "real_recording.npz", **out)
 
 
+def case_inf_members():
+    """Several members of one re-reference group at +-inf in the same sample (amplifier rails, a decoder's overflow
+    marker): nan_to_num makes them +-DBL_MAX (stream/data_processor.py:255) and `ref_matrix @ data`
+    (processing/rereference.py:99-100) multiplies before it adds -- two members give the finite 2/(n-1) DBL_MAX on the
+    other channels, opposite signs cancel, and only a sum beyond DBL_MAX is inf.  Default channel table (common average
+    over 8 ECoG channels), re-reference only, 10 Hz."""
+    rng = np.random.default_rng(61)
+    t = np.arange(4000) / 1000.0
+    data = rng.standard_normal((8, 4000)) * 40 + 12 * np.sin(2 * np.pi * 17 * t)
+    data[[1, 3], 1250] = np.inf                      # two members
+    data[[0, 4, 6], 1950] = np.inf                   # three members
+    data[2, 2650], data[5, 2650] = np.inf, -np.inf   # both signs in one sample
+    data[7, 3350], data[7, 3351] = -np.inf, -np.inf  # one member, two samples
+    s = nm.NMSettings.get_default()
+    s.reset()
+    s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+    s.preprocessing = ["re_referencing"]
+    s.postprocessing.feature_normalization = False
+    s.sampling_rate_features_hz = 10
+    st, df = _run_stream(data, 1000, s)
+    out = {"sfreq": 1000, "data": data, "settings_json": dump(st.settings), "columns": np.array(list(df.columns)),
+           "values": df.to_numpy(dtype=np.float64), "channels_json": json.dumps(st.channels.to_dict("list"))}
+    np.savez_compressed(HERE / "inf_members.npz", **out)
+    print("inf_members", df.shape, "huge", int((np.abs(out["values"]) >= 1e37).sum()), "nan", int(np.isnan(out["values"]).sum()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -895,3 +921,4 @@ if __name__ == "__main__":
     case_ragged_bursts()
     case_dc_offsets()
     case_real_recording()
+    case_inf_members()

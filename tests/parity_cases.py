@@ -2357,3 +2357,74 @@ def case_real_recording(lib, devices=None):
     np.testing.assert_allclose(gz[:, :nf], want_n, rtol=1e-5, atol=2e-6)
     np.testing.assert_array_equal(gz[:, nf:], wz[:, nf:])
     assert np.nanmedian(np.abs(gz[1:, :nf] - wz[1:, :nf])) < 1e-4
+
+
+# ---- several members of one re-reference group on the rail in the same sample ---------------------------------------
+def _rail_class(v, key, settings, ours: bool):
+    """0: an ordinary value; +-1: derived from samples on the rail, with that sign; 2: NaN; 3: a spectral entry of a window
+    with samples on the rail.  The reference's rail is +-DBL_MAX (np.nan_to_num of +-inf in float64), the engine's
+    +-FLT_MAX: features of such a window are "huge" on either scale -- beyond 1e200 there, beyond 1e25 (or +-inf: the
+    square of 1e38 is not a float32) here.  A transform of such a window adds terms of the size of the rail: whether a bin
+    comes out as 300-odd (log10 of a finite sum), +inf or NaN (inf - inf in a butterfly) is the summation order of the FFT
+    at hand, in pocketfft as in the engine's -- one class."""
+    if parity.family_of(key) == "fft":
+        logbig = (25.0 if ours else 200.0) if settings.fft_settings.log_transform else (1e25 if ours else 1e200)
+        return 0 if (np.isfinite(v) and v < logbig) else 3
+    if np.isnan(v):
+        return 2
+    if abs(v) >= (1e25 if ours else 1e200):
+        return int(np.sign(v))
+    return 0
+
+
+def case_inf_members(lib, run=None):
+    """tests/golden/inf_members.npz (the reference's own run): two and three members of the common-average group at +inf
+    in one sample, +inf and -inf together, one member at -inf twice.  Every entry must fall in the reference's class
+    (ordinary / rail-derived with the same sign / NaN) and ordinary entries meet the stated tolerances -- on one plan, on
+    two (``Stream(devices=[0, 0])``: the group sums come from the host as saturating hi / lo pairs) and, under gloo, on
+    two ranks (tests/test_sharding_gloo.py passes its own ``run``)."""
+    import json
+
+    from py_neuromodulation_amd.stream import Stream
+    from tests.helpers import load_golden, settings_from_json
+
+    g = load_golden("inf_members")
+    s = settings_from_json(g["settings_json"])
+    ch = json.loads(str(g["channels_json"]))
+    cols = [str(c) for c in g["columns"]]
+    want = g["values"]
+    runs = {}
+    if run is not None:
+        runs["caller"] = run
+    else:
+        runs["one plan"] = lambda: Stream(sfreq=1000.0, channels=ch, settings=s, lib=lib).run(g["data"], save_csv=False)
+        runs["two plans"] = lambda: Stream(sfreq=1000.0, channels=ch, settings=s, lib=lib, devices=[0, 0]).run(
+            g["data"], save_csv=False)
+    patterns = {}
+    for name, fn in runs.items():
+        df = fn()
+        assert list(df.columns) == cols
+        got = df.to_numpy(dtype=np.float64)
+        assert got.shape == want.shape
+        cls_g = np.array([[_rail_class(got[r, c], cols[c], s, True) for c in range(len(cols))] for r in range(len(got))])
+        cls_w = np.array([[_rail_class(want[r, c], cols[c], s, False) for c in range(len(cols))] for r in range(len(got))])
+        # +inf and -inf in one sample (2650): on every OTHER channel the two terms cancel and the exact value is an ordinary
+        # one; the reference returns the rounding residue of DBL_MAX / 7 - DBL_MAX / 7 (1e-20 of the rail: LineLength
+        # 4e285, Activity DBL_MAX), the engine's float64 sum cancels exactly.  Nothing to compare on those windows.
+        starts = np.arange(0, g["data"].shape[1] - 1000 + 1, 100)
+        residue = np.zeros_like(cls_w, dtype=bool)
+        for r in np.flatnonzero((starts <= 2650) & (2650 < starts + 1000)):
+            residue[r] = [not (c.startswith("ch2_") or c.startswith("ch5_")) and c != "time" for c in cols]
+        cls_w[residue] = cls_g[residue]
+        bad = np.argwhere(cls_g != cls_w)
+        assert len(bad) == 0, f"{name}: {len(bad)} entries in another class than the reference's, e.g. " + "; ".join(
+            f"hop {r} {cols[c]}: got {got[r, c]!r} want {want[r, c]!r}" for r, c in bad[:8])
+        counts = {k: int((np.abs(cls_w) == k).sum()) for k in (1, 2, 3)}
+        assert counts[1] > 100 and counts[3] > 400, f"the golden lost its rails: {counts}"
+        nf = cols.index("time")
+        for r in range(len(got)):
+            keep = [c for c in range(nf) if cls_w[r, c] == 0 and not residue[r, c]]
+            n_bad, rep, _ = parity.compare([cols[c] for c in keep], got[r, keep], want[r, keep], s, 1000.0, 200.0, 1000)
+            assert n_bad == 0, f"{name}, hop {r}\n{rep}"
+        patterns[name] = cls_g
+    return patterns

@@ -880,6 +880,10 @@ def test_real_recording_of_the_reference_tests(gpu_lib, devices):
     pc.case_real_recording(gpu_lib, devices=devices)
 
 
+def test_reref_group_members_on_the_rail(gpu_lib):
+    pc.case_inf_members(gpu_lib)
+
+
 def test_abi_from_plain_c_on_the_gpu(tmp_path):
     """tests/c_abi/abi_smoke.c on a box WITH a device: its `ndev > 0` branch creates a plan and computes one
     feature through the C ABI from plain C (the CPU tier only reaches the argument checks)."""

@@ -255,3 +255,7 @@ def test_input_layouts_single_channel(emu_lib):
 @pytest.mark.parametrize("devices", [None, (0, 0)])
 def test_real_recording_of_the_reference_tests(emu_lib, devices):
     pc.case_real_recording(emu_lib, devices=devices)
+
+
+def test_reref_group_members_on_the_rail(emu_lib):
+    pc.case_inf_members(emu_lib)

@@ -86,6 +86,19 @@ for tag, local in (("ragged", False), ("ragged_local", True)):
     if rank == 0:
         df3.to_pickle(sys.argv[2] + "." + tag)
     dist.barrier()
+# several members of the common-average group on the rail in one sample (tests/golden/inf_members.npz, the reference's own
+# run): the all-reduced float64 group sum must carry 2 x FLT_MAX like the one-plan kernel's
+from tests.helpers import load_golden, settings_from_json
+g4 = load_golden("inf_members")
+s4 = settings_from_json(g4["settings_json"])
+ch4 = json.loads(str(g4["channels_json"]))
+for tag, local in (("inf", False), ("inf_local", True)):
+    st4 = ShardedStream(1000.0, ch4, s4, line_noise=50, rank=rank, world_size=world, device=dev, lib=lib, local_input=local)
+    keys4, rows4, times4 = st4.run(g4["data"][st4.local_rows] if local else g4["data"])
+    df4 = gather_dataframe(keys4, rows4, times4, global_keys(1000.0, s4, ch4))
+    if rank == 0:
+        df4.to_pickle(sys.argv[2] + "." + tag)
+    dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -276,6 +289,12 @@ def _run_two_ranks(tmp_path, backend, port, nproc=2):
         assert np.array_equal(np.isnan(a3), np.isnan(b3)) and np.isnan(a3).any(), tag
         np.testing.assert_allclose(np.nan_to_num(a3), np.nan_to_num(b3), rtol=1e-3 if loose else 2e-5, atol=1e-4 if loose else 2e-6,
                                    err_msg=tag)
+
+    # rails: the sharded table falls in the reference's classes entry by entry (tests/parity_cases.py: case_inf_members)
+    from tests import parity_cases as pc
+    for tag in ("inf", "inf_local"):
+        got4 = pd.read_pickle(str(out) + "." + tag)
+        pc.case_inf_members(lib, run=lambda: got4)
 
 
 def test_multi_device_stream_runs_user_registered_features():
