@@ -29,8 +29,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libnmx.so is built with -fvisibility=hidden: the prototypes below are its whole link-visible surface */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define NMX_ABI_VERSION 9
+#define NMX_ABI_VERSION 10
 
 /* error codes */
 #define NMX_OK 0
@@ -340,6 +344,13 @@ int nmx_plan_attach_norm(nmx_plan* plan, nmx_norm* norm);
 int nmx_host_alloc(int64_t n_bytes, void** out);
 int nmx_host_free(void* p);
 
+/* Device memory of destroyed plans is recycled by later plans (a fresh reference-style DataProcessor per run costs no
+ * hipMalloc / hipFree round trips): bounded by NMX_DEVICE_POOL_MB (default 8192, 0: off) and by an eighth of the device's
+ * free memory, aged out after NMX_POOL_KEEP_PLANS (4) destroyed plans without reuse.  This call hands idle blocks back to
+ * the driver NOW, until at most keep_bytes stay cached (0: all) -- for a process that shares its GPU (a second rank,
+ * another allocator) or is done with the engine for a while.  *freed (may be NULL) = bytes released.  Thread safe. */
+int nmx_device_pool_trim(int64_t keep_bytes, int64_t* freed);
+
 /* Host-side staging passes of the boundary (no device work; a few threads of their own, n_threads <= 0: an eighth of the machine, 4 .. 16).  They
  * replace what a NumPy host does at 1 - 3 GB/s around a batch call -- the reference hands float64 rows
  * (stream/stream.py:298-310) and expects a float64 table in its own column order (stream/stream.py:319-343):
@@ -365,6 +376,9 @@ int nmx_host_stage_parts(const void* src, int src_is_f64, int64_t ld_src, int32_
 int nmx_host_widen_rows(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t r0, int64_t r1,
                         const int64_t* runs, int32_t n_runs, int32_t n_threads);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -155,20 +155,39 @@ static int be_set_device(int dev) { return be_hip(hipSetDevice(dev), "hipSetDevi
 // synchronisation, ~0.1 ms) were 10 of the 39 ms a fresh Stream on a warm process costs.  A freed block goes to a
 // per-device list keyed by its exact size -- identical streams ask for identical sizes -- after the SAME device-wide
 // synchronisation hipFree implies (the engine leans on it: a hand-off buffer regrown in mid-batch may still be read by
-// kernels in flight).  At most NMX_DEVICE_POOL_MB (default 8192; 0: off) stay cached; a failed hipMalloc empties the lists
-// and tries again.  Blocks come back with their old contents, as hipMalloc's may.
+// kernels in flight), so an idle block has no reader on any stream and may be handed to the driver from any thread.
+// What stays cached is bounded three ways (co-tenants of the device -- a second rank, torch's allocator -- cannot reclaim
+// it themselves):
+//   * NMX_DEVICE_POOL_MB (default 8192; 0: off) AND an eighth of what the device has free when a block comes back
+//     (hipMemGetInfo: on a device somebody else has filled the pool shrinks to nothing);
+//   * age: a block no plan has asked for while NMX_POOL_KEEP_PLANS (4) plans were destroyed goes back to the driver
+//     (a test suite, a sweep over window lengths: sizes that never recur);
+//   * nmx_device_pool_trim(keep_bytes): the caller's "give it back now" (engine.release_staging(), atexit).
+// A failed hipMalloc empties the lists and tries again.  Blocks come back with their old contents, as hipMalloc's may.
+struct NmxDevIdle { void* p; long long gen; };
 struct NmxDevPool {
   std::mutex m;
-  std::multimap<std::pair<int, size_t>, void*> idle;
+  std::multimap<std::pair<int, size_t>, NmxDevIdle> idle;
   std::map<void*, std::pair<int, size_t>> live;
   size_t cached = 0, cap = 0;
+  long long gen = 0;   // plans destroyed so far
   bool cap_read = false;
 };
 static NmxDevPool& be_dev_pool() { static NmxDevPool* p = new NmxDevPool(); return *p; }   // (leaked: outlives static destruction)
-static void be_dev_pool_flush(NmxDevPool& D) {   // (caller holds the lock)
-  for (auto& kv : D.idle) (void)hipFree(kv.second);
-  D.idle.clear();
-  D.cached = 0;
+static void be_dev_pool_flush(NmxDevPool& D, size_t keep = 0, long long older_than = -1) {   // (caller holds the lock)
+  for (auto it = D.idle.begin(); it != D.idle.end();) {
+    const bool old = older_than >= 0 && it->second.gen <= older_than;
+    if (!(old || (older_than < 0 && D.cached > keep))) { ++it; continue; }
+    (void)hipFree(it->second.p);
+    D.cached -= it->first.second;
+    it = D.idle.erase(it);
+  }
+}
+static void be_dev_pool_cap(NmxDevPool& D) {   // (caller holds the lock)
+  if (D.cap_read) return;
+  const char* v = getenv("NMX_DEVICE_POOL_MB");
+  D.cap = (size_t)((v && v[0] >= '0' && v[0] <= '9') ? atoll(v) : 8192) << 20;
+  D.cap_read = true;
 }
 static void* be_alloc(size_t n) {
   NmxDevPool& D = be_dev_pool();
@@ -176,14 +195,10 @@ static void* be_alloc(size_t n) {
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   const size_t want = ((n ? n : 4) + 255) & ~(size_t)255;
   std::lock_guard<std::mutex> lk(D.m);
-  if (!D.cap_read) {
-    const char* v = getenv("NMX_DEVICE_POOL_MB");
-    D.cap = (size_t)((v && v[0] >= '0' && v[0] <= '9') ? atoll(v) : 8192) << 20;
-    D.cap_read = true;
-  }
+  be_dev_pool_cap(D);
   auto it = D.idle.find(std::make_pair(dev, want));
   if (it != D.idle.end()) {
-    void* p = it->second;
+    void* p = it->second.p;
     D.idle.erase(it);
     D.cached -= want;
     D.live[p] = std::make_pair(dev, want);
@@ -207,12 +222,36 @@ static void be_free(void* p) {
   if (it == D.live.end()) { (void)hipFree(p); return; }
   const std::pair<int, size_t> key = it->second;
   D.live.erase(it);
-  if (D.cap && D.cached + key.second <= D.cap) {
-    D.idle.emplace(key, p);
+  size_t cap = D.cap;
+  if (cap && key.second >= (size_t)(64u << 20)) {   // (the query costs microseconds: asked for the blocks that matter)
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) cap = std::min(cap, (fr + D.cached) / 8);
+    else (void)hipGetLastError();
+  }
+  if (cap && D.cached + key.second <= cap) {
+    D.idle.emplace(key, NmxDevIdle{p, D.gen});
     D.cached += key.second;
     return;
   }
   (void)hipFree(p);
+}
+// a plan is gone: blocks that sat idle through the last `keep_plans` destroyed plans go back to the driver
+static void be_dev_pool_age() {
+  NmxDevPool& D = be_dev_pool();
+  static const long long keep_plans = [] {
+    const char* v = getenv("NMX_POOL_KEEP_PLANS");
+    return (long long)((v && v[0] >= '0' && v[0] <= '9') ? atoll(v) : 4);
+  }();
+  std::lock_guard<std::mutex> lk(D.m);
+  D.gen += 1;
+  if (D.gen > keep_plans) be_dev_pool_flush(D, 0, D.gen - keep_plans - 1);
+}
+static long long be_dev_pool_trim(long long keep_bytes) {
+  NmxDevPool& D = be_dev_pool();
+  std::lock_guard<std::mutex> lk(D.m);
+  const size_t before = D.cached;
+  be_dev_pool_flush(D, keep_bytes > 0 ? (size_t)keep_bytes : 0);
+  return (long long)(before - D.cached);
 }
 static void* be_host_alloc(size_t n) {
   void* p = nullptr;
@@ -241,6 +280,7 @@ static void be_memset_async(void* d, int v, size_t n, be_stream_t st) { BE_TRY(h
 // a host function in stream order (runs once everything enqueued on `st` before it has completed)
 static void be_host_fn(be_stream_t st, void (*fn)(void*), void* arg) { BE_TRY(hipLaunchHostFunc(st, fn, arg)); }
 static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
+static void be_sync_quiet(be_stream_t st) { if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError(); }   // (error paths: the first message stays)
 static be_stream_t be_stream_create() {
   hipStream_t s = nullptr;
   BE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));

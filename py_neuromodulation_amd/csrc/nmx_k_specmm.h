@@ -595,7 +595,9 @@ struct NmxSmmWave {
     // overflows.
     chk += __shfl_xor(chk, 16, 64);
     chk += __shfl_xor(chk, 32, 64);
-    const bool dirty = !CLEAN && A.clean_on_load && !(chk < INFINITY);
+    // (also behind a stage that has cleaned the samples already: a re-referenced window with members of its group on the
+    // rail holds +-1e38s -- its sums of squares are inf - inf here, the wave-level kernel's two-pass forms are not)
+    const bool dirty = !CLEAN && !(chk < INFINITY);
     if (TD) {
       float s0 = T.es0 + (T.s0.x + T.s0.y), q0 = T.eq0 + ((T.q0[0].x + T.q0[0].y) + (T.q0[1].x + T.q0[1].y));
       float q1 = T.eq1 + ((T.q1[0].x + T.q1[0].y) + (T.q1[1].x + T.q1[1].y));

@@ -102,5 +102,5 @@ extern "C" int nmx_specmm_launch(const NmxTimeOscArgs* A, int n_items, hipStream
 #undef NMX_SMM_LAUNCH
   // 2: the caller launches the pass over the flagged windows (nmx_wave_launch_timeosc_w1000_todo) -- behind its stage
   // timer, which brackets THIS kernel alone (bench.py: roofline_modeA is this kernel's launch duration)
-  return A->clean_on_load ? 2 : 1;
+  return 2;   // (a window's power can overflow behind a cleaning stage too: samples on the rail, re-referenced)
 }

@@ -129,9 +129,19 @@ class _TablePool:
     MIN_BYTES = 1 << 22
 
     def __init__(self, keep: int = 2) -> None:
+        import collections
         import threading
 
         self.keep, self._free, self._lock = keep, [], threading.Lock()
+        # buffers coming home from `_TableLease.__del__`: a finaliser can run on ANY allocation of the thread that holds
+        # the lock (a cyclic-GC pass inside `empty`), so it takes no lock -- deque.append is atomic -- and the list is
+        # merged by the next call that does
+        self._returned = collections.deque()
+
+    def _merge(self) -> None:   # (lock held)
+        while self._returned:
+            self._free.append(self._returned.popleft())
+        del self._free[:max(0, len(self._free) - self.keep)]
 
     def empty(self, shape, fill=None) -> np.ndarray:
         n = int(np.prod(shape))
@@ -139,8 +149,9 @@ class _TablePool:
             return np.empty(shape) if fill is None else np.full(shape, fill)
         raw = None
         with self._lock:
-            for i, b in enumerate(self._free):
-                if n <= b.size <= n + n // 4:
+            self._merge()
+            for i in range(len(self._free)):
+                if n <= self._free[i].size <= n + n // 4:
                     raw = self._free.pop(i)
                     break
         if raw is None:
@@ -151,13 +162,16 @@ class _TablePool:
         return arr
 
     def _give_back(self, raw: np.ndarray) -> None:
-        with self._lock:
-            self._free.append(raw)
-            while len(self._free) > self.keep:
-                self._free.pop(0)
+        self._returned.append(raw)
+        if len(self._returned) > 2 * self.keep + 2 and self._lock.acquire(blocking=False):   # (nobody allocates: trim here)
+            try:
+                self._merge()
+            finally:
+                self._lock.release()
 
     def clear(self) -> int:
         with self._lock:
+            self._merge()
             n = len(self._free)
             self._free.clear()
         return n
@@ -202,18 +216,37 @@ def _release_staging(pool: "_Pinned") -> None:
 
 
 def release_staging() -> int:
-    """Free the page-locked staging pools that no open engine uses; returns how many were freed."""
+    """Free the page-locked staging pools that no open engine uses -- and hand the device memory libnmx keeps of destroyed
+    plans back to the driver (nmx_device_pool_trim: a co-tenant of the GPU cannot reclaim it); returns how many staging
+    pools were freed."""
     n = 0
+    libs = {}
     for key in [k for k, p in _STAGING.items() if p.users <= 0]:
-        _STAGING.pop(key).close()
+        pool = _STAGING.pop(key)
+        libs[id(pool.lib)] = pool.lib
+        pool.close()
         n += 1
+    for p in _STAGING.values():
+        libs[id(p.lib)] = p.lib
+    for lib in libs.values():
+        trim_device_pool(lib)
     return n
+
+
+def trim_device_pool(lib=None, keep_bytes: int = 0) -> int:
+    """Idle device blocks of destroyed plans back to the driver until at most ``keep_bytes`` stay cached -> bytes freed."""
+    lib = lib if lib is not None else _lib.get_library()
+    freed = C.c_int64(0)
+    lib.check(lib.lib.nmx_device_pool_trim(int(keep_bytes), C.byref(freed)))
+    return int(freed.value)
 
 
 def _free_all_staging() -> None:   # atexit
     for key in list(_STAGING):
         try:
-            _STAGING.pop(key).close()
+            pool = _STAGING.pop(key)
+            pool.close()
+            pool.lib.lib.nmx_device_pool_trim(0, None)
         except Exception:
             pass
 

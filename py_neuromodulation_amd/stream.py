@@ -169,12 +169,20 @@ class Stream:
                     procs[w] = self._make_processor(w)
             self.data_processor = dp0 = procs[groups[0]]
             if len(groups) == 1:
+                side = self._side_files(out_dir, experiment_name)
+                had = [f.exists() for f in side]
                 after = threading.Thread(target=write_after, daemon=True)
                 after.start()
                 try:
                     rows = dp0.process_batch(data, starts, spare_cols=1 + n_targets)   # ("time" and the targets behind the features)
-                except BaseException:
+                except BaseException as e:
+                    # the reference writes these files after its loop (stream/stream.py:338): a run that fails leaves none
                     after.join()
+                    for f, was in zip(side, had):
+                        if not was:
+                            f.unlink(missing_ok=True)
+                    if after_err:
+                        raise e from after_err[0]
                     raise
             else:
                 # ragged windows (float sampling rate): the normaliser is sequential over ALL hops, so it
@@ -227,6 +235,12 @@ class Stream:
         if writer is not None and delete_ind_batch_files_after_stream:
             writer.delete_ind_files()
         return df if return_df else {}
+
+    @staticmethod
+    def _side_files(out_dir="", experiment_name: str = "sub"):
+        base = (Path.cwd() if not out_dir else Path(out_dir)) / experiment_name
+        return [base / f"{experiment_name}_SIDECAR.json", base / f"{experiment_name}_SETTINGS.yaml",
+                base / f"{experiment_name}_channels.csv"]
 
     # -- stream/stream.py:426-453, stream/data_processor.py:313-337 -----------------------------
     def _save_after_stream(self, out_dir="", experiment_name: str = "sub", settings_token=None) -> None:

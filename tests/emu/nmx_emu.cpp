@@ -34,6 +34,8 @@ static int be_device_count() { return 1; }
 static int be_set_device(int) { return 0; }
 static void* be_alloc(size_t n) { return calloc(1, n ? n : 4); }
 static void be_free(void* p) { free(p); }
+static void be_dev_pool_age() {}
+static long long be_dev_pool_trim(long long) { return 0; }
 static void* be_host_alloc(size_t n) { return malloc(n ? n : 4); }
 static void be_host_free(void* p) { free(p); }
 static void be_h2d_sync(void* d, const void* s, size_t n) { memcpy(d, s, n); }
@@ -50,6 +52,7 @@ static void be_d2h_2d_async(void* d, size_t dp, const void* s, size_t sp, size_t
 static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v, n); }
 static void be_host_fn(be_stream_t, void (*fn)(void*), void* arg) { fn(arg); }
 static int be_sync(be_stream_t) { return 0; }
+static void be_sync_quiet(be_stream_t) {}
 static be_stream_t be_stream_create() { return nullptr; }
 static be_stream_t be_stream_create_high() { return nullptr; }
 static void be_stream_destroy(be_stream_t) {}

@@ -880,17 +880,24 @@ def case_inf_members():
     data[[0, 4, 6], 1950] = np.inf                   # three members
     data[2, 2650], data[5, 2650] = np.inf, -np.inf   # both signs in one sample
     data[7, 3350], data[7, 3351] = -np.inf, -np.inf  # one member, two samples
-    s = nm.NMSettings.get_default()
-    s.reset()
-    s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
-    s.preprocessing = ["re_referencing"]
-    s.postprocessing.feature_normalization = False
-    s.sampling_rate_features_hz = 10
-    st, df = _run_stream(data, 1000, s)
-    out = {"sfreq": 1000, "data": data, "settings_json": dump(st.settings), "columns": np.array(list(df.columns)),
-           "values": df.to_numpy(dtype=np.float64), "channels_json": json.dumps(st.channels.to_dict("list"))}
+    out = {"sfreq": 1000, "data": data}
+    # "": the set the matrix-pipe spectrum kernel takes (FFT band means + time domain); "stft_": + STFT and Welch, the
+    # wave-level kernel of the default window
+    for tag, more in (("", ()), ("stft_", ("stft", "welch"))):
+        s = nm.NMSettings.get_default()
+        s.reset()
+        s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+        for f in more:
+            setattr(s.features, f, True)
+        s.preprocessing = ["re_referencing"]
+        s.postprocessing.feature_normalization = False
+        s.sampling_rate_features_hz = 10
+        st, df = _run_stream(data, 1000, s)
+        out.update({tag + "settings_json": dump(st.settings), tag + "columns": np.array(list(df.columns)),
+                    tag + "values": df.to_numpy(dtype=np.float64), "channels_json": json.dumps(st.channels.to_dict("list"))})
+        print("inf_members", tag, df.shape, "huge", int((np.abs(out[tag + "values"]) >= 1e37).sum()),
+              "nan", int(np.isnan(out[tag + "values"]).sum()))
     np.savez_compressed(HERE / "inf_members.npz", **out)
-    print("inf_members", df.shape, "huge", int((np.abs(out["values"]) >= 1e37).sum()), "nan", int(np.isnan(out["values"]).sum()))
 
 
 if __name__ == "__main__":

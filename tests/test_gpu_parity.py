@@ -880,8 +880,9 @@ def test_real_recording_of_the_reference_tests(gpu_lib, devices):
     pc.case_real_recording(gpu_lib, devices=devices)
 
 
-def test_reref_group_members_on_the_rail(gpu_lib):
-    pc.case_inf_members(gpu_lib)
+@pytest.mark.parametrize("tag", ["", "stft_"])
+def test_reref_group_members_on_the_rail(gpu_lib, tag):
+    pc.case_inf_members(gpu_lib, tag=tag)
 
 
 def test_abi_from_plain_c_on_the_gpu(tmp_path):

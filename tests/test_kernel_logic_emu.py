@@ -257,5 +257,31 @@ def test_real_recording_of_the_reference_tests(emu_lib, devices):
     pc.case_real_recording(emu_lib, devices=devices)
 
 
-def test_reref_group_members_on_the_rail(emu_lib):
-    pc.case_inf_members(emu_lib)
+@pytest.mark.parametrize("tag", ["", "stft_"])
+def test_reref_group_members_on_the_rail(emu_lib, tag):
+    pc.case_inf_members(emu_lib, tag=tag)
+
+
+def test_failed_run_leaves_no_side_files(emu_lib, tmp_path, monkeypatch):
+    """The reference writes the side-car / settings / channels files after its loop (stream/stream.py:338); the batch driver
+    writes them on a thread next to the device work -- a run that raises must not leave them behind."""
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.data_processor import DataProcessor
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.raw_hjorth = True
+    data = np.random.default_rng(3).standard_normal((3, 2500))
+    st = Stream(sfreq=1000.0, data=data, settings=s, lib=emu_lib)
+
+    def boom(self, *a, **k):
+        raise RuntimeError("device lost")
+
+    monkeypatch.setattr(DataProcessor, "process_batch", boom)
+    with pytest.raises(RuntimeError, match="device lost"):
+        st.run(out_dir=tmp_path, experiment_name="subx", save_csv=False)
+    assert not any((tmp_path / "subx").glob("*")) if (tmp_path / "subx").exists() else True
+    monkeypatch.undo()
+    st.run(out_dir=tmp_path, experiment_name="subx", save_csv=False)
+    assert sorted(p.name for p in (tmp_path / "subx").iterdir()) == ["subx_SETTINGS.yaml", "subx_SIDECAR.json", "subx_channels.csv"]
