@@ -84,6 +84,15 @@ __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
 __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
 }
+__global__ void __launch_bounds__(64) nmx_kern_norm_scan(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_scan_column(A, S, (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(256) nmx_kern_norm_cell(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_scan_cell(A, S, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
+}
+__global__ void __launch_bounds__(256) nmx_kern_norm_ring(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_scan_ring(A, S, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
+}
 // rows on grid.x (2^31 - 1 blocks), column blocks on grid.y: grid.y / .z stop at 65 535, and a long offline table or a
 // long history has more rows than that
 __global__ void __launch_bounds__(256) nmx_kern_power_prep(const NmxPowerPrepArgs P) {
@@ -511,6 +520,12 @@ static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t s) {
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   // one thread per column, one wave per workgroup: columns spread over as many CUs as possible
   hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
+}
+static void be_launch_norm_scan(const NmxNormArgs& A, const NmxNormScan& S, be_stream_t s) {
+  const dim3 cells((unsigned)A.n_rows, (unsigned)((A.n_cols + 255) / 256));
+  hipLaunchKernelGGL(nmx_kern_norm_scan, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A, S);
+  hipLaunchKernelGGL(nmx_kern_norm_cell, cells, dim3(256), 0, s, A, S);
+  hipLaunchKernelGGL(nmx_kern_norm_ring, cells, dim3(256), 0, s, A, S);
 }
 static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be_stream_t s) {
   const unsigned gy = (unsigned)((P.n_cols + 255) / 256);

@@ -147,6 +147,13 @@ static void be_launch_kalman(const NmxKalmanArgs& A, be_stream_t) {
 static void be_launch_norm(const NmxNormArgs& A, be_stream_t) {
   for (int j = 0; j < A.n_cols; ++j) nmx_norm_column(A, j);
 }
+static void be_launch_norm_scan(const NmxNormArgs& A, const NmxNormScan& S, be_stream_t) {
+  for (int j = 0; j < A.n_cols; ++j) nmx_norm_scan_column(A, S, j);
+  for (int r = 0; r < A.n_rows; ++r)
+    for (int j = 0; j < A.n_cols; ++j) nmx_norm_scan_cell(A, S, r, j);
+  for (int r = 0; r < A.n_rows; ++r)
+    for (int j = 0; j < A.n_cols; ++j) nmx_norm_scan_ring(A, S, r, j);
+}
 static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be_stream_t) {
   for (int e = 0; e < P.have + P.n_rows; ++e)
     for (int j = 0; j < P.n_cols; ++j) nmx_power_prep_at(P, e, j);

@@ -44,6 +44,20 @@ def test_library_exports_every_declared_symbol(lib):
     assert not missing, f"libnmx.so lacks {missing}"
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """The converse: built with -fvisibility=hidden and a version script generated from the header, the dynamic symbol
+    table holds the header's functions and nothing else -- the launchers the translation units call each other through
+    (nmx_w64c_launch_rd64, nmx_specmm_launch, nmxi_note_kernel ...), the kernels' host-side handles and libstdc++'s
+    template instantiations are not an API anybody was promised."""
+    import subprocess
+
+    import __graft_entry__ as g
+
+    out = subprocess.run(["nm", "-D", "--defined-only", str(g.build_lib())], check=True, capture_output=True, text=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert names == declared_functions()
+
+
 def test_python_binding_lists_every_declared_symbol():
     from py_neuromodulation_amd import _lib
 
