@@ -84,8 +84,14 @@ __global__ void __launch_bounds__(64) nmx_kern_kalman(const NmxKalmanArgs A) {
 __global__ void __launch_bounds__(64) nmx_kern_norm(const NmxNormArgs A) {
   nmx_norm_column(A, (int)(blockIdx.x * 64 + threadIdx.x));
 }
-__global__ void __launch_bounds__(64) nmx_kern_norm_scan(const NmxNormArgs A, const NmxNormScan S) {
-  nmx_norm_scan_column(A, S, (int)(blockIdx.x * 64 + threadIdx.x));
+__global__ void __launch_bounds__(64) nmx_kern_norm_seg_hist(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_seg_hist(A, S, (int)blockIdx.y, (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(64) nmx_kern_norm_seg_batch(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_seg_batch(A, S, (int)blockIdx.y, (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(64) nmx_kern_norm_seg_offsets(const NmxNormArgs A, const NmxNormScan S) {
+  nmx_norm_seg_offsets(A, S, (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) nmx_kern_norm_cell(const NmxNormArgs A, const NmxNormScan S) {
   nmx_norm_scan_cell(A, S, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
@@ -522,8 +528,11 @@ static void be_launch_norm(const NmxNormArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_norm, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A);
 }
 static void be_launch_norm_scan(const NmxNormArgs& A, const NmxNormScan& S, be_stream_t s) {
+  const unsigned cb = (unsigned)((A.n_cols + 63) / 64);
   const dim3 cells((unsigned)A.n_rows, (unsigned)((A.n_cols + 255) / 256));
-  hipLaunchKernelGGL(nmx_kern_norm_scan, dim3((unsigned)((A.n_cols + 63) / 64)), dim3(64), 0, s, A, S);
+  if (S.n_hseg) hipLaunchKernelGGL(nmx_kern_norm_seg_hist, dim3(cb, (unsigned)S.n_hseg), dim3(64), 0, s, A, S);
+  hipLaunchKernelGGL(nmx_kern_norm_seg_batch, dim3(cb, (unsigned)S.n_bseg), dim3(64), 0, s, A, S);
+  hipLaunchKernelGGL(nmx_kern_norm_seg_offsets, dim3(cb), dim3(64), 0, s, A, S);
   hipLaunchKernelGGL(nmx_kern_norm_cell, cells, dim3(256), 0, s, A, S);
   hipLaunchKernelGGL(nmx_kern_norm_ring, cells, dim3(256), 0, s, A, S);
 }

@@ -507,105 +507,146 @@ NMX_DEV void nmx_norm_column(const NmxNormArgs& A, int j) {
 // sums, then ~150 float64 instructions of division / square root per hop -- 156 waves of pure latency for the default
 // stream (9984 columns), 0.87 ms per 1024 hops inside the plan.  Nothing but the sums is sequential, and with at most
 // cap - 1 hops per launch the window of hop r is a SUFFIX of the history the launch found plus a PREFIX of the batch:
-//     S(r) = Bk[d(r)] + F[r],   Bk[d] = sum of history rows d .. have - 1 (scanned newest -> oldest),
-//                               F[r]  = sum of batch rows 0 .. r,   d(r) = max(0, r - (cap - 1 - have))
+//     S(r) = Bk[d(r)] + F[r],   Bk[d] = sum of history rows d .. have - 1,   F[r] = sum of batch rows 0 .. r,
+//                               d(r) = max(0, r - (cap - 1 - have))
 // (the van Herk / Gil-Werman decomposition with the block boundary at the start of the batch).  Additions only: a value that
 // leaves the window is simply not summed, so the walk's "a value far larger than what stays behind leaves its rounding in
-// the sums: rebuild" logic has nothing to do here.  Three launches:
-//   nmx_norm_scan_column  one thread per column: both scans (loads in blocks of NMX_NORM_SPF, no arithmetic but additions),
-//                         sums / counts per hop -> scratch, a copy of the batch's raw values -> scratch;
-//   nmx_norm_scan_cell    one thread per (hop, column): mean, standard deviation, quotient, clip, nan_to_num -- the
-//                         expensive part, now 2.5 M independent cells per 256 hops instead of 9984 chains;
-//   nmx_norm_scan_ring    the batch's raw values into the ring (AFTER the cells: a hop's two-pass variance reads history
-//                         rows the batch overwrites).
+// the sums: rebuild" logic has nothing to do here.  Both scans are cut into segments of NMX_NORM_SEG rows -- one THREAD
+// per (column, segment): 32 independent loads, 32 additions --, a third kernel turns the segments' totals into offsets:
+//   nmx_norm_seg_hist    local suffix sums of a history segment -> the scratch row of the hop they belong to; total -> table
+//   nmx_norm_seg_batch   local prefix sums of a batch segment + the hop's history part -> scratch; raw values -> scratch
+//   nmx_norm_seg_offsets per column: exclusive suffix (history) / prefix (batch) sums of the tables, in place (<= 20 steps)
+//   nmx_norm_scan_cell   one thread per (hop, column): sums = local + offsets, then mean, standard deviation, quotient,
+//                        clip, nan_to_num -- the expensive part, 2.5 M independent cells per 256 hops, not 9984 chains
+//   nmx_norm_scan_ring   the batch's raw values into the ring (AFTER the cells: a hop's two-pass variance reads history
+//                        rows the batch overwrites).
 // Same results as the walk up to the association of float64 sums of <= cap float32 values (1e-16 relative).
+// (The first form of this had ONE thread scan a column's 555 rows: 0.10 ms alone, 0.29 - 0.40 ms next to the following
+// chunk's kernels -- a long dependent chain is what co-running waves slow down most.)
+#define NMX_NORM_SEG 32
 struct NmxNormScan {
-  double* s1;        // [n_rows][n_cols] sum of the finite values of hop r's window
-  double* s2;        // sum of their squares
+  double* s1;        // [n_rows + 1][n_cols] sums of the finite values: local parts (row n_rows: history position 0)
+  double* s2;        // ... of their squares
   unsigned* cn;      // finite count | (+-inf count << 16)
-  float* xs;         // the batch's raw values
+  float* xs;         // [n_rows][n_cols] the batch's raw values
+  double* t1;        // [n_hseg + n_bseg][n_cols] segment totals, then offsets (history segments first)
+  double* t2;
+  unsigned* tc;
+  int have, grow, dmax, n_hseg, n_bseg;
 };
-#define NMX_NORM_SPF 16
 
 NMX_DEV bool nmx_norm_scan_ok(const NmxNormArgs& A) {
   return (A.method == NMX_NORM_MEAN || A.method == NMX_NORM_ZSCORE) && A.n_rows >= 1 && A.n_rows <= A.cap - 1 && A.cap < 65536;
 }
+// (host) the launch geometry of one piece
+static inline void nmx_norm_scan_shape(const NmxNormArgs& A, NmxNormScan& Sc) {
+  Sc.have = (int)(A.seq0 < (long long)(A.cap - 1) ? A.seq0 : (long long)(A.cap - 1));
+  Sc.grow = A.cap - 1 - Sc.have;                                            // hops before the history starts to lose rows
+  Sc.dmax = A.n_rows - 1 - Sc.grow > 0 ? A.n_rows - 1 - Sc.grow : 0;        // d(n_rows - 1) <= have - 1
+  Sc.n_hseg = (Sc.have + NMX_NORM_SEG - 1) / NMX_NORM_SEG;
+  Sc.n_bseg = (A.n_rows + NMX_NORM_SEG - 1) / NMX_NORM_SEG;
+}
 
-NMX_DEV void nmx_norm_scan_column(const NmxNormArgs& A, const NmxNormScan& Sc, int j) {
-  if (j >= A.n_cols) return;
+// history positions [g SEG, (g + 1) SEG) of column j, newest -> oldest (position i = row seq0 - have + i)
+NMX_DEV void nmx_norm_seg_hist(const NmxNormArgs& A, const NmxNormScan& Sc, int g, int j) {
+  if (j >= A.n_cols || g >= Sc.n_hseg) return;
   if (A.colmask && !A.colmask[j]) return;
-  const int cap = A.cap, nc = A.n_cols, n = A.n_rows;
-  const int have = (int)(A.seq0 < (long long)(cap - 1) ? A.seq0 : (long long)(cap - 1));
-  const int grow = cap - 1 - have;                   // hops of this batch before the history starts to lose rows
-  const int dmax = n - 1 - grow > 0 ? n - 1 - grow : 0;   // d(n - 1) <= have - 1
-  // ---- history, newest -> oldest: Bk[i] for i = dmax .. 0; Bk[i >= 1] belongs to hop i + grow, Bk[0] to hops 0 .. grow
+  const int cap = A.cap, nc = A.n_cols;
+  const int lo = g * NMX_NORM_SEG, hi = lo + NMX_NORM_SEG < Sc.have ? lo + NMX_NORM_SEG : Sc.have;
+  float hb[NMX_NORM_SEG];
+  int sl = (int)((A.seq0 - Sc.have + lo) % cap);
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+  for (int k = 0; k < NMX_NORM_SEG; ++k) {
+    hb[k] = lo + k < hi ? A.ring[(long long)sl * nc + j] : NAN;
+    sl = sl + 1 == cap ? 0 : sl + 1;
+  }
   double b1 = 0.0, b2 = 0.0;
   int bc = 0, bi = 0;
-  {
-    int sl = (int)((A.seq0 + cap - 1) % cap);         // slot of the newest history row (seq0 - 1)
-    for (int i0 = have - 1; i0 >= 0; i0 -= NMX_NORM_SPF) {
-      float hb[NMX_NORM_SPF];
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
-      for (int k = 0; k < NMX_NORM_SPF; ++k) {
-        hb[k] = i0 - k >= 0 ? A.ring[(long long)sl * nc + j] : NAN;
-        sl = sl == 0 ? cap - 1 : sl - 1;
-      }
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-      for (int k = 0; k < NMX_NORM_SPF; ++k) {
-        const int i = i0 - k;
-        if (i < 0) continue;
-        const float h = hb[k];
-        const bool f = nmx_norm_finite(h);
-        const double hd = f ? (double)h : 0.0;
-        b1 += hd; b2 += hd * hd;
-        bc += f ? 1 : 0;
-        bi += (!f && h == h) ? 1 : 0;
-        if (i >= 1 && i <= dmax) {
-          const long long o = (long long)(i + grow) * nc + j;
-          Sc.s1[o] = b1; Sc.s2[o] = b2; Sc.cn[o] = (unsigned)bc | ((unsigned)bi << 16);
-        }
-      }
+  for (int k = NMX_NORM_SEG - 1; k >= 0; --k) {
+    const int i = lo + k;
+    if (i >= hi) continue;
+    const float h = hb[k];
+    const bool f = nmx_norm_finite(h);
+    const double hd = f ? (double)h : 0.0;
+    b1 += hd; b2 += hd * hd;
+    bc += f ? 1 : 0;
+    bi += (!f && h == h) ? 1 : 0;
+    if (i <= Sc.dmax) {   // position i >= 1 belongs to hop i + grow, position 0 to hops 0 .. grow (row n_rows of the scratch)
+      const long long o = (long long)(i >= 1 ? i + Sc.grow : A.n_rows) * nc + j;
+      Sc.s1[o] = b1; Sc.s2[o] = b2; Sc.cn[o] = (unsigned)bc | ((unsigned)bi << 16);
     }
   }
-  // ---- batch, oldest -> newest
+  const long long t = (long long)g * nc + j;
+  Sc.t1[t] = b1; Sc.t2[t] = b2; Sc.tc[t] = (unsigned)bc | ((unsigned)bi << 16);
+}
+
+// batch rows [g SEG, (g + 1) SEG) of column j, oldest -> newest
+NMX_DEV void nmx_norm_seg_batch(const NmxNormArgs& A, const NmxNormScan& Sc, int g, int j) {
+  if (j >= A.n_cols || g >= Sc.n_bseg) return;
+  if (A.colmask && !A.colmask[j]) return;
+  const int nc = A.n_cols, n = A.n_rows;
+  const int lo = g * NMX_NORM_SEG, hi = lo + NMX_NORM_SEG < n ? lo + NMX_NORM_SEG : n;
+  float xb[NMX_NORM_SEG];
+  double p1[NMX_NORM_SEG], p2[NMX_NORM_SEG];
+  unsigned pc[NMX_NORM_SEG];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+  for (int k = 0; k < NMX_NORM_SEG; ++k) {
+    const int r = lo + k < hi ? lo + k : hi - 1;
+    xb[k] = A.rows[(long long)r * A.ld + j];
+    const long long o = (long long)(r > Sc.grow ? r : n) * nc + j;   // the hop's history part (local to its segment)
+    p1[k] = Sc.have ? Sc.s1[o] : 0.0; p2[k] = Sc.have ? Sc.s2[o] : 0.0; pc[k] = Sc.have ? Sc.cn[o] : 0u;
+  }
   double f1 = 0.0, f2 = 0.0;
   int fc = 0, fi = 0;
-  for (int r0 = 0; r0 < n; r0 += NMX_NORM_SPF) {
-    float xb[NMX_NORM_SPF];
-    double p1[NMX_NORM_SPF], p2[NMX_NORM_SPF];
-    unsigned pc[NMX_NORM_SPF];
 #ifndef NMX_HOST_EMU
 #pragma unroll
 #endif
-    for (int k = 0; k < NMX_NORM_SPF; ++k) {
-      const int r = r0 + k < n ? r0 + k : n - 1;
-      const long long o = (long long)r * nc + j;
-      xb[k] = A.rows[(long long)r * A.ld + j];
-      const bool own = r > grow;                      // (its Bk was written above; rows 0 .. grow share Bk[0])
-      p1[k] = own ? Sc.s1[o] : b1; p2[k] = own ? Sc.s2[o] : b2;
-      pc[k] = own ? Sc.cn[o] : ((unsigned)bc | ((unsigned)bi << 16));
-    }
-#ifndef NMX_HOST_EMU
-#pragma unroll
-#endif
-    for (int k = 0; k < NMX_NORM_SPF; ++k) {
-      const int r = r0 + k;
-      if (r >= n) continue;
-      const float x = xb[k];
-      const bool f = nmx_norm_finite(x);
-      const double xd = f ? (double)x : 0.0;
-      f1 += xd; f2 += xd * xd;
-      fc += f ? 1 : 0;
-      fi += (!f && x == x) ? 1 : 0;
-      const long long o = (long long)r * nc + j;
-      Sc.s1[o] = p1[k] + f1; Sc.s2[o] = p2[k] + f2;
-      Sc.cn[o] = ((pc[k] & 0xffffu) + (unsigned)fc) | (((pc[k] >> 16) + (unsigned)fi) << 16);
-      Sc.xs[o] = x;
-    }
+  for (int k = 0; k < NMX_NORM_SEG; ++k) {
+    const int r = lo + k;
+    if (r >= hi) continue;
+    const float x = xb[k];
+    const bool f = nmx_norm_finite(x);
+    const double xd = f ? (double)x : 0.0;
+    f1 += xd; f2 += xd * xd;
+    fc += f ? 1 : 0;
+    fi += (!f && x == x) ? 1 : 0;
+    const long long o = (long long)r * nc + j;
+    Sc.s1[o] = p1[k] + f1; Sc.s2[o] = p2[k] + f2;
+    Sc.cn[o] = ((pc[k] & 0xffffu) + (unsigned)fc) | (((pc[k] >> 16) + (unsigned)fi) << 16);
+    Sc.xs[o] = x;
+  }
+  const long long t = (long long)(Sc.n_hseg + g) * nc + j;
+  Sc.t1[t] = f1; Sc.t2[t] = f2; Sc.tc[t] = (unsigned)fc | ((unsigned)fi << 16);
+}
+
+// totals -> offsets: history segment g gets the sum of the segments NEWER than it (g' > g), batch segment g of the older ones
+NMX_DEV void nmx_norm_seg_offsets(const NmxNormArgs& A, const NmxNormScan& Sc, int j) {
+  if (j >= A.n_cols) return;
+  if (A.colmask && !A.colmask[j]) return;
+  const int nc = A.n_cols;
+  double a1 = 0.0, a2 = 0.0;
+  unsigned ac = 0u;
+  for (int g = Sc.n_hseg - 1; g >= 0; --g) {
+    const long long t = (long long)g * nc + j;
+    const double v1 = Sc.t1[t], v2 = Sc.t2[t];
+    const unsigned vc = Sc.tc[t];
+    Sc.t1[t] = a1; Sc.t2[t] = a2; Sc.tc[t] = ac;
+    a1 += v1; a2 += v2; ac += vc;   // (16-bit fields: counts <= cap < 65536 never carry)
+  }
+  a1 = 0.0; a2 = 0.0; ac = 0u;
+  for (int g = 0; g < Sc.n_bseg; ++g) {
+    const long long t = (long long)(Sc.n_hseg + g) * nc + j;
+    const double v1 = Sc.t1[t], v2 = Sc.t2[t];
+    const unsigned vc = Sc.tc[t];
+    Sc.t1[t] = a1; Sc.t2[t] = a2; Sc.tc[t] = ac;
+    a1 += v1; a2 += v2; ac += vc;
   }
 }
 
@@ -614,16 +655,24 @@ NMX_DEV void nmx_norm_scan_cell(const NmxNormArgs& A, const NmxNormScan& Sc, int
   if (A.colmask && !A.colmask[j]) return;
   const long long q = A.seq0 + r;
   if (q == 0) return;   // the first row ever is returned as it came
-  const long long o = (long long)r * A.n_cols + j;
+  const int nc = A.n_cols;
+  const long long o = (long long)r * nc + j;
   const double x = (double)Sc.xs[o];
-  const unsigned cn = Sc.cn[o];
+  const long long tb = (long long)(Sc.n_hseg + r / NMX_NORM_SEG) * nc + j;
+  double S1 = Sc.t1[tb], S2 = Sc.t2[tb];
+  unsigned cn = Sc.tc[tb];
+  if (Sc.have) {
+    const int d = r > Sc.grow ? r - Sc.grow : 0;
+    const long long th = (long long)(d / NMX_NORM_SEG) * nc + j;
+    S1 += Sc.t1[th]; S2 += Sc.t2[th]; cn += Sc.tc[th];
+  }
+  S1 += Sc.s1[o]; S2 += Sc.s2[o]; cn += Sc.cn[o];
   const int cnt = (int)(cn & 0xffffu), ninf = (int)(cn >> 16);
   double out;
   if (cnt + ninf == 0 || ninf > 0) {
     out = NAN;   // empty window, or +-inf inside it: mean +-inf / NaN, std NaN (see the header)
   } else {
     // sums / count as CORRECTLY rounded quotients (nmx_norm_column): a constant column gives mean == x, variance == 0
-    const double S1 = Sc.s1[o], S2 = Sc.s2[o];
     const double c = (double)cnt, rc = nmx_rcp_f64(c);
     double mean = S1 * rc;
     mean = fma(fma(-mean, c, S1), rc, mean);
@@ -637,12 +686,11 @@ NMX_DEV void nmx_norm_scan_cell(const NmxNormArgs& A, const NmxNormScan& Sc, int
         // cancellation (one-pass error ~ eps mean^2 / var): two passes over the window -- history rows from the ring
         // (untouched until nmx_norm_scan_ring), the batch's rows from the scratch copy (rare)
         const int cap = A.cap;
-        const long long have = A.seq0 < (long long)(cap - 1) ? A.seq0 : (long long)(cap - 1);
         long long t0 = q - (cap - 1);
-        if (t0 < A.seq0 - have) t0 = A.seq0 - have;
+        if (t0 < A.seq0 - Sc.have) t0 = A.seq0 - Sc.have;
         double acc = 0.0;
         for (long long t = t0; t <= q; ++t) {
-          const float h = t < A.seq0 ? A.ring[(t % cap) * A.n_cols + j] : Sc.xs[(t - A.seq0) * A.n_cols + j];
+          const float h = t < A.seq0 ? A.ring[(t % cap) * nc + j] : Sc.xs[(t - A.seq0) * nc + j];
           if (h == h) { const double d = (double)h - mean; acc += d * d; }
         }
         var = acc / c;

@@ -148,7 +148,11 @@ static void be_launch_norm(const NmxNormArgs& A, be_stream_t) {
   for (int j = 0; j < A.n_cols; ++j) nmx_norm_column(A, j);
 }
 static void be_launch_norm_scan(const NmxNormArgs& A, const NmxNormScan& S, be_stream_t) {
-  for (int j = 0; j < A.n_cols; ++j) nmx_norm_scan_column(A, S, j);
+  for (int g = 0; g < S.n_hseg; ++g)
+    for (int j = 0; j < A.n_cols; ++j) nmx_norm_seg_hist(A, S, g, j);
+  for (int g = 0; g < S.n_bseg; ++g)
+    for (int j = 0; j < A.n_cols; ++j) nmx_norm_seg_batch(A, S, g, j);
+  for (int j = 0; j < A.n_cols; ++j) nmx_norm_seg_offsets(A, S, j);
   for (int r = 0; r < A.n_rows; ++r)
     for (int j = 0; j < A.n_cols; ++j) nmx_norm_scan_cell(A, S, r, j);
   for (int r = 0; r < A.n_rows; ++r)

@@ -15,4 +15,4 @@ PY
 done
 rm -rf $O/prof_norm_$TAG
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_norm_$TAG -o p -- python bench.py --steps 5 --warmup 2 --cpu-windows 0 --no-cold-start --no-mode-a > $O/${TAG}_prof_norm.log 2>&1
-python tools/rocpd_summary.py $(ls $O/prof_norm_$TAG/*.db | head -1) $O/${TAG}_kernel_stats_norm.csv | grep -i "norm\|Name"
+python tools/rocpd_summary.py $(ls $O/prof_norm_$TAG/*.db | head -1) $O/${TAG}_kernel_stats_norm.csv | grep -i "norm\|Name"; python tools/rocpd_timeline.py $(ls $O/prof_norm_$TAG/*.db | head -1) 120 2>/dev/null > $O/${TAG}_norm_timeline.txt
