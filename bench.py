@@ -432,7 +432,8 @@ def main() -> None:
     ap.add_argument("--cpu-procs", type=int, default=32, help="worker processes of cpu_baseline_allcores (0 = skip)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start_ms measurement")
     ap.add_argument("--no-normalisation", action="store_true",
-                    help="skip the value_with_normalisation leg (kernel traces: its 256-hop chunks would mix with the headline's 1024-hop launches)")
+                    help="time the headline WITHOUT the reference's default z-score (kernel traces: the normalised plan works in "
+                         "384-hop chunks, which would mix with the 1024-hop launches the stage timers and rooflines are quoted on)")
     ap.add_argument("--no-mode-a", action="store_true", help="skip the roofline_modeA measurement (time / oscillatory kernel from HBM)")
     ap.add_argument("--no-preproc", action="store_true", help="skip notch + re-referencing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -518,44 +519,48 @@ def main() -> None:
         torch.cuda.synchronize(dev)
         cold_ms = (time.perf_counter() - tc) * 1e3
         cold.close()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    # EXACTLY args.steps steps, launched back to back (nothing on the host waits inside the timed region)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    dt = time.perf_counter() - t0
+    # The reference's DEFAULT pipeline ends in the feature normaliser (z-score over the last 30 s of feature rows,
+    # default_settings.yaml:69-78, processing/normalization.py:93-111): it runs INSIDE the plan's launch sequence and the
+    # headline is timed with it.  (`value_without_normalisation`: the same K steps with the normaliser detached.)
+    with_norm = not args.no_normalisation
+    dn = None
+    if with_norm:
+        from py_neuromodulation_amd.processing import DeviceFeatureNormalizer
+
+        sn = make_settings()
+        sn.postprocessing.feature_normalization = True
+        dn = DeviceFeatureNormalizer(sn, eng.n_outputs, device=dev_index)
+
+    def timed(k):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        # EXACTLY k steps, launched back to back (nothing on the host waits inside the timed region)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        return time.perf_counter() - t0
+
+    plain_dt = timed(args.steps)   # (also fills the 30 s burst history: steady state for the headline leg)
+    if with_norm:
+        eng.attach_normalizer(dn)
+        dt = timed(args.steps)
+        eng.attach_normalizer(None)
+    else:
+        dt = plain_dt
     # per-stage HIP-event times (recorded on the launch stream inside libnmx): a few more steps OUTSIDE the timed region --
-    # reading an event waits for it, which would serialise the host against every step above
+    # reading an event waits for it, which would serialise the host against every step above.  Normaliser detached: a
+    # step is then ONE launch sequence of 1024 hops and a stage's timer brackets the kernel(s) of the whole step (with it
+    # the plan works in chunks of 384 hops and the timers hold the last chunk's)
     kt = {k: 0.0 for k in ("prep", "timeosc", "bank", "bank_sw", "bursts", "sharp", "batch")}
     n_kt = min(10, args.steps)
     for _ in range(n_kt):
         step()
         for name, idx in (("batch", 0), ("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6), ("bursts", 4), ("sharp", 5)):
             kt[name] += eng.timing_ms(idx)
-    # the reference's default post-processing (z-score over the last 30 s of feature rows, default_settings.yaml:69-78)
-    # inside the plan's launch sequence: the same K steps once more, reported next to `value`
-    norm_dt = None
-    if world == 1 and not args.no_normalisation:
-        from py_neuromodulation_amd.processing import DeviceFeatureNormalizer
-
-        sn = make_settings()
-        sn.postprocessing.feature_normalization = True
-        dn = DeviceFeatureNormalizer(sn, eng.n_outputs, device=dev_index)
-        eng.attach_normalizer(dn)
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize(dev)
-        tn = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        norm_dt = time.perf_counter() - tn
-        eng.attach_normalizer(None)
     dt_own = dt
     rank_ms = None
     if world > 1:
@@ -597,13 +602,17 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{C}ch/GPU @1kHz, W={W}, hop={hop}, {n_win} hops/step, all 9 hot-path "
-                                   f"features, 4 bands, {'notch50+CAR' if pre else 'no preprocessing'}",
+                                   f"features, 4 bands, {'notch50+CAR' if pre else 'no preprocessing'}"
+                                   f"{', z-score normalisation' if with_norm else ''}",
                        "channels_per_gpu": C, "windows_per_step": n_win, "features_per_window": F,
                        "parallelism": f"channel-shard x{world}, no collective"},
             "features_per_sec": value * F,
             "algorithmic_GBps_pipeline": value / world * C * bytes_cw / 1e9,
-            "value_with_normalisation": (args.steps * n_win / norm_dt) if norm_dt else None,   # + the default z-score (N = 1)
-            "ms_per_step_with_normalisation": (norm_dt / args.steps * 1e3) if norm_dt else None,
+            # (this rank's clock; `value` is the slowest rank's)
+            "value_without_normalisation": args.steps * n_win * world / plain_dt,
+            "ms_per_step_without_normalisation": plain_dt / args.steps * 1e3,
+            "normalisation": ("zscore over 30 s of feature rows inside the plan (default_settings.yaml:69-78)"
+                              if with_norm else "none (--no-normalisation)"),
             "kernel_ms_per_step": {k: v / n_kt for k, v in kt.items()},
             "ms_per_step_by_rank": rank_ms,   # (N > 1: every rank's own wall time per step; `value` uses the slowest)
             "nan_outputs": bad,

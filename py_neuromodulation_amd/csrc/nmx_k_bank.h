@@ -61,6 +61,10 @@ struct NmxBankArgs {
   int n_sw_filters;
   float* sw_out;    // [n_windows][C][n_sw_filters][W]
   float* y_out;     // notch: [n_windows][C][W]
+  int residual;     // notch in residual form: the taps are g = delta - h and what is stored is x - g * x_ext.  The rounding
+                    // of an fp32 FFT convolution is relative to what passes it: the whole signal for h, the few Hz around
+                    // the line for g -- a tenth of it for broadband data -- and the STFT's near-null bins under log10 see
+                    // the difference (headline: 0.82 % of the STFT entries beyond 1e-5 with h)
   // LDS carve (float offsets)
   int off_X, off_a, off_b, off_red, lds_floats;
   // PARTITIONED mode (partitioned != 0: windows x taps whose FFT convolution does not fit one LDS transform -- >= 6 kHz
@@ -175,8 +179,12 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
           F.store_raw ? A.y_out + ((long long)w * A.n_channels + c) * W : nullptr,
           F.burst_index >= 0 ? A.yb_out + (((long long)w * A.n_channels + c) * A.n_burst_bands + F.burst_index) * W : nullptr};
       for (int d = 0; d < 3; ++d)
-        if (dsts[d])
-          for (int i = NMX_TID; i < W; i += NMX_NT) dsts[d][i] = y[i];
+        if (dsts[d]) {
+          if (d == 1 && A.residual)
+            for (int i = NMX_TID; i < W; i += NMX_NT) dsts[d][i] = (A.clean_on_load ? nmx_clean(src[i]) : src[i]) - y[i];
+          else
+            for (int i = NMX_TID; i < W; i += NMX_NT) dsts[d][i] = y[i];
+        }
       NMX_SYNC();
     }
     return;
@@ -267,7 +275,10 @@ NMX_DEV void nmx_bank_item(const NmxBankArgs& A, int w, int c, float* smem, int 
     }
     if (F.store_raw) {
       float* dst = A.y_out + ((long long)w * A.n_channels + c) * W;
-      for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = y[i];
+      if (A.residual)
+        for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = (A.clean_on_load ? nmx_clean(src[i]) : src[i]) - y[i];
+      else
+        for (int i = NMX_TID; i < W; i += NMX_NT) dst[i] = y[i];
     }
     if (F.burst_index >= 0) {  // ---- |hilbert(y)| (bursts.py:153), exact length-W transform ----
       const int Wh = W >> 1;

@@ -753,7 +753,14 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         NMX_UNROLL
         for (int i = 0; i < 16; ++i) {
           const int s0 = 2 * (l + 64 * (i >> 2) + 256 * (i & 3)) - yoff;
-          const nmx_c2 val = v[0][i];
+          nmx_c2 val = v[0][i];
+          if (A.residual) {   // x - g * x_ext (NmxBankArgs::residual): the window's samples again, from L2
+            const nmx_rsrc rx = nmx_make_rsrc(src, 4 * W);
+            nmx_c2 xw = nmx_mk2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, 4 * s0, 0, 0)),
+                                __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, 4 * s0 + 4, 0, 0)));
+            if (A.clean_on_load) xw = nmx_mk2(nmx_clean_bl(xw.x), nmx_clean_bl(xw.y));
+            val = xw - val;
+          }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val.x), rd, 4 * s0, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val.y), rd, 4 * s0 + 4, 0, 0);
         }
@@ -765,8 +772,10 @@ NMX_DEV void nmx_bank_w64_item(const NmxBankW64Args& AA, int w, int c, float* sm
         for (int i = 0; i < 16; ++i) {
           const int s0 = 2 * (l + 64 * (i >> 2) + 256 * (i & 3));
           const nmx_c2 val = v[NMX_LI][i];
-          if (s0 >= yoff && s0 < W + yoff) d2[s0] = val.x;
-          if (s0 + 1 >= yoff && s0 + 1 < W + yoff) d2[s0 + 1] = val.y;
+          if (s0 >= yoff && s0 < W + yoff)
+            d2[s0] = A.residual ? (A.clean_on_load ? nmx_clean(src[s0 - yoff]) : src[s0 - yoff]) - val.x : val.x;
+          if (s0 + 1 >= yoff && s0 + 1 < W + yoff)
+            d2[s0 + 1] = A.residual ? (A.clean_on_load ? nmx_clean(src[s0 + 1 - yoff]) : src[s0 + 1 - yoff]) - val.y : val.y;
         }
       }
 #endif

@@ -350,7 +350,13 @@ NMX_DEV void nmx_bank_w64e_item(const NmxBankW64Args& AA, int w, int c, const Nm
     const nmx_rsrc s2 = nmx_make_rsrc(d + W, two ? 4 * W : 0);
     NMX_UNROLL
     for (int j = 0; j < 16; ++j) {
-      const nmx_c2 y = v[j] * unscale;
+      nmx_c2 y = v[j] * unscale;
+      if (A.residual) {   // x - g * x_ext (NmxBankArgs::residual): the window's samples again, from L2 (0 beyond the row)
+        nmx_c2 xw = nmx_mk2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, 4 * l + 256 * j, 0, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, 4 * l + 256 * j, 0, 0)));
+        if (A.clean_on_load) xw = nmx_mk2(nmx_clean_bl(xw.x), nmx_clean_bl(xw.y));
+        y = xw - y;
+      }
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y.x), s1, 4 * l + 256 * j, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y.y), s2, 4 * l + 256 * j, 0, 0);
     }

@@ -615,7 +615,8 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     # chunk boundary every 9 hops
     for knobs in ({"NMX_BANK_W64C": "0"}, {"NMX_BANK_W64E": "0"}, {"NMX_BANK_W64C": "0", "NMX_BANK_W64E": "0"}, {"NMX_SW_DENSE": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
                   {"NMX_OVERLAP": "2"}, {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_TIMEOSC_W1000": "0"},
-                  {"NMX_TOW_PERSISTENT": "0"}, {"NMX_CHUNK_WINDOWS": "9"}, {"NMX_WAVES_PER_WG": "1"}, {"NMX_WAVES_PER_WG": "3"}):
+                  {"NMX_TOW_PERSISTENT": "0"}, {"NMX_CHUNK_WINDOWS": "9"}, {"NMX_WAVES_PER_WG": "1"}, {"NMX_WAVES_PER_WG": "3"},
+                  {"NMX_NOTCH_RESIDUAL": "0"}, {"NMX_NOTCH_RESIDUAL": "0", "NMX_BANK_W64E": "0"}):
         for knob, val in knobs.items():
             monkeypatch.setenv(knob, val)
         _, keys2, got = run()

@@ -10,7 +10,7 @@ for v in 1 0; do
   python - <<PY
 import json
 d=json.load(open("$O/${TAG}_norm_scan$v.json"))
-print("NMX_NORM_SCAN=$v", "value", round(d["value"]), "ms", round(d["ms_per_step"],3), "with norm", round(d["value_with_normalisation"]), round(d["ms_per_step_with_normalisation"],3))
+print("NMX_NORM_SCAN=$v", "value", round(d["value_without_normalisation"]), "ms", round(d["ms_per_step_without_normalisation"],3), "with norm", round(d["value"]), round(d["ms_per_step"],3))
 PY
 done
 rm -rf $O/prof_norm_$TAG

@@ -10,7 +10,7 @@ run() {  # label, env...
   python - <<PY
 import json
 d=json.load(open("$O/tmp_bench.json"))
-print("$label", "value", round(d["value"]), "ms", round(d["ms_per_step"],3), "with norm", round(d["value_with_normalisation"]), round(d["ms_per_step_with_normalisation"],3), "ratio", round(d["value_with_normalisation"]/d["value"],4))
+print("$label", "value", round(d["value_without_normalisation"]), "ms", round(d["ms_per_step_without_normalisation"],3), "with norm", round(d["value"]), round(d["ms_per_step"],3), "ratio", round(d["value"]/d["value_without_normalisation"],4))
 PY
 }
 for rep in 1 2; do
