@@ -125,25 +125,31 @@ def max_rel_err(eng_factory, x64, rows, W, hop):
     return out
 
 
-# Ceilings of max_rel_err's share of entries above 1e-5 per feature family on the headline workload (50 hops x 256
-# channels against the float64 oracle): what round 5 measured (profiles/r05_bench_1gpu.json) with a factor ~2 of headroom.
-# The smooth families are at zero; STFT / Welch / sharp waves keep the entries the conditioning reports of tests/parity.py
-# explain (bins at a spectral null under log10, extrema decided by an ulp).  A run above a ceiling FAILS the bench.
-PARITY_CEILINGS = {"RawHjorth": 0.0, "raw": 0.0, "LineLength": 0.0, "fft": 2e-4, "welch": 1e-3, "stft": 1.6e-2,
-                   "bandpass": 1e-4, "Sharpwave": 4e-4, "bursts": 4e-4}
+# Ceilings of max_rel_err per feature family on the headline workload (48 hops x 256 channels against the float64 oracle):
+# (share of entries above 1e-5, maximum), set to what round 6 measured (profiles/r06_bench_1gpu.json) + 25 % / x 2 -- the
+# computation is deterministic, the headroom is for a different draw of near-null bins after a code change, not for drift.
+# The smooth families sit at 2 - 8e-7; STFT / Welch / sharp waves keep the entries the conditioning reports of
+# tests/parity.py explain (bins at a spectral null under log10: 124 of 51 200 STFT entries, 1 Welch entry; extrema decided
+# by an ulp: 5 of 76 800).  A run above a ceiling FAILS the bench (exit code 3).
+PARITY_CEILINGS = {"RawHjorth": (0.0, 2e-6), "raw": (0.0, 2e-6), "LineLength": (0.0, 2e-6), "fft": (2e-5, 5e-6),
+                   "welch": (8e-5, 5e-5), "stft": (3.0e-3, 0.1), "bandpass": (0.0, 2e-6), "Sharpwave": (1e-4, 2e-2),
+                   "bursts": (2e-5, 5e-6)}
 
 
 def parity_gate(err: dict) -> dict:
     bad = {}
-    for fam, lim in PARITY_CEILINGS.items():
+    for fam, (lim, lim_max) in PARITY_CEILINGS.items():
         e = err.get(fam)
         if not e:
             continue
         if e["share_above_1e-5"] is not None and e["share_above_1e-5"] > lim:
             bad[fam] = {"share_above_1e-5": e["share_above_1e-5"], "ceiling": lim}
+        if e["max"] is not None and e["max"] > lim_max:
+            bad.setdefault(fam, {}).update({"max": e["max"], "max_ceiling": lim_max})
         if e["nonfinite_mismatch"]:
             bad.setdefault(fam, {})["nonfinite_mismatch"] = e["nonfinite_mismatch"]
-    return {"ok": not bad, "ceilings": PARITY_CEILINGS, "violations": bad}
+    return {"ok": not bad, "ceilings": {k: {"share_above_1e-5": v[0], "max": v[1]} for k, v in PARITY_CEILINGS.items()},
+            "violations": bad}
 
 
 def _allcores_worker(args):

@@ -313,6 +313,16 @@ NMX_DEV void nmx_bank_w64e_item(const NmxBankW64Args& AA, int w, int c, const Nm
       }
     }
   }
+  // the notch in residual form (NmxBankArgs::residual) stores x - g * x_ext: the window's samples stay in registers
+  // (the workgroup's exchange tiles bound the kernel at two waves per SIMD: 256 VGPRs each, 158 in use without them;
+  // re-reading them from L2 behind the inverse transform cost 0.15 ms of the 0.71 ms launch)
+  // (the table-driven form of the reflection is at 236 VGPRs already: it reads them again)
+  constexpr bool KEEP = PAD && WC;
+  nmx_c2 keep[KEEP ? 16 : 1];
+  if constexpr (KEEP) {
+    NMX_UNROLL
+    for (int j = 0; j < 16; ++j) keep[j] = v[j];
+  }
   // ---- the second channel at the first one's scale: an exact power of two (nmx_k_bank_w64c.h) ------------------------
   float m1 = 0.f, m2 = 0.f;
   NMX_UNROLL
@@ -351,11 +361,15 @@ NMX_DEV void nmx_bank_w64e_item(const NmxBankW64Args& AA, int w, int c, const Nm
     NMX_UNROLL
     for (int j = 0; j < 16; ++j) {
       nmx_c2 y = v[j] * unscale;
-      if (A.residual) {   // x - g * x_ext (NmxBankArgs::residual): the window's samples again, from L2 (0 beyond the row)
-        nmx_c2 xw = nmx_mk2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, 4 * l + 256 * j, 0, 0)),
-                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, 4 * l + 256 * j, 0, 0)));
-        if (A.clean_on_load) xw = nmx_mk2(nmx_clean_bl(xw.x), nmx_clean_bl(xw.y));
-        y = xw - y;
+      if (A.residual) {
+        if constexpr (KEEP) {
+          y = keep[j] - y;   // (lanes beyond the window's end hold flank samples: their stores are out of range)
+        } else {
+          nmx_c2 xw = nmx_mk2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, 4 * l + 256 * j, 0, 0)),
+                              __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, 4 * l + 256 * j, 0, 0)));
+          if (A.clean_on_load) xw = nmx_mk2(nmx_clean_bl(xw.x), nmx_clean_bl(xw.y));
+          y = xw - y;
+        }
       }
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y.x), s1, 4 * l + 256 * j, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y.y), s2, 4 * l + 256 * j, 0, 0);
