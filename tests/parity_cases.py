@@ -2436,3 +2436,55 @@ def case_inf_members(lib, run=None, tag=""):
             assert n_bad == 0, f"{name}, hop {r}\n{rep}"
         patterns[name] = cls_g
     return patterns
+
+
+# ---- drift is not an offset: the engine's split carries one CONSTANT per row (nmx_engine_dc.inc) ----------------------------
+def case_trends(lib):
+    """Recordings that wander: a 0.3 Hz swell of 10^3 spreads, one of 10^4, a linear drift that reaches 10^4 spreads over the
+    recording -- next to two well-behaved rows.  A window of such a row holds values hundreds to thousands of times its
+    signal, and a float32 sample rounds at the VALUE's size: what every feature then reads carries that rounding (a
+    per-row linear term would have to travel through every kernel's sums like the constant does; it does not).  The
+    policy's noise levels are those of what the samples hold (tests/parity.py: `Verifier._held`), so the misses are
+    explained entry by entry -- this case COUNTS them, per row, so that the budget file shows what a trend costs:
+    the quiet rows must not miss at all, the wandering rows' smooth time-domain features stay within 1e-3."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.stream import Stream
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    for f in ("raw_hjorth", "fft", "welch", "stft", "linelength", "return_raw"):
+        setattr(s.features, f, True)
+    s.preprocessing = []
+    s.postprocessing.feature_normalization = False
+    s.sampling_rate_features_hz = 5
+    T, sigma = 5000, 50.0
+    rng = np.random.default_rng(91)
+    t = np.arange(T) / 1000.0
+    data = rng.standard_normal((5, T)) * sigma + 8 * np.sin(2 * np.pi * 21 * t)
+    data[1] += 1e3 * sigma * np.sin(2 * np.pi * 0.3 * t + 0.4)
+    data[2] += 1e4 * sigma * np.sin(2 * np.pi * 0.3 * t + 2.0)
+    data[3] += 1e4 * sigma * (t / t[-1])
+    data = data.astype(np.float32).astype(np.float64)   # identical windows on both sides
+    ch = {"name": [f"ch{i}" for i in range(5)], "rereference": ["None"] * 5, "used": [1] * 5, "target": [0] * 5,
+          "type": ["ecog"] * 5, "status": ["good"] * 5, "new_name": [f"ch{i}" for i in range(5)]}
+    df = Stream(1000.0, channels=ch, settings=s, line_noise=50, lib=lib).run(data, save_csv=False)
+    rows = orc.run_stream(data, 1000.0, s, ch)
+    cols = list(df.columns)
+    assert cols == list(rows[0].keys())
+    got = df.to_numpy(float)
+    starts, ends, _ = orc.window_schedule(T, 1000.0, s.sampling_rate_features_hz, s.segment_length_features_ms)
+    pv = parity.PipelineVerifiers(s, ch, 1000.0, data, starts, 1000, line_noise=50)
+    before = dict(parity.STATS["forgiven"])
+    quiet = [i for i, c in enumerate(cols) if c.startswith("ch0_") or c.startswith("ch4_")]
+    for r in range(len(rows)):
+        want = np.array([rows[r][c] for c in cols])
+        n_bad, rep, _ = parity.compare([cols[i] for i in quiet], got[r, quiet], want[quiet], s, 1000.0, 4 * sigma, 1000)
+        assert n_bad == 0, f"quiet rows, hop {r} (no verifier)\n{rep}"
+        wander = [i for i in range(len(cols) - 1) if i not in quiet]
+        n_bad, rep, _ = parity.compare([cols[i] for i in wander], got[r, wander], want[wander], s, 1000.0, 1e4 * sigma, 1000,
+                                       verifier=pv.row(r))
+        assert n_bad == 0, f"wandering rows, hop {r}\n{rep}"
+        smooth = [i for i in wander if parity.family_of(cols[i]) in ("hjorth", "linelength")]
+        np.testing.assert_allclose(got[r, smooth], want[smooth], rtol=1e-3)
+    return {k: v - before.get(k, 0) for k, v in parity.STATS["forgiven"].items()}

@@ -146,6 +146,60 @@ def test_matrix_pipe_spectrum_kernel(gpu_lib, monkeypatch):
             assert n_bad == 0, f"{tag} hop {i}\n{rep}"
 
 
+@pytest.mark.parametrize("C,n_hops", [(1, 1), (1, 17), (3, 15), (3, 16), (3, 4095), (255, 17), (257, 1), (257, 16)])
+def test_matrix_pipe_spectrum_kernel_ragged_shapes(gpu_lib, C, n_hops):
+    """nmx_kern_specmm_w1000 works on tiles of 16 consecutive windows of one channel, four tiles per workgroup, one
+    persistent workgroup per CU: channel counts around a multiple of the wave count and window counts around a multiple
+    of the tile (1, 15, 16, 17, 4095: a last tile with 1 / 15 live columns), with a NaN and an infinity inside the LAST
+    tile (its `todo` mask: the wave-level kernel redoes exactly those windows) and in the first.  Every window against
+    the float64 oracle under the standard policy."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+    sfreq, hop = 1000.0, 8 if n_hops > 1000 else 100
+    T = 1000 + (n_hops - 1) * hop
+    rng = np.random.default_rng(1000 * C + n_hops)
+    t = np.arange(T) / sfreq
+    x = (rng.standard_normal((C, T)) * 50 + 10 * np.sin(2 * np.pi * 20 * t) + rng.uniform(-500, 500, (C, 1))).astype(np.float32)
+    x[C - 1, T - 3] = np.nan            # the last window(s) of the last channel
+    x[0, 5] = np.inf                    # the first window of the first
+    if n_hops > 16:
+        x[C // 2, 16 * hop + 999] = -np.inf   # a window of the second tile only
+    ch = [f"ch{i}" for i in range(C)]
+    starts = np.arange(n_hops) * hop
+    eng = HotPathEngine(s, ch, sfreq, lib=gpu_lib)
+    got = eng.process_batch(x, starts)
+    assert "nmx_kern_specmm_w1000" in eng.kernels(2), eng.kernels(2)
+    keys = list(eng.keys)
+    eng.close()
+    assert not np.isnan(got).any()
+    feats = [orc._FEATURE_CLS[f](s, ch, sfreq) for f in s.features.get_enabled()]
+    # (4095 hops: every 13th window and everything around the tile / batch ends)
+    pick = range(n_hops) if n_hops <= 64 else sorted(set(range(0, n_hops, 13)) | set(range(40)) | set(range(n_hops - 40, n_hops)))
+    for i in pick:
+        w = np.nan_to_num(x[:, starts[i]:starts[i] + 1000].astype(np.float64))
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(w))
+        assert list(want) == keys
+        # a channel with an infinity in this window sits on the rail (+-FLT_MAX here, +-DBL_MAX there): its features are
+        # rail-derived on both scales (tests/parity_cases.py: case_inf_members) -- here only "not NaN, not ordinary"
+        railed = {ch[c] for c in np.flatnonzero(np.isinf(x[:, starts[i]:starts[i] + 1000]).any(axis=1))}
+        keep = [k for k, key in enumerate(keys) if not any(key.startswith(r + "_") for r in railed)]
+        for k, key in enumerate(keys):
+            if k not in keep and ("Activity" in key or "LineLength" in key or "_fft_" in key):
+                assert abs(float(got[i][k])) > 1e6, (i, key, got[i][k])
+        ver = parity.Verifier(s, ch, sfreq, w)
+        wv = list(want.values())
+        n_bad, rep, _ = parity.compare([keys[k] for k in keep], got[i][keep], [wv[k] for k in keep], s, sfreq, 600.0, 1000,
+                                       verifier=ver)
+        assert n_bad == 0, f"C = {C}, {n_hops} hops, hop {i}\n{rep}"
+
+
 def test_pipeline_readme_no_normalisation(gpu_lib):
     pc.case_pipeline_readme_no_normalisation(gpu_lib)
 
@@ -884,6 +938,11 @@ def test_real_recording_of_the_reference_tests(gpu_lib, devices):
 @pytest.mark.parametrize("tag", ["", "stft_"])
 def test_reref_group_members_on_the_rail(gpu_lib, tag):
     pc.case_inf_members(gpu_lib, tag=tag)
+
+
+def test_trends_are_counted_not_hidden(gpu_lib):
+    acc = pc.case_trends(gpu_lib)
+    assert sum(acc.values()) <= 40, acc   # (emulator 11, all Welch bins at 1e-4 of the swell's leakage; see the budget file)
 
 
 def test_abi_from_plain_c_on_the_gpu(tmp_path):

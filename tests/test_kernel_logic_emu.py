@@ -285,3 +285,8 @@ def test_failed_run_leaves_no_side_files(emu_lib, tmp_path, monkeypatch):
     monkeypatch.undo()
     st.run(out_dir=tmp_path, experiment_name="subx", save_csv=False)
     assert sorted(p.name for p in (tmp_path / "subx").iterdir()) == ["subx_SETTINGS.yaml", "subx_SIDECAR.json", "subx_channels.csv"]
+
+
+def test_trends_are_counted_not_hidden(emu_lib):
+    acc = pc.case_trends(emu_lib)
+    assert sum(acc.values()) <= 40, acc   # (emulator 11, all Welch bins at 1e-4 of the swell's leakage; see the budget file)
