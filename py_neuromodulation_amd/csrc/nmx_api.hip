@@ -110,9 +110,10 @@ __global__ void __launch_bounds__(64) nmx_kern_power(const NmxPowerArgs A) {
 __global__ void __launch_bounds__(256) nmx_kern_power_ring(const NmxPowerPrepArgs P) {
   nmx_power_ring_at(P, (int)blockIdx.x, (int)(blockIdx.y * 256 + threadIdx.x));
 }
-__global__ void __launch_bounds__(256) nmx_kern_car(const NmxCarArgs A) {
-  __shared__ double red[256];
-  nmx_car_tile(A, (long long)blockIdx.x * 64, red);
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) nmx_kern_car(const NmxCarArgs A) {
+  __shared__ double red[64 * NW];
+  nmx_car_tile<NW>(A, (long long)blockIdx.x * 64, red);
 }
 __global__ void __launch_bounds__(256) nmx_kern_reref_struct(const NmxRerefStructArgs A) {
   __shared__ double red[NMX_RS_GROUPS * 256];
@@ -544,7 +545,8 @@ static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be
   hipLaunchKernelGGL(nmx_kern_power_ring, dim3((unsigned)P.n_rows, gy), dim3(256), 0, s, P);
 }
 static void be_launch_car(const NmxCarArgs& A, be_stream_t s) {
-  hipLaunchKernelGGL(nmx_kern_car, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
+  if (A.T <= 4096 && A.C >= 64) hipLaunchKernelGGL(nmx_kern_car<16>, dim3((unsigned)((A.T + 63) / 64)), dim3(1024), 0, s, A);
+  else hipLaunchKernelGGL(nmx_kern_car<4>, dim3((unsigned)((A.T + 63) / 64)), dim3(256), 0, s, A);
   nmxi_note_kernel("nmx_kern_car");
 }
 static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t s) {

@@ -101,33 +101,65 @@ NMX_DEV void nmx_car_sample(const NmxCarArgs& A, long long t) {
 // (a quarter of the column), the four partial sums meet in LDS, then every wave writes its own channels.
 // Four times the waves of the one-thread-per-sample form and loops a quarter as long: the kernel was
 // latency bound at 1.6 waves per SIMD (0.21 ms for 105 MB in + 105 MB out).
+// The column sum is formed per CLASS k = channel mod 16, ascending inside a class, then ((c_q + c_(q+4)) + c_(q+8)) + c_(q+12)
+// for q = 0 .. 3, then (q0 + q1) + (q2 + q3) -- whatever the number of waves: NW = 4 for a stream (a wave keeps its four
+// classes in four accumulators: four independent chains), NW = 16 for the one-window call (16 workgroups in all: the 64 loop
+// trips of a wave's quarter of 256 channels were 60 of that call's 450 us; here a wave owns one class).  A window and the
+// stream it was cut from see the same average to the last bit.
+template <int NW = 4>
 NMX_DEV void nmx_car_tile(const NmxCarArgs& A, long long t0, double* red) {
+  static_assert(NW == 4 || NW == 16, "waves per workgroup");
   const int lane = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
   const long long t = t0 + lane;
   const bool in = t < A.T;
   const double o = (double)A.off;
+  auto term = [&](int j) { return o * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j); };
   double s = 0.0;
   if (in) {
-    int j = q;
-    for (; j + 12 < A.C; j += 16) {   // four independent loads in flight
-      const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 4) * A.ldx + t];
-      const float v2 = A.x[(long long)(j + 8) * A.ldx + t], v3 = A.x[(long long)(j + 12) * A.ldx + t];
-      if (A.sub || A.nanv) {
-        s += o * (double)nmx_clean_sub(v0, A.sub, A.nanv, j); s += o * (double)nmx_clean_sub(v1, A.sub, A.nanv, j + 4);
-        s += o * (double)nmx_clean_sub(v2, A.sub, A.nanv, j + 8); s += o * (double)nmx_clean_sub(v3, A.sub, A.nanv, j + 12);
-      } else {
-        s += o * (double)nmx_clean(v0); s += o * (double)nmx_clean(v1);
-        s += o * (double)nmx_clean(v2); s += o * (double)nmx_clean(v3);
+    if (NW == 4) {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;   // classes q, q + 4, q + 8, q + 12
+      int j = q;
+      for (; j + 12 < A.C; j += 16) {   // four independent loads in flight, four independent sums
+        const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 4) * A.ldx + t];
+        const float v2 = A.x[(long long)(j + 8) * A.ldx + t], v3 = A.x[(long long)(j + 12) * A.ldx + t];
+        if (A.sub || A.nanv) {
+          c0 += o * (double)nmx_clean_sub(v0, A.sub, A.nanv, j); c1 += o * (double)nmx_clean_sub(v1, A.sub, A.nanv, j + 4);
+          c2 += o * (double)nmx_clean_sub(v2, A.sub, A.nanv, j + 8); c3 += o * (double)nmx_clean_sub(v3, A.sub, A.nanv, j + 12);
+        } else {
+          c0 += o * (double)nmx_clean(v0); c1 += o * (double)nmx_clean(v1);
+          c2 += o * (double)nmx_clean(v2); c3 += o * (double)nmx_clean(v3);
+        }
       }
+      if (j < A.C) c0 += term(j);
+      if (j + 4 < A.C) c1 += term(j + 4);
+      if (j + 8 < A.C) c2 += term(j + 8);
+      s = ((c0 + c1) + c2) + c3;
+    } else {
+      int j = q;
+      for (; j + 48 < A.C; j += 64) {   // one class: ascending, four loads in flight
+        const float v0 = A.x[(long long)j * A.ldx + t], v1 = A.x[(long long)(j + 16) * A.ldx + t];
+        const float v2 = A.x[(long long)(j + 32) * A.ldx + t], v3 = A.x[(long long)(j + 48) * A.ldx + t];
+        s += o * (double)nmx_clean_sub(v0, A.sub, A.nanv, j); s += o * (double)nmx_clean_sub(v1, A.sub, A.nanv, j + 16);
+        s += o * (double)nmx_clean_sub(v2, A.sub, A.nanv, j + 32); s += o * (double)nmx_clean_sub(v3, A.sub, A.nanv, j + 48);
+      }
+      for (; j < A.C; j += 16) s += term(j);
     }
-    for (; j < A.C; j += 4) s += o * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j);
   }
   red[q * 64 + lane] = s;
   __syncthreads();
-  const double b = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
   if (!in) return;
+  double b;
+  if (NW == 4) {
+    b = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  } else {
+    double p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      p[k] = ((red[k * 64 + lane] + red[(k + 4) * 64 + lane]) + red[(k + 8) * 64 + lane]) + red[(k + 12) * 64 + lane];
+    b = (p[0] + p[1]) + (p[2] + p[3]);
+  }
   const double a = (double)A.diag - (double)A.off;
-  for (int j = q; j < A.C; j += 4)
+  for (int j = q; j < A.C; j += NW)
     A.y[(long long)j * A.ldy + t] = nmx_reref_store(a * (double)nmx_clean_sub(A.x[(long long)j * A.ldx + t], A.sub, A.nanv, j) + b);
 }
 #endif

@@ -64,6 +64,9 @@ def main(n_calls=500):
         row = {"channels": C, "features": len(dp.keys),
                "engine_process_window": pct(time_calls(lambda: dp.engine.process_window(data), n_calls)),
                "DataProcessor_process_dict": pct(time_calls(lambda: dp.process(data), n_calls))}
+        row["kernels"] = {name: dp.engine.kernels(i) for name, i in (("prep", 1), ("timeosc", 2), ("bank", 3), ("bank_sw", 6),
+                                                                      ("bursts", 4), ("sharp", 5)) if dp.engine.kernels(i)}
+        row["device_ms_last_call"] = round(dp.engine.timing_ms(0), 4)
         o = orc.DataProcessor(1000.0, s, channels.to_dict("list"), line_noise=50)
         n_o = 30 if C <= 6 else 6
         row["oracle_process_cpu_1core"] = pct(time_calls(lambda: o.process(data), n_o, warm=2))
