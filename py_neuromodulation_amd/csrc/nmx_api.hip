@@ -1,6 +1,8 @@
 // nmx_api.hip -- libnmx.so: HIP (gfx950) backend + C ABI.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC nmx_api.hip -o ../libnmx.so
 // There is no CPU path in this library: every entry point that computes launches kernels.
+#include <chrono>
+#include <thread>
 #include <hip/hip_runtime.h>
 
 #include "nmx_k_bank.h"
@@ -296,6 +298,32 @@ static void be_memset_async(void* d, int v, size_t n, be_stream_t st) { BE_TRY(h
 // a host function in stream order (runs once everything enqueued on `st` before it has completed)
 static void be_host_fn(be_stream_t st, void (*fn)(void*), void* arg) { BE_TRY(hipLaunchHostFunc(st, fn, arg)); }
 static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
+// The wait at the end of a host-memory batch, with a watchdog: hipStreamSynchronize has no timeout, and a kernel that never
+// ends (round 4 saw ONE such run of the knob sweep in tests/test_gpu_parity.py, never reproduced: profiles/r05_hang_soak.txt)
+// leaves a caller that says nothing.  Polls the stream instead -- spinning for the first 200 us (the one-window call of a
+// real-time loop returns sooner than through the blocking wait), then sleeping 50 us at a time -- and gives up after
+// NMX_SYNC_TIMEOUT_S (default 300; 0: wait for ever) with the stage-by-stage kernel lists of the batch in the message.
+static int be_sync_watch(be_stream_t st, const std::string* kernels, int n_lists) {
+  static const double limit = [] {
+    const char* v = getenv("NMX_SYNC_TIMEOUT_S");
+    return (v && ((v[0] >= '0' && v[0] <= '9') || v[0] == '.')) ? atof(v) : 300.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return be_hip(q, "hipStreamQuery");
+    (void)hipGetLastError();   // (hipErrorNotReady is sticky in the thread's last-error slot)
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (limit > 0.0 && el > limit) {
+      std::string msg = "the device did not finish a batch within " + std::to_string((int)limit) + " s (NMX_SYNC_TIMEOUT_S); kernels of the last launch sequence:";
+      for (int i = 1; i < n_lists; ++i)
+        if (kernels && !kernels[i].empty()) msg += " [stage " + std::to_string(i) + ": " + kernels[i] + "]";
+      return nmx_fail(NMX_E_HIP, msg);
+    }
+    if (el > 200e-6) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
 static void be_sync_quiet(be_stream_t st) { if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError(); }   // (error paths: the first message stays)
 static be_stream_t be_stream_create() {
   hipStream_t s = nullptr;

@@ -38,8 +38,6 @@
 
 #include "nmx_device.h"
 
-#ifndef NMX_HOST_EMU
-
 // (nmx_common.h: NMX_SMM_NG = 63 table granules of four n -- n < 250 live, 250 / 251 zero --, NMX_SMM_TAB_FLOATS:
 // [class: cos even, cos odd, sin even, sin odd][G][row 16][t 4])
 #define NMX_SMM_STEP_BYTES 8192                         // 16 windows x 4 streams x 128 bytes
@@ -50,8 +48,6 @@
 #define NMX_SMM_WAVES 4
 #define NMX_SMM_LDS_BYTES (NMX_SMM_WAVES * NMX_SMM_WAVE_BYTES)       // 163 840 = all of it at five slots
 static_assert(NMX_SMM_RING >= 3 && NMX_SMM_RING <= 5, "ring depth");
-
-typedef float nmx_v4 __attribute__((ext_vector_type(4)));
 
 static inline bool nmx_specmm_ok(const NmxTimeOscArgs& A) {
   if (!A.smm_tab || A.W != 1000 || A.n_bands > 8 || A.n_bands < 1) return false;
@@ -65,6 +61,77 @@ static inline bool nmx_specmm_ok(const NmxTimeOscArgs& A) {
   // the hops were batched)
   return true;
 }
+
+#ifdef NMX_HOST_EMU
+// ---- logic emulator (tests/emu, never loaded by the package): the kernel's ARITHMETIC for one (window, channel) -- the
+// twice-folded half-sample-phase contraction against the host's table, band means of log10 |Y| / |Y| over the plan's bin
+// ranges, the single-pass time domain about the window's first sample with telescoped difference sums, the overflow
+// flag for the wave-level redo -- without its machinery (DMA ring, MFMA operand layout, packed arithmetic): what the
+// CPU tier can check is the table, the bin bookkeeping, the formulas and the flag protocol.  fp32 like the device,
+// summation orders differ (the tests hold both to the oracle).  -> true: the window is left to the redo pass.
+NMX_DEV bool nmx_specmm_item_emu(const NmxTimeOscArgs& A, int w, int c) {
+  const NmxOsc& O = A.fft;
+  const float* x = A.x + (long long)c * A.ch_stride + (long long)w * A.win_stride + (A.starts ? A.starts[w] : 0ll);
+  const float* tab = A.smm_tab;
+  const int ke0 = O.k_lo + (O.k_lo & 1), ko0 = O.k_lo + 1 - (O.k_lo & 1);
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, chk = 0.f;
+  for (int r = 0; r < 16; ++r)
+    for (int par = 0; par < 2; ++par) {
+      const int k = (par ? ko0 : ke0) + 2 * r;
+      float yc = 0.f, ys = 0.f;
+      for (int n = 0; n < 250; ++n) {
+        const float a = x[n], b = x[499 - n], cc = x[500 + n], d = x[999 - n];
+        const float sc = par ? (a + d) - (b + cc) : (a + d) + (b + cc);
+        const float ss = par ? (a - d) - (cc - b) : (a - d) + (cc - b);
+        yc += tab[(((size_t)par * NMX_SMM_NG + (size_t)(n >> 2)) * 16 + (size_t)r) * 4 + (size_t)(n & 3)] * sc;
+        ys += tab[(((size_t)(2 + par) * NMX_SMM_NG + (size_t)(n >> 2)) * 16 + (size_t)r) * 4 + (size_t)(n & 3)] * ss;
+      }
+      const float pw = yc * yc + ys * ys;   // (rows past k_hi: zero table rows, pw = 0 -- inside no band)
+      chk += pw;
+      const float val = O.log_transform ? 0.5f * log10f(pw) : sqrtf(pw);
+      for (int b = 0; b < A.n_bands; ++b)
+        if (k >= O.bin_lo[b] && k < O.bin_hi[b]) bs[b] += val;
+    }
+  if (!(chk < INFINITY)) return true;   // a NaN / an infinity among the samples, or a power that overflows
+  float* o = A.out + (long long)w * A.n_outputs;
+  for (int b = 0; b < A.n_bands; ++b) o[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = bs[b] * O.inv_bins[b];
+  if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) {
+    const float p = x[0];
+    // (64 partial sums per statistic, like the device's lanes, then a tree: one fp32 accumulator over 1000 terms would
+    // carry sqrt(1000) roundings into the cancellation q0 - s0^2 / W)
+    float P[5][64];
+    for (int k = 0; k < 5; ++k) for (int l = 0; l < 64; ++l) P[k][l] = 0.f;
+    for (int n = 0; n < 1000; ++n) { const float u = x[n] - p; P[0][n & 63] += u; P[1][n & 63] += u * u; }
+    for (int n = 0; n < 999; ++n) { const float d1 = (x[n + 1] - p) - (x[n] - p); P[2][n & 63] += d1 * d1; P[4][n & 63] += fabsf(d1); }
+    for (int n = 0; n < 998; ++n) {
+      const float d2 = ((x[n + 2] - p) - (x[n + 1] - p)) - ((x[n + 1] - p) - (x[n] - p));
+      P[3][n & 63] += d2 * d2;
+    }
+    for (int k = 0; k < 5; ++k)
+      for (int h = 32; h >= 1; h >>= 1)
+        for (int l = 0; l < h; ++l) P[k][l] += P[k][l + h];
+    const float s0 = P[0][0], q0 = P[1][0], q1 = P[2][0], q2 = P[3][0], sa = P[4][0];
+    const float u0 = 0.f, u1 = x[1] - p, u998 = x[998] - p, u999 = x[999] - p;
+    const float rW = 1.f / 1000.f, rW1 = 1.f / 999.f, rW2 = 1.f / 998.f;
+    const float sd1 = u999 - u0, sd2 = (u999 - u998) - (u1 - u0);   // telescoped sums of the differences
+    const float v0 = (q0 - s0 * s0 * rW) * rW, v1 = (q1 - sd1 * sd1 * rW1) * rW1, v2 = (q2 - sd2 * sd2 * rW2) * rW2;
+    const float a0 = v0 < 0.f ? 0.f : v0, a1 = v1 < 0.f ? 0.f : v1, a2 = v2 < 0.f ? 0.f : v2;
+    const float act = nmx_clean(a0), mob = nmx_clean(sqrtf(a1 / a0)), comp = nmx_clean(sqrtf(a2 / a1) / mob);
+    if (A.features & NMXD_F_HJORTH) {
+      const int col = A.hjorth_cols.base + c * A.hjorth_cols.ch_stride;
+      o[col] = act;
+      o[col + A.hjorth_cols.a_stride] = mob;
+      o[col + 2 * A.hjorth_cols.a_stride] = comp;
+    }
+    if (A.features & NMXD_F_LINELENGTH) o[A.ll_cols.base + c * A.ll_cols.ch_stride] = sa * rW1 * rW1;
+    if (A.features & NMXD_F_RAW) o[A.raw_cols.base + c * A.raw_cols.ch_stride] = x[999] + (A.dcf ? A.dcf[c] : 0.f);
+  }
+  return false;
+}
+#endif
+
+#ifndef NMX_HOST_EMU
+typedef float nmx_v4 __attribute__((ext_vector_type(4)));
 
 // ---- the DMA of one step: eight instructions, LDS destination = M0 + 16 * lane ------------------------------------------
 // (inline asm: the compiler's own wait-count pass would put vmcnt(0) in front of every LDS read behind a builtin DMA --

@@ -25,6 +25,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_resample.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_timeosc.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_specmm.h"
 
 typedef void* be_stream_t;
 struct be_timer_t { bool used = false; };
@@ -53,6 +54,7 @@ static void be_memset_async(void* d, int v, size_t n, be_stream_t) { memset(d, v
 static void be_host_fn(be_stream_t, void (*fn)(void*), void* arg) { fn(arg); }
 static int be_sync(be_stream_t) { return 0; }
 static void be_sync_quiet(be_stream_t) {}
+static int be_sync_watch(be_stream_t, const std::string*, int) { return 0; }
 static be_stream_t be_stream_create() { return nullptr; }
 static be_stream_t be_stream_create_high() { return nullptr; }
 static void be_stream_destroy(be_stream_t) {}
@@ -71,12 +73,29 @@ static void be_stage(int) {}
 static void be_stage_reset() {}
 static std::string be_stage_kernels(int) { return "host emulator (tests only)"; }
 
+// the matrix-pipe spectrum kernel's arithmetic and flag protocol (nmx_k_specmm.h): a 16-bit mask per tile of 16 windows of one
+// channel (tile = group * n_channels + channel), the flagged windows redone by the generic item code with its cleaning
 static int be_launch_timeosc(const NmxTimeOscArgs& A, int n_items, int, size_t lds, be_stream_t) {
+  static const bool smm = [] { const char* v = getenv("NMX_SPECMM"); return !(v && v[0] == '0'); }();
+  if (smm && A.smm_tab && nmx_specmm_ok(A)) {
+    const int C = A.n_channels, n_windows = n_items / C;
+    for (int t = 0; t < ((n_windows + 15) / 16) * C; ++t) A.todo[t] = 0;
+    for (int w = 0; w < n_windows; ++w)
+      for (int c = 0; c < C; ++c)
+        if (nmx_specmm_item_emu(A, w, c)) A.todo[(w / 16) * C + c] |= (unsigned short)(1u << (w & 15));
+    return 1;
+  }
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_time_osc_item(A, it / A.n_channels, it % A.n_channels, sm.data());
   return 0;
 }
-static void be_launch_timeosc_redo(const NmxTimeOscArgs&, int, be_stream_t) {}
+static void be_launch_timeosc_redo(const NmxTimeOscArgs& A, int n_items, be_stream_t) {
+  const int C = A.n_channels, n_windows = n_items / C;
+  std::vector<float> sm((size_t)A.lds_floats + 16);
+  for (int w = 0; w < n_windows; ++w)
+    for (int c = 0; c < C; ++c)
+      if (A.todo[(w / 16) * C + c] & (1u << (w & 15))) nmx_time_osc_item(A, w, c, sm.data());
+}
 static void be_launch_bank(const NmxBankArgs& A, int n_items, int, size_t lds, be_stream_t) {
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_bank_item(A, it / A.n_channels, it % A.n_channels, sm.data());

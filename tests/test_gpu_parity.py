@@ -945,6 +945,35 @@ def test_trends_are_counted_not_hidden(gpu_lib):
     assert sum(acc.values()) <= 40, acc   # (emulator 11, all Welch bins at 1e-4 of the swell's leakage; see the budget file)
 
 
+def test_watchdog_names_the_kernels_of_a_batch_that_does_not_finish(tmp_path):
+    """hipStreamSynchronize has no timeout; the wait at the end of a host-memory batch polls with one
+    (NMX_SYNC_TIMEOUT_S, nmx_api.hip: be_sync_watch) and its error lists the launch sequence stage by stage.  Shown with
+    a limit far below a 400-hop batch's run time, in a process of its own (the limit is read once)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "import bench\n"
+        "from py_neuromodulation_amd import fir_design, _lib\n"
+        "from py_neuromodulation_amd.engine import HotPathEngine\n"
+        "s = bench.make_settings(); C = 64\n"
+        "eng = HotPathEngine(s, [f'ch{i}' for i in range(C)], 1000.0, ref_matrix=bench.car_matrix(C), notch_taps=fir_design.notch_bank(1000.0, 50))\n"
+        "x = bench.synth(C, 1000 + 399 * 100, 1000.0, 1)\n"
+        "try:\n"
+        "    eng.process_batch(x, np.arange(400) * 100)\n"
+        "except _lib.NmxError as e:\n"
+        "    print('CAUGHT', e)\n"
+    )
+    env = dict(__import__("os").environ, NMX_SYNC_TIMEOUT_S="0.0001")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert "CAUGHT" in res.stdout and "did not finish" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "nmx_kern_bank_w64c" in res.stdout and "stage 4" in res.stdout, res.stdout[-2000:]
+
+
 def test_abi_from_plain_c_on_the_gpu(tmp_path):
     """tests/c_abi/abi_smoke.c on a box WITH a device: its `ndev > 0` branch creates a plan and computes one
     feature through the C ABI from plain C (the CPU tier only reaches the argument checks)."""

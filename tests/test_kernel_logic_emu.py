@@ -290,3 +290,43 @@ def test_failed_run_leaves_no_side_files(emu_lib, tmp_path, monkeypatch):
 def test_trends_are_counted_not_hidden(emu_lib):
     acc = pc.case_trends(emu_lib)
     assert sum(acc.values()) <= 40, acc   # (emulator 11, all Welch bins at 1e-4 of the swell's leakage; see the budget file)
+
+
+def test_matrix_pipe_spectrum_kernel_arithmetic_and_flags(emu_lib):
+    """The emulator body of nmx_k_specmm.h (twice-folded half-sample-phase contraction against the HOST's table, bin
+    bookkeeping, single-pass time domain, the overflow flag and the redo of flagged windows): config[1]'s feature set on
+    windows with offsets, a NaN stretch, an infinity, a flat channel; odd channel count, a ragged last tile -- against the
+    float64 oracle, and the plan must say which path it took."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings
+    from py_neuromodulation_amd.engine import HotPathEngine
+
+    s = NMSettings.get_default()
+    s.features.disable_all()
+    s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = True
+    C, n = 5, 19
+    rng = np.random.default_rng(3)
+    T = 1000 + (n - 1) * 100
+    x = (rng.standard_normal((C, T)) * 50 + rng.uniform(-500, 500, (C, 1))).astype(np.float32)
+    x[1] = 0.0
+    x[2, 1500:1507] = np.nan
+    x[3, 700] = np.inf
+    ch = [f"ch{i}" for i in range(C)]
+    eng = HotPathEngine(s, ch, 1000.0, lib=emu_lib)
+    assert bool(eng.desc.features) and eng.process_batch(x, np.arange(n) * 100).shape == (n, eng.n_outputs)
+    got = eng.process_batch(x, np.arange(n) * 100)
+    one = np.stack([eng.process_window(x[:, a:a + 1000].astype(np.float64)) for a in (0, 900, 1800)])
+    np.testing.assert_array_equal(got[[0, 9, 18]], one)
+    feats = [orc._FEATURE_CLS[f](s, ch, 1000.0) for f in s.features.get_enabled()]
+    for i in range(n):
+        w = np.nan_to_num(x[:, i * 100:i * 100 + 1000].astype(np.float64))
+        want = {}
+        for f in feats:
+            want.update(f.calc_feature(w))
+        assert list(want) == list(eng.keys)
+        keep = [k for k, key in enumerate(eng.keys) if not (key.startswith("ch3_") and i * 100 <= 700)]   # (ch3 on the rail there)
+        wv = list(want.values())
+        n_bad, rep, _ = parity.compare([eng.keys[k] for k in keep], got[i][keep], [wv[k] for k in keep], s, 1000.0, 600.0, 1000,
+                                       verifier=parity.Verifier(s, ch, 1000.0, w))
+        assert n_bad == 0, f"hop {i}\n{rep}"
+    eng.close()
