@@ -948,7 +948,7 @@ def test_trends_are_counted_not_hidden(gpu_lib):
 def test_watchdog_names_the_kernels_of_a_batch_that_does_not_finish(tmp_path):
     """hipStreamSynchronize has no timeout; the wait at the end of a host-memory batch polls with one
     (NMX_SYNC_TIMEOUT_S, nmx_api.hip: be_sync_watch) and its error lists the launch sequence stage by stage.  Shown with
-    a limit far below a 400-hop batch's run time, in a process of its own (the limit is read once)."""
+    a limit far below a 1024-hop batch's run time, in a process of its own (the limit is read once)."""
     import subprocess
     import sys
     from pathlib import Path
@@ -960,15 +960,16 @@ def test_watchdog_names_the_kernels_of_a_batch_that_does_not_finish(tmp_path):
         "import bench\n"
         "from py_neuromodulation_amd import fir_design, _lib\n"
         "from py_neuromodulation_amd.engine import HotPathEngine\n"
-        "s = bench.make_settings(); C = 64\n"
+        "s = bench.make_settings(); C = 256\n"
         "eng = HotPathEngine(s, [f'ch{i}' for i in range(C)], 1000.0, ref_matrix=bench.car_matrix(C), notch_taps=fir_design.notch_bank(1000.0, 50))\n"
-        "x = bench.synth(C, 1000 + 399 * 100, 1000.0, 1)\n"
+        "x = eng.pinned_empty((C, 1000 + 1023 * 100)); x[...] = bench.synth(C, 1000 + 1023 * 100, 1000.0, 1)\n"
+        "out = eng.pinned_empty((1024, eng.n_outputs))\n"
         "try:\n"
-        "    eng.process_batch(x, np.arange(400) * 100)\n"
+        "    eng.process_batch(x, np.arange(1024) * 100, out=out)   # (page-locked both ways: ~6 ms of device work queued in < 1 ms)\n"
         "except _lib.NmxError as e:\n"
         "    print('CAUGHT', e)\n"
     )
-    env = dict(__import__("os").environ, NMX_SYNC_TIMEOUT_S="0.0001")
+    env = dict(__import__("os").environ, NMX_SYNC_TIMEOUT_S="0.00001")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert "CAUGHT" in res.stdout and "did not finish" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
     assert "nmx_kern_bank_w64c" in res.stdout and "stage 4" in res.stdout, res.stdout[-2000:]
