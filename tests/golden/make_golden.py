@@ -900,6 +900,36 @@ def case_inf_members():
     np.savez_compressed(HERE / "inf_members.npz", **out)
 
 
+def case_dc_nan():
+    """NaN samples on a channel 10^5 spreads off zero, NO re-reference in front (the notch / the features read the rows
+    directly): nan_to_num makes them the VALUE 0 (stream/data_processor.py:255) -- a step of the offset's size in that
+    channel, which its stateful features (burst history and thresholds) keep seeing on later hops."""
+    rng = np.random.default_rng(71)
+    t = np.arange(7000) / 1000.0
+    data = rng.standard_normal((3, 7000)) * 20 + 9 * np.sin(2 * np.pi * 19 * t) * (np.sin(2 * np.pi * 0.9 * t) > 0)
+    data += (20.0 * 1e5 * np.array([1.0, -0.5, 0.3]))[:, None]
+    data[1, 2500:2506] = np.nan
+    out = {"sfreq": 1000, "data": data}
+    for tag, pre in (("notch", ["notch_filter"]), ("nopre", [])):
+        s = nm.NMSettings.get_default()
+        s.reset()
+        s.features.fft = s.features.raw_hjorth = s.features.linelength = s.features.return_raw = s.features.bursts = True
+        s.bursts_settings.time_duration_s = 3
+        s.preprocessing = pre
+        s.postprocessing.feature_normalization = False
+        s.sampling_rate_features_hz = 5
+        import pandas as pd
+        ch = pd.DataFrame({"name": ["a", "b", "c"], "rereference": ["None"] * 3, "used": [1] * 3, "target": [0] * 3,
+                           "type": ["ecog"] * 3, "status": ["good"] * 3, "new_name": ["a", "b", "c"]})
+        st, df = _run_stream(data, 1000, s, channels=ch)
+        out[f"{tag}_settings_json"] = dump(st.settings)
+        out[f"{tag}_columns"] = np.array(list(df.columns))
+        out[f"{tag}_values"] = df.to_numpy(dtype=np.float64)
+        out["channels_json"] = json.dumps(ch.to_dict("list"))
+        print("dc_nan", tag, df.shape, "nan entries", int(np.isnan(out[f"{tag}_values"]).sum()))
+    np.savez_compressed(HERE / "dc_nan.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected cases only: make_golden.py bandpower_kalman ...
         for name in sys.argv[1:]:
@@ -929,3 +959,4 @@ if __name__ == "__main__":
     case_dc_offsets()
     case_real_recording()
     case_inf_members()
+    case_dc_nan()

@@ -975,6 +975,10 @@ def test_watchdog_names_the_kernels_of_a_batch_that_does_not_finish(tmp_path):
     assert "nmx_kern_bank_w64c" in res.stdout and "stage 4" in res.stdout, res.stdout[-2000:]
 
 
+def test_nan_on_an_offset_channel_without_a_rereference(gpu_lib):
+    pc.case_dc_nan(gpu_lib)
+
+
 def test_abi_from_plain_c_on_the_gpu(tmp_path):
     """tests/c_abi/abi_smoke.c on a box WITH a device: its `ndev > 0` branch creates a plan and computes one
     feature through the C ABI from plain C (the CPU tier only reaches the argument checks)."""

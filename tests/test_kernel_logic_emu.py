@@ -330,3 +330,7 @@ def test_matrix_pipe_spectrum_kernel_arithmetic_and_flags(emu_lib):
                                        verifier=parity.Verifier(s, ch, 1000.0, w))
         assert n_bad == 0, f"hop {i}\n{rep}"
     eng.close()
+
+
+def test_nan_on_an_offset_channel_without_a_rereference(emu_lib):
+    pc.case_dc_nan(emu_lib)
