@@ -293,7 +293,14 @@ class MultiDeviceProcessor:
             self._user = UserColumns(self.settings, self.ch_names_used, self.sfreq_raw, self.keys,
                                      device=self.devices[0], lib=lib)
         self._user_chunk = 64
-        self.stage_threads = 0              # of libnmx's staging passes (0: its default)
+        # threads of libnmx's staging passes.  The library's default (an eighth of the machine, 4 - 16) assumes eight ranks
+        # share a node; here ONE process feeds every device, and the pass that reads the float64 recording for all parts sets
+        # the rate beyond two of them (profiles/r06_staging_bandwidth.json: 16 threads 50 - 70 GB/s of source, 64: 65 - 90;
+        # a device consumes ~31 GB/s at 150 k hops/s): eight per device, at most 64 and half the machine.  NMX_HOST_THREADS
+        # overrides.
+        self.stage_threads = 0
+        if len(self.devices) > 2 and not os.environ.get("NMX_HOST_THREADS"):
+            self.stage_threads = int(max(16, min(64, 8 * len(self.devices), (os.cpu_count() or 32) // 2)))
         self.pipeline_min = (64, 1 << 20)   # hops, samples: below, staging and widening are not worth their threads
 
     @property
