@@ -300,7 +300,7 @@ static void be_host_fn(be_stream_t st, void (*fn)(void*), void* arg) { BE_TRY(hi
 static int be_sync(be_stream_t st) { return be_hip(hipStreamSynchronize(st), "hipStreamSynchronize"); }
 // The wait at the end of a host-memory batch, with a watchdog: hipStreamSynchronize has no timeout, and a kernel that never
 // ends (round 4 saw ONE such run of the knob sweep in tests/test_gpu_parity.py, never reproduced: profiles/r05_hang_soak.txt)
-// leaves a caller that says nothing.  Polls the stream instead -- spinning for the first 200 us (the one-window call of a
+// leaves a caller that says nothing.  Polls the stream instead -- spinning for the first millisecond (the one-window call of a
 // real-time loop returns sooner than through the blocking wait), then sleeping 50 us at a time -- and gives up after
 // NMX_SYNC_TIMEOUT_S (default 300; 0: wait for ever) with the stage-by-stage kernel lists of the batch in the message.
 static int be_sync_watch(be_stream_t st, const std::string* kernels, int n_lists) {
@@ -321,7 +321,7 @@ static int be_sync_watch(be_stream_t st, const std::string* kernels, int n_lists
         if (kernels && !kernels[i].empty()) msg += " [stage " + std::to_string(i) + ": " + kernels[i] + "]";
       return nmx_fail(NMX_E_HIP, msg);
     }
-    if (el > 200e-6) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (el > 1e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (a sleep of 50 us is 100+ with timer slack: none inside a one-window call)
   }
 }
 static void be_sync_quiet(be_stream_t st) { if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError(); }   // (error paths: the first message stays)
