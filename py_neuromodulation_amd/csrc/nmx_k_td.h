@@ -174,7 +174,9 @@ NMX_DEV bool nmx_td_emit(const NmxTimeOscArgs& A, int w, int c, NmxTdRegs& R, fl
     p3 += fabsf(D[k][1].y);
   }
   const float p0 = nmx_wave_reduce(a0.x + a0.y, 0.f, add);
-  if (!(fabsf(p0) < INFINITY)) return false;   // NaN / +-inf in the window (wave-uniform)
+  // NaN / +-inf in the window, or samples on the rail (a cleaned infinity behind a re-reference: +-1e38s, whose squares are
+  // not float32s): the scalar formulation with its two-pass forms (wave-uniform)
+  if (!(fabsf(p0) < 1e30f)) return false;
   if (!SUM4) p3 = nmx_wave_reduce(p3, 0.f, add);
   R.sum = p0;
   const float rW = 1.f / (float)W, rW1 = 1.f / (float)(W - 1), rW2 = 1.f / (float)(W - 2);   // (scalar unit: W is uniform)

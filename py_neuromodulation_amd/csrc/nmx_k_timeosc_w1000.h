@@ -70,7 +70,12 @@ struct NmxBandAcc {
     for (int b = 0; b < NB; ++b)
       if (b < n_bands) s[b] += (k >= O.bin_lo[b] && k < O.bin_hi[b]) ? v : 0.f;
   }
-  NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane) {
+  // `rail`: the window holds samples on the rail (+-FLT_MAX: cleaned infinities, or what a re-reference makes of them).  Its
+  // spectral magnitudes are of the size of the rail -- finite 300-odd logs in the reference's float64 --, their squares
+  // overflow, and whether a transform's butterflies then leave +inf or inf - inf = NaN is its summation order: NaN is
+  // reported as the overflow it is, +inf (an EMPTY band stays NaN: the reference's mean of nothing)
+  NMX_DEV static float railed(float v, float inv, bool rail) { return (rail && v != v && inv == inv) ? INFINITY : v; }
+  NMX_DEV void emit(const NmxOsc& O, int n_bands, int vals_per_bin, float* out_row, int c, int lane, bool rail = false) {
     if (NB == 4) {
       // the four band sums stay in lanes 0 / 16 / 32 / 48 (bands 0, 2, 1, 3): ONE multiplication and ONE store
       // instruction for the four results, no broadcast through scalar registers; 1 / bins from the plan (NaN for an
@@ -79,7 +84,7 @@ struct NmxBandAcc {
       const int row = lane >> 4, b = ((row & 1) << 1) | (row >> 1);
       float inv = b == 0 ? O.inv_bins[0] : (b == 1 ? O.inv_bins[1] : (b == 2 ? O.inv_bins[2] : O.inv_bins[3]));
       if (vals_per_bin != 1) inv *= 1.f / (float)vals_per_bin;
-      if ((lane & 15) == 0 && b < n_bands) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = r * inv;
+      if ((lane & 15) == 0 && b < n_bands) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = railed(r * inv, inv, rail);
       return;
     }
     float tot[NB];
@@ -91,11 +96,11 @@ struct NmxBandAcc {
     for (int b = 0; b < NB; ++b) {
       if (b >= n_bands) continue;
       if (vals_per_bin == 1) {   // (compile-time at the call sites: the plan's 1 / bins, NaN for an empty band)
-        if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = tot[b] * O.inv_bins[b];
+        if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = railed(tot[b] * O.inv_bins[b], O.inv_bins[b], rail);
         continue;
       }
       const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
-      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? tot[b] * __builtin_amdgcn_rcpf((float)cnt) : NAN;
+      if (lane == 0) out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? railed(tot[b] * __builtin_amdgcn_rcpf((float)cnt), 1.f, rail) : NAN;
     }
   }
 };
@@ -138,6 +143,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
 
   const bool spec1000 = fft_on || welch_on;
   float wsum;
+  bool rail = false;   // (NmxBandAcc::emit)
   const float dcv = nmx_dc_of(A, c);   // the constant the window was split from (0 without a split)
   NMX_PROF_DECL
   {
@@ -146,6 +152,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
     // (always: the window sum it forms is also the NaN / infinity test of the window)
     const bool fast = nmx_td_emit<1000, (!LOW || SPEC != 0), (SPEC & NMX_TOW_FEATS)>(A, w, c, Rt, spec1000 ? (float*)fb : nullptr);
     wsum = Rt.sum;
+    rail = !fast;
     if (fast) {
       if (stft_on) {   // park the CENTRED window in LDS (group 3: lanes 0..57); see the STFT block below
         const float mean = wsum * (1.f / 1000.f);
@@ -212,7 +219,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
         const float v = fft_log ? nmx_log10_half_fast(pw) : sqrtf(pw);   // log10 |X| = log10(|X|^2) / 2
         acc.add(O, nb, k, v);
       }
-      acc.emit(O, nb, 1, out_row, c, lane);
+      acc.emit(O, nb, 1, out_row, c, lane, rail);
     }
     NMX_PROF(2)
 #ifndef NMX_HOST_EMU
@@ -231,7 +238,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       float p = (yr * yr + yi * yi) * (2.f * O.scale);   // (1 <= k < 500: two-sided density)
       if (welch_log) p = nmx_log10_fast(p);
       if (k >= O.k_lo && k < O.k_hi) acc.add(O, nb, k, p);
-      acc.emit(O, nb, 1, out_row, c, lane);
+      acc.emit(O, nb, 1, out_row, c, lane, rail);
     } else
 #endif
     if (welch_on) {
@@ -245,7 +252,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
         if (welch_log) p = nmx_log10_fast(p);
         acc.add(O, nb, k, p);
       }
-      acc.emit(O, nb, 1, out_row, c, lane);
+      acc.emit(O, nb, 1, out_row, c, lane, rail);
     }
     NMX_WAVE_FENCE();
     NMX_PROF(3)
@@ -308,7 +315,7 @@ NMX_DEV void nmx_timeosc_w1000_body(const NmxTimeOscArgs& A, int w, int c, NmxTd
       }
       NMX_WAVE_FENCE();
     }
-    acc.emit(O, nb, 5, out_row, c, lane);
+    acc.emit(O, nb, 5, out_row, c, lane, rail);
   }
 }
 
