@@ -517,8 +517,9 @@ def main() -> None:
 
     cold_ms = None
     if not args.no_cold_start and rank == 0:   # first step of a fresh plan (outside the timed region)
-        # ... on a process that has launched a kernel before: the first launch of a process uploads the code object and wakes
-        # the device (260 ms on a fresh box, once) -- that is the process's start, not the plan's
+        # ... on a process that has launched a kernel before (code object uploaded, device awake).  What stays in the number:
+        # the plan's ~3 GB of hand-off buffers allocated for the first time -- 20 ms on a device this process family has used
+        # before, up to 260 ms on the first process after other tenants released the memory (driver side, measured both)
         tiny = HotPathEngine(s, ch[:8], sfreq, device=dev_index, ref_matrix=car_matrix(8) if pre else None,
                              notch_taps=fir_design.notch_bank(sfreq, 50) if pre else None)
         tiny.process_window(np.zeros((8, W)) + np.arange(W)[None, :] % 7)
