@@ -59,8 +59,13 @@ NMX_DEV void nmx_hjorth(const float* y, int n, float* red, int mode, bool need_m
   }
 }
 
+// `rail`: the window holds samples on the rail (+-FLT_MAX: cleaned infinities or what a re-reference makes of them).  Its
+// spectral magnitudes are of the size of the rail, their squares overflow, and whether a transform's butterflies then leave
+// +inf or inf - inf = NaN is its summation order: a NaN band mean / median / maximum is reported as the overflow it is,
+// +inf -- as the wave-level kernels do (nmx_k_timeosc_w1000.h: NmxBandAcc::railed).  (An empty band stays NaN.)
+NMX_DEV float nmx_railed(float v, bool rail) { return (rail && v != v) ? INFINITY : v; }
 NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin, int n_bands,
-                            float* out_row, int c, float* red) {
+                            float* out_row, int c, float* red, bool rail = false) {
   if (O.estimators == NMXD_EST_MEAN && n_bands <= 8) {
     // default configuration: all band means with one multi-value reduction
     float p[8];
@@ -84,7 +89,7 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
       for (int b = 0; b < 8; ++b)
         if (b < n_bands) {
           const int cnt = (O.bin_hi[b] - O.bin_lo[b]) * vals_per_bin;
-          out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? p[b] / (float)cnt : NAN;
+          out_row[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = cnt > 0 ? nmx_railed(p[b] / (float)cnt, rail) : NAN;
         }
     }
     return;
@@ -99,11 +104,11 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
     if (need_mean && cnt > 0) mean = nmx_est_mean(v, cnt, red);
     const int col0 = O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride;
     if (O.estimators & NMXD_EST_MEAN) {
-      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = mean;
+      if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = cnt > 0 ? nmx_railed(mean, rail) : mean;
       ++slot;
     }
     if (O.estimators & NMXD_EST_MEDIAN) {
-      const float r = cnt > 0 ? nmx_est_median(v, cnt, red) : NAN;
+      const float r = cnt > 0 ? nmx_railed(nmx_est_median(v, cnt, red), rail) : NAN;
       if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = r;
       ++slot;
     }
@@ -113,7 +118,7 @@ NMX_DEV void nmx_emit_bands(const NmxOsc& O, const float* spec, int vals_per_bin
       ++slot;
     }
     if (O.estimators & NMXD_EST_MAX) {
-      const float r = cnt > 0 ? nmx_est_max(v, cnt, red) : NAN;
+      const float r = cnt > 0 ? nmx_railed(nmx_est_max(v, cnt, red), rail) : NAN;
       if (NMX_TID == 0) out_row[col0 + slot * O.cols.b_stride] = r;
       ++slot;
     }
@@ -149,6 +154,13 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
     nmx_stage_row(src, W, [=](int i, float v) { xs[i] = clean ? nmx_clean(v) : v; });
   }
   NMX_SYNC();
+  bool rail = false;   // samples on the rail in this window (nmx_emit_bands)
+  if (A.fft.enabled || A.welch.enabled || A.stft.enabled) {
+    int any = 0;
+    for (int i = NMX_TID; i < W; i += NMX_NT) any |= !(fabsf(xs[i]) < 1e30f);
+    rail = nmx_block_or(any, red) != 0;
+    NMX_SYNC();
+  }
 
   // ---- time-domain features: Hjorth + LineLength fused, two multi-value reductions ---------
   if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH)) {
@@ -230,7 +242,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       spec[k - O.k_lo] = v;
     }
     NMX_SYNC();
-    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red);
+    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red, rail);
     if (O.return_spectrum)
       for (int k = NMX_TID; k < O.nfreq; k += NMX_NT)
         out_row[O.psd_cols.base + c * O.psd_cols.ch_stride + k * O.psd_cols.a_stride] = spec[k];
@@ -272,7 +284,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       spec[k] = v;
     }
     NMX_SYNC();
-    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red);
+    nmx_emit_bands(O, spec, 1, A.n_bands, out_row, c, red, rail);
     if (O.return_spectrum)
       for (int k = NMX_TID; k < O.nfreq; k += NMX_NT)
         out_row[O.psd_cols.base + c * O.psd_cols.ch_stride + k * O.psd_cols.a_stride] = spec[k];
@@ -374,7 +386,7 @@ NMX_DEV void nmx_time_osc_item(const NmxTimeOscArgs& A, int w, int c, float* sme
       }
     }
     NMX_SYNC();
-    nmx_emit_bands(O, spec, O.nseg, A.n_bands, out_row, c, red);
+    nmx_emit_bands(O, spec, O.nseg, A.n_bands, out_row, c, red, rail);
     if (O.return_spectrum)
       for (int k = NMX_TID; k < O.nfreq; k += NMX_NT) {
         float s = 0.f;

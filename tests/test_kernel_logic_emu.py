@@ -259,7 +259,7 @@ def test_real_recording_of_the_reference_tests(emu_lib, devices):
 
 @pytest.mark.parametrize("tag", ["", "stft_"])
 def test_reref_group_members_on_the_rail(emu_lib, tag):
-    pc.case_inf_members(emu_lib, tag=tag)
+    pc.case_inf_members(emu_lib, tag=tag, spectral_nan_ok=False)
 
 
 def test_failed_run_leaves_no_side_files(emu_lib, tmp_path, monkeypatch):
