@@ -355,6 +355,21 @@ class DataProcessor:
             users.append(self._user_rows(wins))
         return np.concatenate(outs), np.concatenate(masks), np.concatenate(users)
 
+    def _row_dict(self, row: np.ndarray) -> dict:
+        """{key: float} in the reference's key order (stream/data_processor.py:238-311 returns a dict).  Built from a template
+        that already holds the keys: copying a 10 000-entry dict and overwriting its values costs 0.43 ms where
+        ``dict(zip(keys, values))`` -- which grows its table eleven times on the way -- costs 0.72 (the engine's part of a
+        256-channel call is 0.36 ms)."""
+        keys = self.keys
+        tmpl = getattr(self, "_row_template", None)
+        if tmpl is None or tmpl[0] is not keys or len(tmpl[1]) != len(keys):
+            tmpl = self._row_template = (keys, dict.fromkeys(keys, 0.0), tuple(keys))
+        if len(tmpl[1]) != len(tmpl[2]):   # (duplicate keys: nothing a template can hold)
+            return dict(zip(keys, row.tolist()))
+        d = tmpl[1].copy()
+        d.update(zip(tmpl[2], row.tolist()))
+        return d
+
     def process(self, data: np.ndarray) -> dict:
         start_time = time()
         if self._user is not None:
@@ -368,14 +383,14 @@ class DataProcessor:
                 from . import logger
 
                 logger.info("Last batch took: %.3f seconds to process", time() - start_time)
-            return dict(zip(self.keys, row.tolist()))
+            return self._row_dict(row)
         out, mask = self.engine.process_window(data, want_nan_mask=True)
         row = self._postprocess_row(out.astype(np.float64), mask)
         if self.verbose:
             from . import logger
 
             logger.info("Last batch took: %.3f seconds to process", time() - start_time)
-        return dict(zip(self.keys, row.tolist()))
+        return self._row_dict(row)
 
     def process_batch(self, data: np.ndarray, starts: np.ndarray, spare_cols: int = 0) -> np.ndarray:
         """data[C_all, T], window start samples -> float64[n, n_features] (same post-processing,
