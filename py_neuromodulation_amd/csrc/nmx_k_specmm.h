@@ -30,7 +30,7 @@
 // workgroup share nothing and never synchronise.
 // Time domain: the lane that owns 8 consecutive samples of a run also reads a 2-sample halo (left of an ascending run,
 // right of a descending one: the neighbour that is already in LDS) and advances its window's sums of u, u^2, d1^2,
-// d2^2, |d1| (u = x - x[0]) on PACKED arithmetic (two samples per instruction; the unaligned pairs the differences need
+// d2^2, |d1| (u = x - pivot, the mean of four samples spread over the window) on PACKED arithmetic (two samples per instruction; the unaligned pairs the differences need
 // are one v_pk_mov each) in the shadow of the MFMAs; the four partial sums of a window meet once per tile.
 // Conditions (host: nmx_specmm_ok): W = 1000, FFT over the whole window, band means only, bins inside 32 consecutive k
 // with k_lo >= 1, no Welch / STFT.  Device only.
@@ -96,7 +96,7 @@ NMX_DEV bool nmx_specmm_item_emu(const NmxTimeOscArgs& A, int w, int c) {
   float* o = A.out + (long long)w * A.n_outputs;
   for (int b = 0; b < A.n_bands; ++b) o[O.cols.base + c * O.cols.ch_stride + b * O.cols.a_stride] = bs[b] * O.inv_bins[b];
   if (A.features & (NMXD_F_HJORTH | NMXD_F_LINELENGTH | NMXD_F_RAW)) {
-    const float p = x[0];
+    const float p = 0.25f * ((x[0] + x[999]) + (x[499] + x[500]));   // (the device's pivot)
     // (64 partial sums per statistic, like the device's lanes, then a tree: one fp32 accumulator over 1000 terms would
     // carry sqrt(1000) roundings into the cancellation q0 - s0^2 / W)
     float P[5][64];
@@ -111,7 +111,7 @@ NMX_DEV bool nmx_specmm_item_emu(const NmxTimeOscArgs& A, int w, int c) {
       for (int h = 32; h >= 1; h >>= 1)
         for (int l = 0; l < h; ++l) P[k][l] += P[k][l + h];
     const float s0 = P[0][0], q0 = P[1][0], q1 = P[2][0], q2 = P[3][0], sa = P[4][0];
-    const float u0 = 0.f, u1 = x[1] - p, u998 = x[998] - p, u999 = x[999] - p;
+    const float u0 = x[0] - p, u1 = x[1] - p, u998 = x[998] - p, u999 = x[999] - p;
     const float rW = 1.f / 1000.f, rW1 = 1.f / 999.f, rW2 = 1.f / 998.f;
     const float sd1 = u999 - u0, sd2 = (u999 - u998) - (u1 - u0);   // telescoped sums of the differences
     const float v0 = (q0 - s0 * s0 * rW) * rW, v1 = (q1 - sd1 * sd1 * rW1) * rW1, v2 = (q2 - sd2 * sd2 * rW2) * rW2;
@@ -236,7 +236,8 @@ struct NmxSmmLane {
   unsigned od0, od1;     // descending run in ADDRESS order: granules 6 - 2 ks, 7 - 2 ks
   unsigned oha, ohd;     // halos: last two samples of granule 2 ks - 1 / first two of granule 8 - 2 ks (mod 8: ks = 0 reads the previous buffer)
   unsigned ohb0;         // step 0, ks = 0, stream b: x[500], x[501] = stream c, granule 0
-  unsigned opilot;       // x[0] of the window: stream a, granule 0
+  unsigned opilot;       // x[0] of the window: stream a, granule 0 (x[500]: stream c, the same place)
+  unsigned opilot7;      // x[499] / x[999]: the last sample of granule 7 of step 0's b / d runs
   int ks;
 };
 
@@ -285,6 +286,7 @@ struct NmxSmmWave {
     L.ohd = off((8 - 2 * ks) & 7);
     L.ohb0 = 2 * 2048 + off(0);
     L.opilot = off(0);
+    L.opilot7 = off(7) + 12;
     r = 0;
     pend.row = nullptr;
     pend.flag = nullptr;
@@ -372,7 +374,13 @@ struct NmxSmmWave {
       N.hb = ld2(FIRST && k0 ? cur + L.ohb0 : ba + 2048 + L.ohd);
       N.hd = ld2(ba + 6144 + L.ohd);
     }
-    if (FIRST) N.pilot = cl(*(__attribute__((address_space(3))) const float*)(unsigned long)(cur + L.opilot));
+    if (FIRST) {
+      // the pivot of the single-pass sums: the mean of x[0], x[499], x[500], x[999] -- all in step 0's buffer.  (It was x[0]
+      // alone: behind a resampler or a notch the first sample of a window can sit several spreads off the rest -- an edge
+      // transient --, and q0 - s0^2 / W then cancels (1 + k^2)-fold: fuzz seed 102790, Hjorth mobility 1.8e-5 off.)
+      auto at = [&](unsigned a) { return cl(*(__attribute__((address_space(3))) const float*)(unsigned long)a); };
+      N.pilot = 0.25f * ((at(cur + L.opilot) + at(cur + 6144 + L.opilot7)) + (at(cur + 2048 + L.opilot7) + at(cur + 4096 + L.opilot)));
+    }
   }
 
   struct Tile {

@@ -21,7 +21,7 @@ THAT entry, the ill-conditioning that explains it (oracle/nm_oracle.py, "Conditi
 
   * spectral features (FFT / Welch / STFT, band estimators and "psd" keys): fp32 puts an ABSOLUTE error on every bin
     (the rounding of each sample is relative to its size, DC offset included, and spreads over all bins like white
-    noise): FP32_BIN_EPS (2e-6, ~32 fp32 ulp) x the magnitude white noise with the rms of what the float32 samples hold
+    noise): FP32_BIN_EPS (3e-6, ~48 fp32 ulp) x the magnitude white noise with the rms of what the float32 samples hold
     has in that family (the spread; the level too where the engine leaves it in the samples, Verifier._held), x (1 + number of fp32 pre-processing stages in front of the features: each adds its own rounding).
     The DC, Nyquist and N/4 bins add the samples coherently and get 2^-24 sqrt(N) amp / rms on top (a rounding bias of half
     an ulp adds up N-fold there).  With log_transform that absolute error becomes relative: a miss is accepted iff it
@@ -112,11 +112,12 @@ def tolerances(key: str, settings, sfreq: float, amp_scale: float, W: int):
     return 1e-5, 1e-9 * max(amp_scale, 1.0)
 
 
-FP32_BIN_EPS = 2e-6     # absolute fp32 error of a spectral bin (pre-processing + transform) relative to the window's white-noise level: ~32 ulp.
-                        # History: 2e-6 (round 4) -> 3e-6 in round 5, when the noise level stopped counting the channel's DC offset and two
-                        # fuzz seeds (6494, 20455: 4 kHz / 2 kHz windows behind a 3999- / 1999-tap notch) reached 2.2e-6 -> back to 2e-6 in
-                        # round 6: the notch in residual form (nmx_k_bank.h: NmxBankArgs::residual) took most of its own rounding out of
-                        # the bins; the whole GPU tier and 3 923 fuzz cases of all seven generators pass at this level
+FP32_BIN_EPS = 3e-6     # absolute fp32 error of a spectral bin (pre-processing + transform) relative to the window's white-noise level: ~48 ulp.
+                        # Recalibrated in round 5, when the noise level stopped counting the channel's DC offset (it used to inflate the
+                        # floor up to sixfold): the largest ratio among 5 651 cases of tests/fuzz_sweep.py was 2.2e-6 (seeds 6494, 20455:
+                        # 4 kHz / 2 kHz windows behind a 3999- / 1999-tap notch).  Round 6 tried 2e-6 again behind the residual notch: the
+                        # GPU tier and 27 000 fuzz cases passed, then a recompile of the matrix-pipe spectrum kernel (another FMA
+                        # contraction, no notch in sight) moved one near-null bin of its ragged-shape test to 2.6e-6 -- 3e-6 stays
 HJORTH_EPS = 1e-7       # white noise on a (filtered) series relative to the rms of the input row: two fp32 ulp
 DECISION_RTOL = 1e-6    # decision margin relative to max |input row| below which fp32 can flip it
 
