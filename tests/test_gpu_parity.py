@@ -577,7 +577,7 @@ def test_high_rate_partitioned_fir(gpu_lib):
     pc.case_high_rate_partitioned_fir(gpu_lib)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + [102790])   # (102790: an edge transient in x[0] behind the resampler -- the matrix-pipe kernel's pivot)
 def test_random_settings_highrate(gpu_lib, seed):
     pc.case_random_settings_highrate(gpu_lib, seed)
 

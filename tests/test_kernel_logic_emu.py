@@ -110,7 +110,7 @@ def test_high_rate_partitioned_fir(emu_lib):
     pc.case_high_rate_partitioned_fir(emu_lib)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", list(range(3)) + [102790])
 def test_random_settings_highrate(emu_lib, seed):
     pc.case_random_settings_highrate(emu_lib, seed)
 
