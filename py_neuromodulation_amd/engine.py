@@ -25,6 +25,7 @@ import numpy as np
 
 from . import _lib, fir_design
 from ._lib import Cols, PlanDesc
+from .settings import validation_error
 
 _FEATURE_BITS = {"raw_hjorth": _lib.F_HJORTH, "return_raw": _lib.F_RAW,
                  "bandpass_filter": _lib.F_BANDPOWER, "stft": _lib.F_STFT, "fft": _lib.F_FFT,
@@ -282,6 +283,27 @@ class _Pinned:
         self._bufs = {}
 
 
+MAX_PLAN_WINDOW = 16384   # nmx_plan_create: window in [4, 16384] samples
+
+
+def long_segments(n_samples: int, halo: int, window: int = MAX_PLAN_WINDOW):
+    """A FIR filter over a recording longer than one plan's window, for the stand-alone filter classes (MNEFilter,
+    NotchFilter, PreprocessingFilter: the reference's filter any length): windows ``[lo, lo + window)`` of the recording
+    and the output samples ``[a, b)`` each of them is exact for -- every sample at least ``halo`` (half the filter, or
+    the sum of the halves of a chain) away from a cut that is not an end of the recording, so that it sees the same
+    input samples as in one long convolution; at the two ends of the recording the window's own edge handling (zeros,
+    or the notch's reflection) IS the recording's.  Yields (lo, a, b)."""
+    step = window - 2 * halo
+    if step < 1:
+        raise ValueError(f"a filter chain of {2 * halo + 1} taps leaves no room for data in one {window}-sample window")
+    a = 0
+    while a < n_samples:
+        lo = min(max(a - halo, 0), n_samples - window)
+        b = n_samples if lo + window >= n_samples else lo + window - halo
+        yield lo, a, b
+        a = b
+
+
 class HotPathEngine:
     """One plan on one GPU for ``len(ch_names)`` channels."""
 
@@ -509,8 +531,9 @@ class HotPathEngine:
                 names = list(bs.frequency_bands)
                 for nme in names:
                     if nme not in band_index:
-                        raise ValueError(f"bursting {nme} needs to be defined in "
-                                         "settings['frequency_ranges_hz']")
+                        raise validation_error(f"bursting {nme} needs to be defined in "
+                                               "settings['frequency_ranges_hz']",
+                                               ["burst_settings", "frequency_bands"])
                 groups = _enabled(bs.burst_features)
                 slots, mask, bit = [], 0, 0
                 for g, outs in _BURST_SLOTS:

@@ -17,7 +17,7 @@ from collections.abc import Sequence
 
 import numpy as np
 
-from .engine import HotPathEngine
+from .engine import MAX_PLAN_WINDOW, HotPathEngine, long_segments
 
 FEATURE_DICT = {  # features/feature_processor.py:10-25 (hot-path subset)
     "raw_hjorth": "Hjorth", "return_raw": "Raw", "bandpass_filter": "BandPower", "stft": "STFT",
@@ -35,15 +35,47 @@ class _EngineFeature:
         self.settings = settings
         self.ch_names = list(ch_names)
         self.sfreq = sfreq
+        self._kwargs = engine_kwargs
+        if not self.ch_names:
+            # the reference's classes accept an empty channel list (tests/test_sharpwave.py:46-62 constructs one to
+            # have the settings checked): the plan description is derived -- every settings error raised -- for one
+            # stand-in channel, and there is nothing to compute.
+            HotPathEngine(settings, ["_"], sfreq, features=self._feature_list(settings), dry_run=True, **engine_kwargs)
+            self.engine, self.keys, self._engines = None, [], {}
+            return
         self.engine = HotPathEngine(settings, self.ch_names, sfreq,
                                     features=self._feature_list(settings), **engine_kwargs)
         self.keys = self.engine.keys
+        self._engines = {self.engine.W_in: self.engine}   # by window length, see `calc_feature`
 
     def _feature_list(self, settings):
         return [self.feature_name]
 
+    def _engine_for(self, n_samples: int) -> HotPathEngine:
+        """A sampling rate that is not a whole number of samples per segment makes the reference's generator cut
+        windows of two lengths (stream/generator.py:41-53; tests/test_timing.py:43-76), and its feature classes take
+        whatever length arrives: one plan per length here, and what carries over from hop to hop (burst history,
+        Kalman filters) travels with the stream when the length changes (nmx_state_export / _import; the layout depends
+        on the settings, not on the length) -- as `Stream.run` does for its own ragged runs."""
+        eng = self._engines.get(n_samples)
+        if eng is None:
+            kw = dict(self._kwargs)
+            kw["raw_window" if self.engine.resample_ratio else "window"] = n_samples
+            eng = HotPathEngine(self.settings, self.ch_names, self.sfreq, features=self._feature_list(self.settings), **kw)
+            self._engines[n_samples] = eng
+        if eng is not self.engine:
+            state = self.engine.export_state()
+            if state:
+                eng.import_state(state)
+            self.engine = eng
+        return eng
+
     def calc_feature(self, data: np.ndarray) -> dict:
-        out = self.engine.process_window(data)
+        if self.engine is None:
+            return {}
+        n = np.shape(data)[-1]
+        eng = self.engine if n == self.engine.W_in else self._engine_for(n)
+        out = eng.process_window(data)
         return dict(zip(self.keys, out.tolist()))
 
 
@@ -116,21 +148,31 @@ class MNEFilter:
         self.sfreq = sfreq
         self._engines: dict = {}
 
-    def filter_data(self, data: np.ndarray) -> np.ndarray:
+    def _engine(self, C_: int, W: int) -> HotPathEngine:
         from .settings import NMSettings
 
+        key = (C_, W)
+        if key not in self._engines:
+            s = NMSettings.get_default()
+            s.frequency_ranges_hz = {f"b{i}": [1, 2] for i in range(self.num_filters)}
+            s.bandpass_filter_settings.segment_lengths_ms = {f"b{i}": 1 for i in range(self.num_filters)}
+            self._engines[key] = HotPathEngine(s.validate(), [f"c{i}" for i in range(C_)], self.sfreq,
+                                               features=["bandpass_filter"], bank_taps=self.filter_bank, window=W)
+        return self._engines[key]
+
+    def filter_data(self, data: np.ndarray) -> np.ndarray:
         data = np.asarray(data, np.float64)
         if data.ndim > 2:
             raise ValueError(f"Data must have one or two dimensions. Got: {data.ndim} dimensions.")
         if data.ndim == 1:
             data = data[None]
-        key = data.shape
-        if key not in self._engines:
-            s = NMSettings.get_default()
-            s.frequency_ranges_hz = {f"b{i}": [1, 2] for i in range(self.num_filters)}
-            s.bandpass_filter_settings.segment_lengths_ms = {f"b{i}": 1 for i in range(self.num_filters)}
-            eng = HotPathEngine(s.validate(), [f"c{i}" for i in range(data.shape[0])], self.sfreq,
-                                features=["bandpass_filter"], bank_taps=self.filter_bank,
-                                window=data.shape[1])
-            self._engines[key] = eng
-        return self._engines[key].filter_window(data)
+        C_, T = data.shape
+        if T <= MAX_PLAN_WINDOW:
+            return self._engine(C_, T).filter_window(data)
+        # A recording longer than one plan's window (filter/mne_filter.py:100-128 convolves any length, "same"
+        # alignment, zeros outside; tests/test_nm_filter.py filters 10 s at 4 kHz): see `long_segments`.
+        eng = self._engine(C_, MAX_PLAN_WINDOW)
+        out = np.empty((C_, self.num_filters, T), np.float64)
+        for lo, a, b in long_segments(T, max((len(t) - 1) // 2 for t in self.filter_bank)):
+            out[:, :, a:b] = eng.filter_window(data[:, lo:lo + MAX_PLAN_WINDOW])[:, :, a - lo:b - lo]
+        return out

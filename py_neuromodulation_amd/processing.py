@@ -20,7 +20,7 @@ import numpy as np
 
 from . import channels as chmod
 from . import fir_design
-from .engine import HotPathEngine
+from .engine import MAX_PLAN_WINDOW, HotPathEngine, long_segments
 from .settings import NMSettings
 
 
@@ -42,6 +42,28 @@ def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, re
                          notch_taps=notch_taps, ref_matrix=ref_matrix, window=W)
 
 
+def _windowed(engines: dict, make, data: np.ndarray, halo: int) -> np.ndarray:
+    """``process`` of a stand-alone FIR pre-processor: one window (of whatever length; 1-D like MNE's filters take it),
+    or a recording longer than a plan's window in exact segments (engine.long_segments)."""
+    data = np.asarray(data, np.float64)
+    x = data[None] if data.ndim == 1 else data
+    C_, T = x.shape
+
+    def eng(W):
+        if (C_, W) not in engines:
+            engines[(C_, W)] = make(C_, W)
+        return engines[(C_, W)]
+
+    if T <= MAX_PLAN_WINDOW:
+        y = eng(T).preprocess_window(x)
+    else:
+        e = eng(MAX_PLAN_WINDOW)
+        y = np.empty((e.C, T), np.float64)
+        for lo, a, b in long_segments(T, halo):
+            y[:, a:b] = e.preprocess_window(x[:, lo:lo + MAX_PLAN_WINDOW])[:, a - lo:b - lo]
+    return y[0] if data.ndim == 1 else y
+
+
 class NotchFilter:
     def __init__(self, sfreq: float, line_noise: float | None = None, freqs=None,
                  notch_widths=3, trans_bandwidth: float = 6.8) -> None:
@@ -54,11 +76,8 @@ class NotchFilter:
     def process(self, data: np.ndarray) -> np.ndarray:
         if self.filter_bank is None:
             return data
-        data = np.asarray(data, np.float64)
-        if data.shape not in self._engines:
-            eng = _pre_engine(data.shape[0], data.shape[1], self.sfreq, notch_taps=self.filter_bank)
-            self._engines[data.shape] = eng
-        return self._engines[data.shape].preprocess_window(data)
+        return _windowed(self._engines, lambda C_, W: _pre_engine(C_, W, self.sfreq, notch_taps=self.filter_bank),
+                         data, (len(self.filter_bank) - 1) // 2)
 
 
 class ReReferencer:
@@ -90,10 +109,8 @@ class PreprocessingFilter:
     def process(self, data: np.ndarray) -> np.ndarray:
         if not self.taps:
             return data
-        data = np.asarray(data, dtype=np.float64)
-        if data.shape not in self._engines:
-            self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq, pre_taps=self.taps)
-        return self._engines[data.shape].preprocess_window(data)
+        return _windowed(self._engines, lambda C_, W: _pre_engine(C_, W, self.sfreq, pre_taps=self.taps),
+                         data, sum((len(t) - 1) // 2 for t in self.taps))
 
 
 class RawNormalizer:

@@ -25,12 +25,27 @@ from typing import Any
 
 import numpy as np
 
-__all__ = ["NMSettings", "FrequencyRange", "BoolSelector", "SettingsError"]
+__all__ = ["NMSettings", "FrequencyRange", "BoolSelector", "SettingsError", "validation_error"]
 
 
 class SettingsError(ValueError):
     """Raised for invalid settings (the reference raises pydantic's ValidationError,
     which is also a ValueError subclass)."""
+
+
+def validation_error(message: str, location=()) -> ValueError:
+    """The error a plugin class raises for settings the reference rejects with ``create_validation_error``
+    (utils/pydantic_extensions.py:26-56, e.g. features/bursts.py:68-73): pydantic's own ``ValidationError`` where
+    pydantic is installed -- callers of the reference catch that type, and it cannot be subclassed -- and
+    ``SettingsError`` where it is not.  Both are ``ValueError``s."""
+    try:
+        from pydantic_core import InitErrorDetails, ValidationError
+    except ImportError:   # pragma: no cover - pydantic comes with the reference
+        return SettingsError(message)
+    return ValidationError.from_exception_data(
+        "Validation Error",
+        [InitErrorDetails(type="value_error", loc=tuple(location), input=None, ctx={"error": message})],
+        input_type="python", hide_input=False)
 
 
 class FrequencyRange:

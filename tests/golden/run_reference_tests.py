@@ -1,0 +1,103 @@
+"""Build-container only: the reference's OWN test files (/root/reference/tests, read in place -- nothing is copied) run
+against the reference package with the engine's plugin classes swapped in (the nine feature
+classes, the pre-processors, MNEFilter / NotchFilter), on the test-only logic emulator of the kernels (there is no GPU
+here; on a GPU box the same swap runs on libnmx.so).
+
+    python tests/golden/run_reference_tests.py            # swapped
+    python tests/golden/run_reference_tests.py --plain    # the unmodified reference under the same shim: the baseline
+
+What the shim supplies instead of the packages this image lacks: MNE's filter design / resampling as restated in
+oracle/mne_restated.py (tests/golden/ref_shim.py), and `nm.io.read_BIDS_data` for the one BIDS recording the fixtures
+use (tests/conftest.py:8-69) through the BrainVision reader of tests/golden/make_golden.py (MNE and mne_bids are not
+installable).  Out of scope and not collected: bispectra, coherence, fooof, mne_connectivity, nolds, LSL, database, the
+example gallery (OUT OF SCOPE).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(ROOT))
+
+IN_SCOPE = ["test_all_features.py", "test_bad_channels.py", "test_bursts.py", "test_feature_sampling_rates.py",
+            "test_initalization_offline_stream.py", "test_nan_values.py", "test_nm_filter.py", "test_nm_resample.py",
+            "test_normalization_settings.py", "test_notch_filter.py", "test_osc_features.py", "test_preprocessing_filter.py",
+            "test_rereference.py", "test_sampling.py", "test_settings_change_after_init.py", "test_sharpwave.py",
+            "test_target_channel_add.py", "test_timing.py"]
+FEATURE_CLASSES = ("Hjorth", "Raw", "BandPower", "STFT", "FFT", "Welch", "SharpwaveAnalyzer", "Bursts", "LineLength")
+PREPROCESSOR_CLASSES = ("NotchFilter", "ReReferencer", "Resampler", "PreprocessingFilter")
+
+
+class _Raw:
+    """What the fixtures read off `mne.io.Raw`: names, types, bads, the data in volt."""
+
+    def __init__(self, names, types, data, sfreq):
+        self.ch_names, self._types, self._data = list(names), list(types), data
+        self.info = {"bads": [], "sfreq": sfreq, "line_freq": 50}
+
+    def get_channel_types(self):
+        return list(self._types)
+
+    def get_data(self):
+        return self._data
+
+
+def main(swap: bool) -> int:
+    import numpy as np
+    import pandas as pd
+    import pytest
+
+    import ref_shim
+
+    nm = ref_shim.load_reference()
+    warnings.filterwarnings("ignore")
+    import make_golden as mg   # (its BrainVision reader; importing it runs nothing)
+
+    ieeg = Path(ref_shim.REFERENCE_ROOT) / "py_neuromodulation/data/sub-testsub/ses-EphysMedOff/ieeg"
+
+    def read_BIDS_data(PATH_RUN=None, line_noise=50):
+        stored, names, scale, sfreq = mg._read_brainvision(next(ieeg.glob("*_ieeg.vhdr")))
+        tsv = pd.read_csv(next(ieeg.glob("*_channels.tsv")), sep="\t")
+        types = [{"DBS": "dbs", "ECOG": "ecog", "MISC": "misc", "SEEG": "seeg"}[t] for t in tsv["type"]]
+        data = stored.T.astype(np.float64) * scale[:, None]
+        return _Raw(names, types, data, sfreq), data, sfreq, 50, None, None
+
+    nm.io.read_BIDS_data = read_BIDS_data
+    import py_neuromodulation.utils.io as nmio
+
+    nmio.read_BIDS_data = read_BIDS_data
+    if swap:
+        import py_neuromodulation.features as nmf
+        import py_neuromodulation.filter as nmflt
+        import py_neuromodulation.processing as nmp
+
+        import __graft_entry__ as ge
+        import py_neuromodulation_amd.features as amd_f
+        import py_neuromodulation_amd.processing as amd_p
+        from py_neuromodulation_amd import _lib
+
+        if _lib._default is None:
+            _lib._default = _lib.NmxLibrary(ge.build_emu())
+        for c in FEATURE_CLASSES:
+            setattr(nmf, c, getattr(amd_f, c))
+        for c in PREPROCESSOR_CLASSES:
+            setattr(nmp, c, getattr(amd_p, c))
+        nmflt.NotchFilter = amd_p.NotchFilter
+        nmflt.MNEFilter = amd_f.MNEFilter
+    tests = Path(ref_shim.REFERENCE_ROOT) / "tests"
+    args = [str(tests / f) for f in IN_SCOPE] + ["-q", "-p", "no:cacheprovider", "-o", "addopts=", "--rootdir", str(tests),
+                                                  "-W", "ignore", "--tb=line", "-c", "/dev/null"]
+    os.chdir("/tmp")
+    return int(pytest.main(args))
+
+
+if __name__ == "__main__":
+    sys.exit(main("--plain" not in sys.argv))

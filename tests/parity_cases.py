@@ -2531,3 +2531,146 @@ def case_dc_nan(lib):
             keys = [k for k, o in zip(cols, ok) if o]
             n_bad, rep, _ = parity.compare(keys, got[r][ok], want[r][ok], s, 1000.0, 80.0, 1000, verifier=pv.row(r))
             assert n_bad == 0, f"{tag}, hop {r}\n{rep}"
+
+
+class _default_library:
+    """The plugin classes load the package's own library; the cases that drive them run on `lib` through this."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        from py_neuromodulation_amd import _lib
+
+        self.prev, _lib._default = _lib._default, self.lib
+
+    def __exit__(self, *exc):
+        from py_neuromodulation_amd import _lib
+
+        _lib._default = self.prev
+
+
+def case_standalone_classes_any_length(lib):
+    """What the reference's own tests do with the stand-alone classes (found by running /root/reference/tests with the
+    classes swapped, tests/golden/run_reference_tests.py): MNEFilter.filter_data on 10 s at 4 kHz
+    (tests/test_nm_filter.py:11-96), NotchFilter.process on a 1-D window of `sfreq` samples at 150 / 200 Hz
+    (tests/test_notch_filter.py:7-31), a recording longer than one plan's window through the notch and the
+    preprocessing filter -- segments with halos (engine.long_segments) must equal ONE long convolution."""
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings, features, fir_design
+    from py_neuromodulation_amd.engine import MAX_PLAN_WINDOW, long_segments
+    from py_neuromodulation_amd.processing import NotchFilter, PreprocessingFilter
+
+    # every output sample exactly once, each at least `halo` from a cut that is not an end of the recording
+    for T, halo in ((40000, 1999), (16385, 499), (100000, 7998), (16384 + 15386, 499)):
+        nxt = 0
+        for lo, a, b in long_segments(T, halo):
+            assert a == nxt and b > a and 0 <= lo and lo + MAX_PLAN_WINDOW <= T
+            assert (lo == 0 or a - lo >= halo) and (lo + MAX_PLAN_WINDOW == T or lo + MAX_PLAN_WINDOW - b >= halo)
+            nxt = b
+        assert nxt == T
+    rng = np.random.default_rng(77)
+    with _default_library(lib):
+        sfreq, T = 4000, 40000
+        t = np.arange(T) / sfreq
+        x = np.sin(2 * np.pi * t * np.array([[10.0], [50.0]])) + 0.3 * rng.standard_normal((2, T)) + 40.0
+        f_ranges = [[4, 8], [8, 12], [13, 35], [60, 200], [200, 500]]
+        for flen, lt, f_ranges in (("999ms", 4, f_ranges), ("1999ms", 8, [[13, 35]]), ("3999ms", 8, [[13, 35]])):
+            f = features.MNEFilter(f_ranges, sfreq, filter_length=flen, l_trans_bandwidth=lt, h_trans_bandwidth=lt)
+            y = f.filter_data(x)
+            assert y.shape == (2, len(f_ranges), T)
+            from scipy.signal import fftconvolve   # filter/mne_filter.py:118-124: "same" convolution per filter
+
+            want = np.stack([np.stack([fftconvolve(row, np.asarray(tp, float), "same") for tp in f.filter_bank])
+                             for row in x])
+            np.testing.assert_allclose(y, want, rtol=0, atol=2e-5 * np.abs(want).max())
+            y1 = f.filter_data(x[1])
+            assert y1.shape == (1, len(f_ranges), T)
+            np.testing.assert_array_equal(y1[0], y[1])
+        for fs in (150, 200, 500):
+            d = rng.random(fs)
+            nf = NotchFilter(fs, 50)
+            got = nf.process(d)
+            assert got.shape == (fs,)
+            want = orc.NotchFilter(fs, 50, taps=nf.filter_bank).process(d)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max())
+        xl = rng.standard_normal((3, 40000)) * 20 + np.array([[0.0], [300.0], [-50.0]])
+        nf = NotchFilter(1000.0, 50)
+        want = orc.NotchFilter(1000.0, 50, taps=nf.filter_bank).process(xl)
+        np.testing.assert_allclose(nf.process(xl), want, rtol=0, atol=2e-5 * np.abs(want).max())
+        s = NMSettings.get_default()
+        s.preprocessing_filter.bandstop_filter = s.preprocessing_filter.lowpass_filter = True
+        s.preprocessing_filter.bandpass_filter = False
+        s = s.validate()
+        pf = PreprocessingFilter(s, 1000.0)
+        want = orc.PreprocessingFilter(s, 1000.0, taps=fir_design.preprocessing_filter_bank(s.preprocessing_filter, 1000.0)).process(xl)
+        np.testing.assert_allclose(pf.process(xl), want, rtol=0, atol=2e-5 * np.abs(want).max())
+
+
+def case_plugin_classes_as_the_reference_uses_them(lib):
+    """The calls the reference's loop and its tests make on ONE feature class: windows of two lengths from a sampling
+    rate that is not a whole number of samples per segment (stream/generator.py:41-53, tests/test_timing.py:43-76: 332 /
+    333 samples behind the resampler) with the burst history carried from length to length, an empty channel list
+    (tests/test_sharpwave.py:46-62), and pydantic's ValidationError for a burst band that is not defined
+    (features/bursts.py:68-73, tests/test_bursts.py:9-13)."""
+    import pytest
+    from oracle import nm_oracle as orc
+    from py_neuromodulation_amd import NMSettings, features
+
+    from tests import parity
+
+    rng = np.random.default_rng(78)
+    with _default_library(lib):
+        s = NMSettings.get_default()
+        s.segment_length_features_ms = 333
+        s.fft_settings.windowlength_ms = 300
+        s = s.validate()
+        ch, sfreq = ["a", "b"], 1000.0
+        hj, ohj = features.Hjorth(s, ch, sfreq), orc.Hjorth(s, ch, sfreq)
+        ff, off = features.FFT(s, ch, sfreq), orc.FFT(s, ch, sfreq)
+        for n in (333, 332, 332, 333, 334, 333):
+            x = rng.standard_normal((2, n)) * 10 + np.sin(2 * np.pi * 22 * np.arange(n) / sfreq) * 30
+            for got, want in ((hj.calc_feature(x), ohj.calc_feature(x)), (ff.calc_feature(x), off.calc_feature(x))):
+                assert list(got) == list(want)
+                n_bad, rep, _ = parity.compare(list(got), np.array(list(got.values())), list(want.values()), s, sfreq,
+                                               40.0, n, verifier=parity.Verifier(s, ch, sfreq, x))
+                assert n_bad == 0, rep
+        # burst history and thresholds travel with the stream across the lengths
+        sb = NMSettings.get_default()
+        sb.segment_length_features_ms = 1000
+        sb = sb.validate()
+        fs = 1111.111
+        bu, obu = features.Bursts(sb, ch, fs), orc.Bursts(sb, ch, fs)
+        t0, misses, total = 0, 0, 0
+        for hop in range(40):
+            n = 1111 + (hop % 3 == 1)
+            tt = (t0 + np.arange(n)) / fs
+            t0 += 111
+            amp = 1.0 + 0.8 * np.sin(2 * np.pi * 0.7 * tt)
+            x = np.stack([amp * np.sin(2 * np.pi * 18 * tt), amp * np.sin(2 * np.pi * 70 * tt + 1)]) * 20 \
+                + rng.standard_normal((2, n))
+            got, want = bu.calc_feature(x), obu.calc_feature(x)
+            assert list(got) == list(want)
+            g, w = np.array(list(got.values())), np.array(list(want.values()))
+            bad = ~np.isclose(g, w, rtol=1e-4, atol=1e-6)
+            misses += int(bad.sum())
+            total += g.size
+        assert len(bu._engines) == 2
+        assert misses <= 0.01 * total, (misses, total)   # (a threshold crossing decided in fp32 may differ)
+        # an empty channel list: the settings are still checked, nothing is computed
+        sw = features.SharpwaveAnalyzer(NMSettings.get_default().validate(), [], 1000.0)
+        assert sw.calc_feature(np.zeros((0, 1000))) == {}
+        bad = NMSettings.get_default()
+        bad.fft_settings.windowlength_ms = 2000
+        with pytest.raises(AssertionError):
+            features.FFT(bad, [], 1000.0)
+        wrong = NMSettings.get_default()
+        wrong.bursts_settings.frequency_bands = ["wrong_band"]
+        try:
+            from pydantic import ValidationError as expected
+        except ImportError:
+            from py_neuromodulation_amd.settings import SettingsError as expected
+        with pytest.raises(expected):
+            features.Bursts(wrong, ["ch1", "ch2"], 1000)
+        with pytest.raises(ValueError):
+            features.Bursts(wrong, ["ch1", "ch2"], 1000)

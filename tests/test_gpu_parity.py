@@ -1030,3 +1030,11 @@ def test_bench_two_gloo_ranks_share_one_gpu(scaling):
         assert d["exchange_ms_per_step"] is not None
     else:
         assert d["config"]["channels_per_gpu"] == 256
+
+
+def test_standalone_classes_any_length(gpu_lib):
+    pc.case_standalone_classes_any_length(gpu_lib)
+
+
+def test_plugin_classes_as_the_reference_uses_them(gpu_lib):
+    pc.case_plugin_classes_as_the_reference_uses_them(gpu_lib)

@@ -334,3 +334,11 @@ def test_matrix_pipe_spectrum_kernel_arithmetic_and_flags(emu_lib):
 
 def test_nan_on_an_offset_channel_without_a_rereference(emu_lib):
     pc.case_dc_nan(emu_lib)
+
+
+def test_standalone_classes_any_length(emu_lib):
+    pc.case_standalone_classes_any_length(emu_lib)
+
+
+def test_plugin_classes_as_the_reference_uses_them(emu_lib):
+    pc.case_plugin_classes_as_the_reference_uses_them(emu_lib)
