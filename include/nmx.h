@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NMX_ABI_VERSION 10
+#define NMX_ABI_VERSION 11
 
 /* error codes */
 #define NMX_OK 0
@@ -350,6 +350,24 @@ int nmx_host_free(void* p);
  * the driver NOW, until at most keep_bytes stay cached (0: all) -- for a process that shares its GPU (a second rank,
  * another allocator) or is done with the engine for a while.  *freed (may be NULL) = bytes released.  Thread safe. */
 int nmx_device_pool_trim(int64_t keep_bytes, int64_t* freed);
+
+/* The stand-alone ReReferencer in FLOAT64 (processing/rereference.py:88-102: `ref_matrix @ data` on the float64 array the
+ * reference holds; its tests compare at rtol 1e-7, tests/test_rereference.py:57-182): y[n_out][ldy] = R[n_out][n_in] x
+ * x[n_in][ldx] over n_samples columns of any number, float64 in, float64 accumulation in the order of the columns of R,
+ * float64 out -- IEEE semantics of a dense product (a NaN / inf sample reaches every row, as 0 x NaN does there).  Host
+ * pointers; one kernel on `device`, HBM bound.  Inside a plan the re-reference runs on the fp32 windows (1e-5). */
+int nmx_reref_f64(int device, const double* ref_matrix, int n_out, int n_in, const double* x, int64_t ldx,
+                  int64_t n_samples, double* y, int64_t ldy);
+
+/* The stand-alone Resampler in FLOAT64 (processing/resample.py:42-60: mne.filter.resample(x.astype(float64), up = ratio,
+ * down = 1) -- FFT method, boxcar window, npad "auto", reflect_limited padding) for ANY window length (the reference's tests
+ * resample 10 s at 4 kHz in one call, tests/test_nm_resample.py:8-47): y[n_channels][ldy] <- x[n_channels][ldx], n_out =
+ * round(ratio * n_samples) (round-half-even, as Python's) samples per row.  Host pointers; power-of-two Stockham transforms
+ * over HBM in float64, Bluestein's chirp convolution for a resampled padded length that is not a power of two
+ * (nmx_k_resample64.h).  NaN / inf samples spread over their row as in the reference.  Inside a plan the resampler runs on
+ * fp32 windows in LDS (raw_window / resample_ratio of the plan description). */
+int nmx_resample_f64(int device, const double* x, int64_t ldx, int n_channels, int64_t n_samples, double ratio, double* y,
+                     int64_t ldy, int64_t n_out);
 
 /* Host-side staging passes of the boundary (no device work; a few threads of their own, n_threads <= 0: an eighth of the machine, 4 .. 16).  They
  * replace what a NumPy host does at 1 - 3 GB/s around a batch call -- the reference hands float64 rows

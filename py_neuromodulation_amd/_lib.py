@@ -12,7 +12,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-NMX_ABI_VERSION = 10
+NMX_ABI_VERSION = 11
 NMX_MAX_BANDS = 16
 NMX_MAX_FILTERS = 24
 NMX_MAX_SW_COMBOS = 48
@@ -84,7 +84,7 @@ _EXPORTS = [
     "nmx_state_export", "nmx_state_import", "nmx_last_timing_ms", "nmx_last_kernels",
     "nmx_norm_create", "nmx_norm_destroy", "nmx_norm_process", "nmx_norm_reset",
     "nmx_norm_state_size", "nmx_norm_state_export", "nmx_norm_state_import",
-    "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free", "nmx_device_pool_trim",
+    "nmx_plan_attach_norm", "nmx_host_alloc", "nmx_host_free", "nmx_device_pool_trim", "nmx_reref_f64", "nmx_resample_f64",
     "nmx_plan_carries_offsets", "nmx_plan_set_offsets", "nmx_plan_get_offsets", "nmx_plan_set_pipeline",
     "nmx_host_stage_rows", "nmx_host_group_sums", "nmx_host_stage_parts", "nmx_host_widen_rows",
 ]
@@ -156,6 +156,10 @@ class NmxLibrary:
         L.nmx_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
         L.nmx_host_free.argtypes = [C.c_void_p]
         L.nmx_device_pool_trim.argtypes = [C.c_int64, C.POINTER(C.c_int64)]
+        L.nmx_resample_f64.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
+                                       C.c_int64]
+        L.nmx_reref_f64.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                    C.c_int64]
         L.nmx_plan_set_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nmx_plan_carries_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.nmx_plan_set_offsets.argtypes = [C.c_void_p, C.c_void_p]

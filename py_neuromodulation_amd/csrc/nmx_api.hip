@@ -15,6 +15,7 @@
 #include "nmx_k_prep.h"
 #include "nmx_k_rawnorm.h"
 #include "nmx_k_resample.h"
+#include "nmx_k_resample64.h"
 #include "nmx_k_sharpwave.h"
 #include "nmx_k_timeosc.h"
 
@@ -584,6 +585,29 @@ static void be_launch_reref_struct(const NmxRerefStructArgs& A, be_stream_t s) {
 static void be_launch_shift(const NmxShiftArgs& A, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_shift, dim3((unsigned)((A.T + 255) / 256), (unsigned)A.C), dim3(256), 0, s, A);
   nmxi_note_kernel("nmx_kern_shift");
+}
+__global__ void __launch_bounds__(256) nmx_kern_reref64(const NmxReref64Args A) {
+  nmx_reref64_tile(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y * NMX_REREF64_ROWS);
+}
+static void be_launch_reref64(const NmxReref64Args& A, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_reref64, dim3((unsigned)((A.T + 255) / 256), (unsigned)((A.C + NMX_REREF64_ROWS - 1) / NMX_REREF64_ROWS)),
+                     dim3(256), 0, s, A);
+}
+__global__ void __launch_bounds__(256) nmx_kern_rs64_elem(const NmxResample64Args A, int mode, const NmxCplx64* src, NmxCplx64* dst) {
+  nmx_rs64_elem(A, mode, src, dst, (int)blockIdx.y, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) nmx_kern_rs64_pass(const NmxCplx64* src, NmxCplx64* dst, long long ld, long long n, long long ns,
+                                                          long long st, int sign) {
+  nmx_rs64_pass(src, dst, ld, n, ns, st, sign, (int)blockIdx.y, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+static void be_launch_rs64_elem(const NmxResample64Args& A, int mode, const NmxCplx64* src, NmxCplx64* dst, long long n, int rows,
+                                be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_rs64_elem, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, s, A, mode, src, dst);
+}
+static void be_launch_rs64_pass(const NmxCplx64* src, NmxCplx64* dst, long long ld, long long n, long long ns, long long st, int sign,
+                                int rows, be_stream_t s) {
+  hipLaunchKernelGGL(nmx_kern_rs64_pass, dim3((unsigned)((n / 2 + 255) / 256), (unsigned)rows), dim3(256), 0, s, src, dst, ld, n, ns,
+                     st, sign);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t s) {
   hipLaunchKernelGGL(nmx_kern_nanmask, dim3(n_items), dim3(64), 64 * sizeof(float), s, A);

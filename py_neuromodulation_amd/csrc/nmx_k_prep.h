@@ -268,6 +268,34 @@ NMX_DEV void nmx_shift_sample(const NmxShiftArgs& A, long long t, int c) {
   if (t < A.T) A.y[(long long)c * A.ldy + t] = nmx_clean_sub(A.x[(long long)c * A.ldx + t], A.sub, A.nanv, c);
 }
 
+// ---- the stand-alone ReReferencer in float64 (nmx_reref_f64): y = R x, one thread per sample column and NMX_REREF64_ROWS
+// output rows; x is read once per row group (coalesced 8-byte loads), R broadcast from the scalar cache ----------------------
+#define NMX_REREF64_ROWS 8
+struct NmxReref64Args {
+  const double* x;   // [C_in][ldx]
+  long long ldx;
+  double* y;         // [C][ldy]
+  long long ldy;
+  const double* R;   // [C][C_in]
+  int C, C_in;
+  long long T;
+};
+NMX_DEV void nmx_reref64_tile(const NmxReref64Args& A, long long t, int c0) {
+  if (t >= A.T) return;
+  double acc[NMX_REREF64_ROWS];
+  for (int i = 0; i < NMX_REREF64_ROWS; ++i) acc[i] = 0.0;
+  const int nrow = (A.C - c0) < NMX_REREF64_ROWS ? (A.C - c0) : NMX_REREF64_ROWS;
+  for (int j = 0; j < A.C_in; ++j) {
+    const double v = A.x[(long long)j * A.ldx + t];
+#ifndef NMX_HOST_EMU
+#pragma unroll
+#endif
+    for (int i = 0; i < NMX_REREF64_ROWS; ++i)
+      if (i < nrow) acc[i] += A.R[(long long)(c0 + i) * A.C_in + j] * v;
+  }
+  for (int i = 0; i < nrow; ++i) A.y[(long long)(c0 + i) * A.ldy + t] = acc[i];
+}
+
 struct NmxNanMaskArgs {
   const float* x;
   long long ldx;

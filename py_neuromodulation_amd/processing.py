@@ -1,17 +1,20 @@
 """NMPreprocessor-compatible pre-processing + host-side feature normalisation.
 
-  NotchFilter   filter/notch_filter.py:9-93     process(data[C, W]) -> data   (HIP FIR kernel)
-  ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data  (HIP kernel)
-  PreprocessingFilter processing/filter_preprocessing.py:44-94  chained single FIRs (HIP FIR kernel)
-  RawNormalizer processing/normalization.py:113-116  mean / zscore / median / zscore-median / robust / minmax of the
-                raw window against its history
-  Resampler     processing/resample.py:19-60    FFT resampling per window (HIP kernel; restated MNE
-                                                algorithm, parity unpinned); identity at ratio 1
+  NotchFilter   filter/notch_filter.py:9-93     process(data[C, W] or [W]) -> data   (HIP FIR kernel; any length)
+  ReReferencer  processing/rereference.py:9-102 process(data) = ref_matrix @ data in float64 (HIP kernel nmx_reref_f64)
+  PreprocessingFilter processing/filter_preprocessing.py:44-94  chained single FIRs (HIP FIR kernel; any length)
+  RawNormalizer processing/normalization.py:113-116  mean / zscore / median / zscore-median / robust / minmax / quantile /
+                power of the raw window against its history
+  Resampler     processing/resample.py:19-60    FFT resampling in float64, any length (HIP kernels nmx_resample_f64;
+                restated MNE algorithm, parity unpinned); identity at ratio 1
   FeatureNormalizer processing/normalization.py:119-122 -- the reference's one-vector call shape over the device
-                normaliser below ("power", scikit-learn's PowerTransformer, is not implemented: no host path).
-  DeviceFeatureNormalizer  the same post-processing for every other method (mean, median, zscore (default),
-                zscore-median, robust, minmax, quantile) as a HIP scan over a whole batch of hops
-                (libnmx nmx_norm_*, SURVEY 8f "next" #1).
+                normaliser below.
+  DeviceFeatureNormalizer  the same post-processing for every method (mean, median, zscore (default), zscore-median,
+                robust, minmax, quantile, power) as a HIP scan over a whole batch of hops (libnmx nmx_norm_*,
+                SURVEY 8f "next" #1).
+
+These are the STAND-ALONE objects (what a user of the reference constructs by hand, and what its tests exercise); inside
+``DataProcessor`` / ``Stream`` the same stages are fused into the plan and run on its fp32 windows.
 """
 
 from __future__ import annotations
@@ -24,22 +27,16 @@ from .engine import MAX_PLAN_WINDOW, HotPathEngine, long_segments
 from .settings import NMSettings
 
 
-def _pre_engine(C_in, W, sfreq, notch_taps=None, ref_matrix=None, C_out=None, resample_to=None,
-                pre_taps=None, raw_norm=None):
+def _pre_engine(C, W, sfreq, notch_taps=None, pre_taps=None, raw_norm=None):
+    """A plan that only pre-processes (feature "return_raw") ``C`` channels x ``W`` samples: the stand-alone FIR stages
+    and the raw normaliser reuse the kernels of the fused path."""
     s = NMSettings.get_default()
-    C = C_out if C_out is not None else C_in
+    names = [f"c{i}" for i in range(C)]
     if raw_norm is not None:
-        return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
-                             raw_norm=raw_norm, window=W)
+        return HotPathEngine(s, names, sfreq, features=["return_raw"], raw_norm=raw_norm, window=W)
     if pre_taps is not None:
-        return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
-                             pre_taps=pre_taps, window=W)
-    if resample_to is not None:   # W raw samples at `sfreq` -> round(ratio * W) at `resample_to`
-        return HotPathEngine(s, [f"c{i}" for i in range(C)], resample_to, features=["return_raw"],
-                             notch_taps=notch_taps, ref_matrix=ref_matrix, resample_from=sfreq,
-                             raw_window=W, window=int(round(float(resample_to / sfreq) * W)))
-    return HotPathEngine(s, [f"c{i}" for i in range(C)], sfreq, features=["return_raw"],
-                         notch_taps=notch_taps, ref_matrix=ref_matrix, window=W)
+        return HotPathEngine(s, names, sfreq, features=["return_raw"], pre_taps=pre_taps, window=W)
+    return HotPathEngine(s, names, sfreq, features=["return_raw"], notch_taps=notch_taps, window=W)
 
 
 def _windowed(engines: dict, make, data: np.ndarray, halo: int) -> np.ndarray:
@@ -81,20 +78,32 @@ class NotchFilter:
 
 
 class ReReferencer:
-    def __init__(self, sfreq: float, channels) -> None:
+    """processing/rereference.py:9-102 as a stand-alone object: ``ref_matrix @ data`` in FLOAT64 on the device
+    (nmx_reref_f64: the reference's own tests compare the result with float64 arithmetic at rtol 1e-7), any number of
+    samples.  Inside ``DataProcessor`` / ``Stream`` the re-reference is a stage of the plan on its fp32 windows."""
+
+    def __init__(self, sfreq: float, channels, device: int = 0) -> None:
         self.sfreq = sfreq
         self.ref_matrix = chmod.reref_matrix(chmod.load_channels(channels))
-        self._engines: dict = {}
+        self.device = int(device)
 
     def process(self, data: np.ndarray) -> np.ndarray:
         if self.ref_matrix is None:
             return data
-        data = np.asarray(data, np.float64)
-        if data.shape not in self._engines:
-            self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq,
-                                                    ref_matrix=self.ref_matrix,
-                                                    C_out=self.ref_matrix.shape[0])
-        return self._engines[data.shape].preprocess_window(data)
+        from ._lib import get_library
+
+        lib = get_library()
+        R = np.ascontiguousarray(self.ref_matrix, dtype=np.float64)
+        x = np.asarray(data, dtype=np.float64)
+        if x.ndim != 2 or x.shape[0] != R.shape[1]:
+            raise ValueError(f"expected data with {R.shape[1]} rows, got {x.shape}")
+        if x.strides[1] != 8 or x.strides[0] < 8 * x.shape[1] or x.strides[0] % 8:
+            x = np.ascontiguousarray(x)
+        y = np.empty((R.shape[0], x.shape[1]), np.float64)
+        lib.check(lib.lib.nmx_reref_f64(self.device, R.ctypes.data, R.shape[0], R.shape[1], x.ctypes.data,
+                                        x.strides[0] // 8 if x.shape[0] > 1 else max(x.shape[1], 1), x.shape[1],
+                                        y.ctypes.data, max(y.shape[1], 1)))
+        return y
 
 
 class PreprocessingFilter:
@@ -139,24 +148,32 @@ class RawNormalizer:
 
 
 class Resampler:
-    """processing/resample.py:19-60: ``mne.filter.resample(data, up = new / old, down = 1)`` per window
-    (FFT method, reflect_limited padding) on the device; identity at ratio 1 like the reference."""
+    """processing/resample.py:19-60 as a stand-alone object: ``mne.filter.resample(data.astype(float64), up = new / old,
+    down = 1)`` along the last axis (FFT method, reflect_limited padding) in FLOAT64 on the device, for any window length
+    (nmx_resample_f64; the reference's tests resample 10 s of data in one call); identity at ratio 1 like the reference.
+    Inside ``DataProcessor`` / ``Stream`` the resampler is a stage of the plan on its fp32 windows."""
 
-    def __init__(self, sfreq: float, resample_freq_hz: float, **kwargs) -> None:
+    def __init__(self, sfreq: float, resample_freq_hz: float, device: int = 0, **kwargs) -> None:
         self.sfreq = float(sfreq)
         self.resample_freq_hz = float(resample_freq_hz)
         ratio = float(resample_freq_hz / sfreq)
         self.up = 0.0 if ratio == 1.0 else ratio
-        self._engines: dict = {}
+        self.device = int(device)
 
     def process(self, data: np.ndarray) -> np.ndarray:
         if not self.up:
             return data
+        from ._lib import get_library
+
+        lib = get_library()
         data = np.asarray(data, dtype=np.float64)
-        if data.shape not in self._engines:
-            self._engines[data.shape] = _pre_engine(data.shape[0], data.shape[1], self.sfreq,
-                                                    resample_to=self.resample_freq_hz)
-        return self._engines[data.shape].preprocess_window(data)
+        x = np.ascontiguousarray(data.reshape(-1, data.shape[-1]))
+        n_out = int(round(self.up * x.shape[1]))
+        y = np.empty((x.shape[0], n_out), np.float64)
+        if x.shape[0] and x.shape[1]:
+            lib.check(lib.lib.nmx_resample_f64(self.device, x.ctypes.data, x.shape[1], x.shape[0], x.shape[1], self.up,
+                                               y.ctypes.data, max(n_out, 1), n_out))
+        return y.reshape(data.shape[:-1] + (n_out,))
 
 
 class FeatureNormalizer:

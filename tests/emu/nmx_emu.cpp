@@ -23,6 +23,7 @@
 #include "../../py_neuromodulation_amd/csrc/nmx_k_prep.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_rawnorm.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_resample.h"
+#include "../../py_neuromodulation_amd/csrc/nmx_k_resample64.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_sharpwave.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_timeosc.h"
 #include "../../py_neuromodulation_amd/csrc/nmx_k_specmm.h"
@@ -188,6 +189,20 @@ static void be_launch_power(const NmxPowerPrepArgs& P, const NmxPowerArgs& A, be
 static void be_launch_shift(const NmxShiftArgs& A, be_stream_t) {
   for (int c = 0; c < A.C; ++c)
     for (long long t = 0; t < A.T; ++t) nmx_shift_sample(A, t, c);
+}
+static void be_launch_reref64(const NmxReref64Args& A, be_stream_t) {
+  for (int c0 = 0; c0 < A.C; c0 += NMX_REREF64_ROWS)
+    for (long long t = 0; t < A.T; ++t) nmx_reref64_tile(A, t, c0);
+}
+static void be_launch_rs64_elem(const NmxResample64Args& A, int mode, const NmxCplx64* src, NmxCplx64* dst, long long n, int rows,
+                                be_stream_t) {
+  for (int c = 0; c < rows; ++c)
+    for (long long i = 0; i < n; ++i) nmx_rs64_elem(A, mode, src, dst, c, i);
+}
+static void be_launch_rs64_pass(const NmxCplx64* src, NmxCplx64* dst, long long ld, long long n, long long ns, long long st, int sign,
+                                int rows, be_stream_t) {
+  for (int c = 0; c < rows; ++c)
+    for (long long t = 0; t < n / 2; ++t) nmx_rs64_pass(src, dst, ld, n, ns, st, sign, c, t);
 }
 static void be_launch_nanmask(const NmxNanMaskArgs& A, int n_items, be_stream_t) {
   float sm[64];

@@ -798,7 +798,7 @@ def case_bandpower_kalman_sequence(lib):
 
 
 def case_resampler(lib):
-    """Resampler.process == the restated mne.filter.resample (oracle/mne_restated.py, PARITY UNPINNED
+    """The plan's resampler stage == the restated mne.filter.resample (oracle/mne_restated.py, PARITY UNPINNED
     against MNE itself): down- and up-sampling, power-of-two and composite lengths, an odd resampled
     length (full complex inverse), NaN cleaning, and the engine path notch -> resample -> features.
     Tolerance: fp32 transforms of ~1e3..4e3 points on data of amplitude A: 2e-5 * A absolute."""
@@ -813,12 +813,13 @@ def case_resampler(lib):
                               (1000, 250, 1000), (1375, 500, 1375), (1000, 1000, 300)):
         t = np.arange(W) / sf_old
         x = rng.standard_normal((3, W)) * 20 + 50 * np.sin(2 * np.pi * 11 * t) + rng.uniform(-300, 300, (3, 1))
-        rs = Resampler(sf_old, sf_new)
-        if rs.up:   # the class builds its engine lazily with the product library; inject `lib` here
-            rs._engines[x.shape] = HotPathEngine(
+        if sf_old == sf_new:
+            got = Resampler(sf_old, sf_new).process(x)     # (identity: the array itself, like the reference)
+            assert got is x
+        else:   # the plan's fp32 LDS resampler on one window (the stand-alone class: case_standalone_resampler_float64)
+            got = HotPathEngine(
                 NMSettings.get_default(), [f"c{i}" for i in range(3)], sf_new, features=["return_raw"],
-                resample_from=sf_old, raw_window=W, window=int(round(sf_new / sf_old * W)), lib=lib)
-        got = rs.process(x)
+                resample_from=sf_old, raw_window=W, window=int(round(sf_new / sf_old * W)), lib=lib).preprocess_window(x)
         want = mr.resample(x, up=sf_new / sf_old, down=1.0)
         assert got.shape == want.shape == (3, int(round(sf_new / sf_old * W)))
         amp = np.abs(x).max()
@@ -2674,3 +2675,86 @@ def case_plugin_classes_as_the_reference_uses_them(lib):
             features.Bursts(wrong, ["ch1", "ch2"], 1000)
         with pytest.raises(ValueError):
             features.Bursts(wrong, ["ch1", "ch2"], 1000)
+
+
+def case_standalone_rereferencer_float64(lib):
+    """The stand-alone ReReferencer is `ref_matrix @ data` in float64 (processing/rereference.py:88-102): the reference's
+    tests hold it to rtol 1e-7 against float64 arithmetic (tests/test_rereference.py:57-182); nmx_reref_f64 keeps float64
+    from the caller's array to the result, for any number of samples, strided rows, IEEE NaN / inf semantics."""
+    import pandas as pd
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.processing import ReReferencer
+
+    rng = np.random.default_rng(91)
+    n = 21
+    names = [f"c{i}" for i in range(n)]
+    types = ["ecog"] * 9 + ["dbs"] * 8 + ["seeg"] * 4
+    ref = ["average"] * 9 + [f"c{9 + (i + 1) % 8}" for i in range(8)] + ["None", "c17&c19", "average", "average"]
+    ch = pd.DataFrame({"name": names, "rereference": ref, "used": [1] * n, "target": [0] * n, "type": types,
+                       "status": ["good"] * 20 + ["bad"], "new_name": names})
+    with _default_library(lib):
+        rr = ReReferencer(1000.0, ch)
+        R = chmod.reref_matrix(chmod.load_channels(ch))
+        n = R.shape[1]   # (the used rows of the table)
+        assert R.shape == (n, n) and n >= 20
+        for T in (1, 255, 1000, 40001):
+            x = rng.standard_normal((n, T)) * 50 + rng.uniform(-4000, 4000, (n, 1))
+            got = rr.process(x)
+            assert got.dtype == np.float64 and got.shape == (n, T)
+            np.testing.assert_allclose(got, R @ x, rtol=1e-12, atol=1e-11)
+        big = rng.standard_normal((2 * n, 3000)) * 1e3
+        view = big[::2, 500:2500]                      # strided rows, offset start
+        np.testing.assert_allclose(rr.process(view), R @ view, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(rr.process(np.asfortranarray(x[:, :300])), R @ x[:, :300], rtol=1e-12, atol=1e-11)
+        x = rng.standard_normal((n, 64))
+        x[3, 5], x[12, 7], x[0, 9] = np.nan, np.inf, -np.inf
+        with np.errstate(invalid="ignore"):
+            want = R @ x
+        got = rr.process(x)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-12, atol=1e-11)
+        import pytest
+
+        with pytest.raises(ValueError):
+            rr.process(x[:5])
+        assert rr.process(np.zeros((n, 0))).shape == (n, 0)
+
+
+def case_standalone_resampler_float64(lib):
+    """The stand-alone Resampler is mne.filter.resample on the float64 array (processing/resample.py:42-60), any length:
+    the reference's tests resample 10 s at 4 kHz and at 1 kHz in one call (tests/test_nm_resample.py:8-47).
+    nmx_resample_f64 against the oracle's restatement: power-of-two and Bluestein lengths, odd / prime padded lengths,
+    windows of 1 - 5 samples, N-D input, NaN."""
+    from oracle import mne_restated as mr
+    from py_neuromodulation_amd.processing import Resampler
+
+    rng = np.random.default_rng(92)
+    with _default_library(lib):
+        for fs, to, T in ((4000.0, 1000.0, 40000), (1000.0, 4000.0, 10000), (1375.0, 1000.0, 1375), (1000.0, 900.0, 333),
+                          (2048.0, 1000.0, 5000), (1000.0, 1111.0, 999), (1000.0, 500.0, 5), (1000.0, 3000.0, 1),
+                          (1000.0, 250.0, 2), (22050.0, 1000.0, 22050), (1000.0, 999.0, 70001)):
+            x = rng.standard_normal((3, T)) * 10 + rng.uniform(-1e3, 1e3, (3, 1))
+            got = Resampler(fs, to).process(x)
+            want = mr.resample(x, up=to / fs, down=1.0)
+            assert got.shape == want.shape and got.dtype == np.float64
+            if want.size:
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max())
+        r = Resampler(4000.0, 1000.0)
+        t = np.linspace(0, 10, 40000)
+        data = np.sin(2 * np.pi * t * np.arange(10, 51, 10)[:, None])        # (tests/test_nm_resample.py:8-30)
+        out = r.process(data)
+        assert out.shape == (5, 10000)
+        np.testing.assert_allclose(out[:, 50:-50], data[:, ::4][:, 50:-50], atol=2e-3)
+        one = r.process(data[2])                                            # 1-D in, 1-D out
+        assert one.shape == (10000,)
+        np.testing.assert_array_equal(one, out[2])
+        cube = rng.standard_normal((2, 3, 400))
+        np.testing.assert_allclose(r.process(cube), mr.resample(cube.reshape(6, 400), up=0.25).reshape(2, 3, 100),
+                                   rtol=0, atol=1e-12)
+        bad = data[:2, :4000].copy()
+        bad[1, 77] = np.nan
+        y = r.process(bad)
+        assert np.isnan(y[1]).all() and not np.isnan(y[0]).any()
+        same = Resampler(1000.0, 1000.0)
+        assert same.process(data) is data

@@ -1038,3 +1038,11 @@ def test_standalone_classes_any_length(gpu_lib):
 
 def test_plugin_classes_as_the_reference_uses_them(gpu_lib):
     pc.case_plugin_classes_as_the_reference_uses_them(gpu_lib)
+
+
+def test_standalone_rereferencer_float64(gpu_lib):
+    pc.case_standalone_rereferencer_float64(gpu_lib)
+
+
+def test_standalone_resampler_float64(gpu_lib):
+    pc.case_standalone_resampler_float64(gpu_lib)

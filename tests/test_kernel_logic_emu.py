@@ -342,3 +342,11 @@ def test_standalone_classes_any_length(emu_lib):
 
 def test_plugin_classes_as_the_reference_uses_them(emu_lib):
     pc.case_plugin_classes_as_the_reference_uses_them(emu_lib)
+
+
+def test_standalone_rereferencer_float64(emu_lib):
+    pc.case_standalone_rereferencer_float64(emu_lib)
+
+
+def test_standalone_resampler_float64(emu_lib):
+    pc.case_standalone_resampler_float64(emu_lib)
