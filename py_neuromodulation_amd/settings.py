@@ -414,7 +414,9 @@ class NMSettings(_Node):
             return settings.validate()
         if settings is None:
             return cls.get_default()
-        if hasattr(settings, "frequency_ranges_hz"):  # the reference's pydantic object
+        if hasattr(settings, "model_dump"):   # the reference's pydantic object (stream/settings.py): the same tree
+            return cls(**settings.model_dump()).validate()
+        if hasattr(settings, "frequency_ranges_hz"):  # any other duck-typed settings object: read as it is
             return settings
         return cls.from_file(settings)
 

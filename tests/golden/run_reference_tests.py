@@ -3,7 +3,8 @@ against the reference package with the engine's plugin classes swapped in (INTEG
 classes, the pre-processors, MNEFilter / NotchFilter), on the test-only logic emulator of the kernels (there is no GPU
 here; on a GPU box the same swap runs on libnmx.so).
 
-    python tests/golden/run_reference_tests.py            # swapped
+    python tests/golden/run_reference_tests.py            # classes swapped (the reference's own Stream / DataProcessor loop)
+    python tests/golden/run_reference_tests.py --stream   # + `nm.Stream` itself = the engine's fused Stream
     python tests/golden/run_reference_tests.py --plain    # the unmodified reference under the same shim: the baseline
 
 What the shim supplies instead of the packages this image lacks: MNE's filter design / resampling as restated in
@@ -50,7 +51,7 @@ class _Raw:
         return self._data
 
 
-def main(swap: bool) -> int:
+def main(swap: bool, stream: bool = False) -> int:
     import numpy as np
     import pandas as pd
     import pytest
@@ -92,6 +93,11 @@ def main(swap: bool) -> int:
             setattr(nmp, c, getattr(amd_p, c))
         nmflt.NotchFilter = amd_p.NotchFilter
         nmflt.MNEFilter = amd_f.MNEFilter
+        if stream:   # the tests construct `nm.Stream(...)` with the reference's pydantic settings and call `.run(...)`
+            import py_neuromodulation.stream as nms
+            import py_neuromodulation_amd as amd
+
+            nm.Stream = nms.Stream = amd.Stream
     tests = Path(ref_shim.REFERENCE_ROOT) / "tests"
     args = [str(tests / f) for f in IN_SCOPE] + ["-q", "-p", "no:cacheprovider", "-o", "addopts=", "--rootdir", str(tests),
                                                   "-W", "ignore", "--tb=line", "-c", "/dev/null"]
@@ -100,4 +106,4 @@ def main(swap: bool) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main("--plain" not in sys.argv))
+    sys.exit(main("--plain" not in sys.argv, "--stream" in sys.argv))

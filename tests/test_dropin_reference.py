@@ -43,3 +43,7 @@ def test_reference_own_tests_pass_with_swapped_plugins():
     assert set(swap_failed) <= set(plain_failed), (swap_failed, plain_failed)
     assert swap_passed >= plain_passed >= 84, (swap_passed, plain_passed)
     assert all(f.startswith("test_all_features.py") for f in swap_failed), swap_failed
+    # ... and with `nm.Stream` itself replaced by the engine's fused Stream (the reference's pydantic settings object in,
+    # the reference's DataFrame / files out)
+    stream_failed, stream_passed = _reference_suite("--stream")
+    assert set(stream_failed) <= set(plain_failed) and stream_passed >= plain_passed, (stream_failed, stream_passed)
