@@ -98,12 +98,90 @@ def main(swap: bool, stream: bool = False) -> int:
             import py_neuromodulation_amd as amd
 
             nm.Stream = nms.Stream = amd.Stream
+    plugins = []
+    record = os.environ.get("NMX_REFTEST_RECORD")
+    if record:
+        # every table a `Stream.run` of the reference's tests returns, on the same (seeded per test) random input in every
+        # mode: `--compare` below holds the tables of two modes against each other
+        import pickle
+
+        class _Recorder:
+            node, calls, tables = "", 0, {}
+
+            def pytest_runtest_setup(self, item):
+                import zlib
+
+                self.node, self.calls = item.nodeid.split("tests/")[-1], 0
+                np.random.seed(zlib.crc32(self.node.encode()))
+
+            def pytest_sessionfinish(self, session):
+                with open(record, "wb") as f:
+                    pickle.dump(self.tables, f)
+
+        rec = _Recorder()
+        plugins.append(rec)
+        cls = nm.Stream
+        inner = cls.run
+
+        raw_tables = bool(os.environ.get("NMX_REFTEST_NONORM"))
+
+        def run(self, *a, **k):
+            if raw_tables:   # the tables before the z-score (which divides by the spread of a column over a few hops: what
+                self.settings.postprocessing.feature_normalization = False   # is 1e-7 of a value becomes 1e-4 of its score)
+            df = inner(self, *a, **k)
+            try:
+                rec.tables[f"{rec.node}#{rec.calls}"] = (list(df.columns), df.to_numpy(dtype=float, copy=True))
+                rec.calls += 1
+            except Exception:   # (a test that mocks the return value)
+                pass
+            return df
+
+        cls.run = run
     tests = Path(ref_shim.REFERENCE_ROOT) / "tests"
     args = [str(tests / f) for f in IN_SCOPE] + ["-q", "-p", "no:cacheprovider", "-o", "addopts=", "--rootdir", str(tests),
                                                   "-W", "ignore", "--tb=line", "-c", "/dev/null"]
     os.chdir("/tmp")
-    return int(pytest.main(args))
+    return int(pytest.main(args, plugins=plugins))
+
+
+def compare(path_a: str, path_b: str) -> int:
+    """Tables of two recorded modes, entry by entry: same tests, same columns, same shapes; relative difference against
+    the larger of |value| and the column's median magnitude (a log-spectrum entry near a null is relative to its column)."""
+    import pickle
+
+    import numpy as np
+
+    a, b = pickle.load(open(path_a, "rb")), pickle.load(open(path_b, "rb"))
+    assert sorted(a) == sorted(b), (sorted(set(a) ^ set(b)))
+    total = beyond5 = beyond3 = nanmis = 0
+    fam = {}
+    for key in sorted(a):
+        (ca, xa), (cb, xb) = a[key], b[key]
+        assert ca == cb and xa.shape == xb.shape, key
+        na, nb = np.isnan(xa), np.isnan(xb)
+        nanmis += int((na != nb).sum())
+        ok = ~(na | nb) & np.isfinite(xa) & np.isfinite(xb)
+        scale = np.maximum(np.abs(xa), np.nanmedian(np.abs(np.where(ok, xa, np.nan)), axis=0, keepdims=True))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = np.where(ok, np.abs(xa - xb) / np.maximum(scale, 1e-300), 0.0)
+        total += int(ok.sum())
+        beyond5 += int((rel > 1e-5).sum())
+        beyond3 += int((rel > 1e-3).sum())
+        for j, c in enumerate(ca):
+            f = next((t for t in ("stft", "welch", "fft", "bandpass", "Sharpwave", "bursts", "RawHjorth", "LineLength", "raw", "time")
+                      if t in c), "other")
+            n, m5, mx = fam.get(f, (0, 0, 0.0))
+            fam[f] = (n + int(ok[:, j].sum()), m5 + int((rel[:, j] > 1e-5).sum()), max(mx, float(rel[:, j].max(initial=0.0))))
+    print(f"{len(a)} tables, {total} finite entries compared; NaN pattern differs in {nanmis}; relative difference > 1e-5 in "
+          f"{beyond5} ({100.0 * beyond5 / max(total, 1):.3f} %), > 1e-3 in {beyond3}")
+    for f, (n, m5, mx) in sorted(fam.items()):
+        print(f"  {f:12s} {n:9d} entries, {m5:6d} beyond 1e-5, max {mx:.2e}")
+    return 0
 
 
 if __name__ == "__main__":
+    if "--compare" in sys.argv:
+        i = sys.argv.index("--compare")
+        sys.exit(compare(sys.argv[i + 1], sys.argv[i + 2]))
+
     sys.exit(main("--plain" not in sys.argv, "--stream" in sys.argv))
