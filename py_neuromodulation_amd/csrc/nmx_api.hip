@@ -52,6 +52,14 @@ __global__ void __launch_bounds__(NMX_FILL_NT) nmx_kern_burst_fill(const NmxBurs
   const int item = blockIdx.x;
   nmx_burst_fill_item(A, item / A.n_bands, item % A.n_bands, n2, slots, nmx_smem);
 }
+__global__ void __launch_bounds__(NMX_FILL_NT) nmx_kern_burst_fill_sort(const NmxBurstThrArgs A, int n2, unsigned short* slots, float* sorted) {
+  const int item = blockIdx.x;
+  nmx_burst_fill_sort_item(A, item / A.n_bands, item % A.n_bands, n2, slots, sorted, nmx_smem);
+}
+__global__ void __launch_bounds__(64) nmx_kern_burst_fill_walk(const NmxBurstThrArgs A, int n2, const unsigned short* slots, const float* sorted) {
+  const int item = blockIdx.x;
+  nmx_burst_fill_walk_item(A, item / A.n_bands, item % A.n_bands, n2, slots, sorted, nmx_smem);
+}
 // long histories (4 kHz x 30 s at the 60th percentile: 48 001 list entries): 1024 threads x 64 entries each
 __global__ void __launch_bounds__(1024) nmx_kern_burst_thr_wide(const NmxBurstThrArgs A) {
   const int item = blockIdx.x;
@@ -388,6 +396,7 @@ static void be_init_once() {
   be_allow_lds(nmx_kern_burst_thr<128>);
   be_allow_lds(nmx_kern_burst_thr_wide);
   be_allow_lds(nmx_kern_burst_fill);
+  be_allow_lds(nmx_kern_burst_fill_sort);
   be_allow_lds(nmx_kern_rawnorm_order);   // 24 * (window + hop) + 8 KiB: above 64 KiB from ~2390 samples
 }
 
@@ -506,10 +515,21 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int nt, s
   else if (chunk <= 64) { hipLaunchKernelGGL(nmx_kern_burst_thr<64>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<64>"); }
   else { hipLaunchKernelGGL(nmx_kern_burst_thr<128>, dim3(n_items), dim3(nt), lds, s, A); nmxi_note_kernel("nmx_kern_burst_thr<128>"); }
 }
-static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short* slots, be_stream_t s) {
+static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short* slots, float* sorted, be_stream_t s) {
   be_init_once();
   int n2 = 2048;
   while (n2 < A.W + (A.n_windows - 1) * A.overlap) n2 <<= 1;
+  static int split = -1;
+  if (split < 0) { const char* v = getenv("NMX_FILL_SPLIT"); split = !(v && v[0] == '0'); }
+  const size_t lds_walk = nmx_burst_fill_walk_lds(n2, A.n_windows);
+  if (split && lds_walk <= 48 * 1024) {   // (a hop count whose slot pairs do not fit: the one-launch form)
+    hipLaunchKernelGGL(nmx_kern_burst_fill_sort, dim3(n_items), dim3(NMX_FILL_NT), nmx_burst_fill_sort_lds(n2), s, A, n2, slots, sorted);
+    hipLaunchKernelGGL(nmx_kern_burst_fill_walk, dim3(n_items), dim3(64), lds_walk, s, A, n2, (const unsigned short*)slots,
+                       (const float*)sorted);
+    nmxi_note_kernel("nmx_kern_burst_fill_sort");
+    nmxi_note_kernel("nmx_kern_burst_fill_walk");
+    return;
+  }
   hipLaunchKernelGGL(nmx_kern_burst_fill, dim3(n_items), dim3(NMX_FILL_NT), nmx_burst_fill_lds(n2), s, A, n2, slots);
   nmxi_note_kernel("nmx_kern_burst_fill");
 }

@@ -24,6 +24,16 @@
 
 // LDS bytes for a sort size of n2 samples
 static inline size_t nmx_burst_fill_lds(int n2) { return (size_t)n2 * 4 + 2 * ((size_t)n2 / 8) + 2 * NMX_FILL_CHUNK + 64; }
+// The same computation as TWO launches (round 6, the default): steps 1 - 2 and the top-K head by a 1024-thread workgroup
+// that holds the 128 KB sort (nmx_burst_fill_sort_item: ~0.1 ms, the only part that needs a CU to itself), step 3 by ONE
+// wave per sequence with 21 KB of LDS (nmx_burst_fill_walk_item: the arrival mask, the staged slots and the two slots
+// (rank, rank + 1) of every hop; the sorted values stay in global memory and are read once per hop, all hops in parallel,
+// AFTER the walk).  The monolithic kernel kept 152 KB of a CU's LDS for the ~0.9 ms its one walking wave needs: 768
+// sequences = three rounds over the 256 CUs, 3.1 ms during which the next chunk's filters found no CU to run on.
+static inline size_t nmx_burst_fill_sort_lds(int n2) { return (size_t)n2 * 4 + (size_t)n2 / 8 + 64; }
+static inline size_t nmx_burst_fill_walk_lds(int n2, int n_hops) {
+  return (size_t)n2 / 8 + 2 * NMX_FILL_CHUNK + 4 * (size_t)n_hops + 64;
+}
 
 // hops a fresh stream can hand to this kernel: all samples of the batch must fit the LDS sort
 static inline int nmx_burst_fill_hops(const NmxBurstThrArgs& A, int n_windows) {
@@ -258,6 +268,136 @@ NMX_DEV void nmx_burst_fill_item(const NmxBurstThrArgs& A, int c, int bi, int n2
   float* gtop = A.top + ((long long)c * A.n_bands + bi) * A.K;
   const int keep = M < A.K ? M : A.K;
   for (int i = tid; i < keep; i += nt) gtop[i] = S[i];
+}
+
+// ---- the two-launch form ------------------------------------------------------------------------------------------------
+// steps 1 - 2 + the state's top-K head; `sorted` = [n_seq][NMX_FILL_MAX] floats in global memory
+NMX_DEV void nmx_burst_fill_sort_item(const NmxBurstThrArgs& A, int c, int bi, int n2, unsigned short* slots, float* sorted,
+                                      float* smem) {
+  float* S = smem;                               // [n2] all samples, descending after the sort
+  unsigned* claim = (unsigned*)(S + n2);         // [n2 / 32] slots taken by the look-up
+  const int tid = (int)threadIdx.x, nt = NMX_FILL_NT;
+  const int W = A.W, ov = A.overlap, n = A.n_windows;
+  const int M = W + (n - 1) * ov;
+  const long long row = (long long)A.n_channels * A.n_bands * W;
+  const long long sidx = (long long)c * A.n_bands + bi;
+  const float* e0 = A.env + sidx * W;
+  for (int i = tid; i < n2; i += nt) {
+    float v = -INFINITY;
+    if (i < W) v = e0[i];
+    else if (i < M) { const int h = 1 + (i - W) / ov, o = (i - W) - (h - 1) * ov; v = e0[(long long)h * row + (W - ov) + o]; }
+    S[i] = v;
+  }
+  for (int i = tid; i < n2 / 32; i += nt) claim[i] = 0u;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {   // (the bitonic network of nmx_burst_fill_item)
+    int j = k >> 1;
+    for (; j >= 128; j >>= 1) {
+      for (int t = tid; t < n2 / 2; t += nt) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+        const float a = S[i], b = S[l];
+        if (((i & k) == 0) ? (a < b) : (a > b)) { S[i] = b; S[l] = a; }
+      }
+      __syncthreads();
+    }
+    for (int t = tid; t < n2 / 2; t += nt)
+      for (int jj = j; jj > 0; jj >>= 1) {
+        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), l = i + jj;
+        const float a = S[i], b = S[l];
+        if (((i & k) == 0) ? (a < b) : (a > b)) { S[i] = b; S[l] = a; }
+      }
+    if (k >= 128) __syncthreads();
+  }
+  __syncthreads();
+  unsigned short* sl = slots + sidx * NMX_FILL_MAX;
+  for (int i = tid; i < M; i += nt) {
+    float x;
+    if (i < W) x = e0[i];
+    else { const int h = 1 + (i - W) / ov, o = (i - W) - (h - 1) * ov; x = e0[(long long)h * row + (W - ov) + o]; }
+    int lo = 0, hi = M;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] > x) lo = mid + 1; else hi = mid; }
+    int p = lo;
+    for (;;) {
+      const unsigned bit = 1u << (p & 31);
+      if (!(atomicOr(&claim[p >> 5], bit) & bit)) break;
+      ++p;
+    }
+    sl[i] = (unsigned short)p;
+  }
+  float* Sg = sorted + sidx * NMX_FILL_MAX;
+  for (int i = tid; i < M; i += nt) Sg[i] = S[i];
+  float* gtop = A.top + sidx * A.K;
+  const int keep = M < A.K ? M : A.K;
+  for (int i = tid; i < keep; i += nt) gtop[i] = S[i];
+}
+
+// step 3: ONE wave per sequence (a 64-thread workgroup); the thresholds from the sorted values in global memory, every hop
+// by its own lane, after the walk (same two floats, same float64 interpolation: bit-identical to nmx_burst_fill_item)
+NMX_DEV void nmx_burst_fill_walk_item(const NmxBurstThrArgs& A, int c, int bi, int n2, const unsigned short* slots,
+                                      const float* sorted, float* smem) {
+  unsigned* act = (unsigned*)smem;                          // [n2 / 32] arrived bits
+  unsigned short* sq = (unsigned short*)(act + n2 / 32);    // [NMX_FILL_CHUNK] slots of the next hops
+  unsigned short* pp = sq + NMX_FILL_CHUNK;                 // [2 n] the slots of rank and rank + 1 at every hop
+  const int lane = (int)threadIdx.x;
+  const int W = A.W, ov = A.overlap, n = A.n_windows;
+  const long long sidx = (long long)c * A.n_bands + bi;
+  const unsigned short* sl = slots + sidx * NMX_FILL_MAX;
+  const int nw64 = n2 / 64;
+  for (int i = lane; i < n2 / 32; i += 64) act[i] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  long long total = 0;
+  int pa = 0x7fffffff, ra_prev = 0;
+  const int nh = ov <= NMX_FILL_CHUNK ? NMX_FILL_CHUNK / ov : 0;
+  for (int h = 0; h < n; ++h) {
+    const int n_new = h ? ov : W;
+    int below = 0;
+    if (h == 0 || nh == 0) {
+      const int off = h ? W + (h - 1) * ov : 0;
+      for (int t = lane; t < n_new; t += 64) {
+        const int p = (int)sl[off + t];
+        atomicOr(&act[p >> 5], 1u << (p & 31));
+        below += __popcll(__ballot(p < pa));
+      }
+    } else {
+      const int hc = (h - 1) % nh;
+      if (hc == 0) {
+        const int cnt = ((n - h) < nh ? (n - h) : nh) * ov;
+        const unsigned short* g = sl + W + (h - 1) * ov;
+        for (int t = lane; t < cnt; t += 64) sq[t] = g[t];
+      }
+      for (int t = lane; t < ov; t += 64) {
+        const int p = (int)sq[hc * ov + t];
+        atomicOr(&act[p >> 5], 1u << (p & 31));
+        below += __popcll(__ballot(p < pa));
+      }
+    }
+    total += n_new;
+    below = __builtin_amdgcn_readfirstlane(below);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const long long m = total < (long long)A.n_ring ? total : (long long)A.n_ring;
+    const double pos = A.q * (double)(m - 1);
+    const long long lo_q = (long long)floor(pos);
+    const bool have_hi = lo_q + 1 <= m - 1;
+    const int ra = (int)(m - 1 - lo_q);
+    const int k = h ? ra - (ra_prev + below) : ra + 1;
+    if (k > 0) pa = nmx_fill_forward(act, h ? pa : -1, k, lane, nw64);
+    else if (k < 0) pa = nmx_fill_backward(act, pa, -k, lane, nw64);
+    ra_prev = ra;
+    const int pb = have_hi ? nmx_fill_backward(act, pa, 1, lane, nw64) : 0;
+    if (lane == 0) { pp[2 * h] = (unsigned short)pa; pp[2 * h + 1] = (unsigned short)pb; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const float* Sg = sorted + sidx * NMX_FILL_MAX;
+  for (int h = lane; h < n; h += 64) {
+    const long long tot = (long long)W + (long long)h * ov;
+    const long long m = tot < (long long)A.n_ring ? tot : (long long)A.n_ring;
+    const double pos = A.q * (double)(m - 1);
+    const long long lo_q = (long long)floor(pos);
+    const bool have_hi = lo_q + 1 <= m - 1;
+    A.thr[((long long)h * A.n_channels + c) * A.n_bands + bi] =
+        nmx_lerp_thr((double)Sg[pp[2 * h]], have_hi ? (double)Sg[pp[2 * h + 1]] : 0.0, pos - (double)lo_q, have_hi);
+  }
+  if (lane == 0) { A.counts[2 * sidx] = total; A.counts[2 * sidx + 1] = (long long)n; }
 }
 #endif
 

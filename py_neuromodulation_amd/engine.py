@@ -703,11 +703,18 @@ class HotPathEngine:
             if data.dtype == np.float64 and self.carries_offsets and True:
                 seg = np.ascontiguousarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)   # (C order: NumPy's sums follow the memory layout, the constants must not)
                 ok = np.isfinite(seg)
-                cnt = np.maximum(ok.sum(1), 1)
-                m = np.where(ok, seg, 0.0).sum(1) / cnt
-                sd = np.sqrt(np.where(ok, (seg - m[:, None]) ** 2, 0.0).sum(1) / cnt)
-                if np.any(np.abs(m) > 64.0 * sd):
-                    d = np.where(ok.any(1), m, 0.0)
+                if ok.all():   # (the same sums over the same C-ordered values: the same constants, a third of the time)
+                    m = seg.sum(1) / seg.shape[1]
+                    dev = seg - m[:, None]
+                    sd = np.sqrt((dev * dev).sum(1) / seg.shape[1])
+                    if np.any(np.abs(m) > 64.0 * sd):
+                        d = m
+                else:
+                    cnt = np.maximum(ok.sum(1), 1)
+                    m = np.where(ok, seg, 0.0).sum(1) / cnt
+                    sd = np.sqrt(np.where(ok, (seg - m[:, None]) ** 2, 0.0).sum(1) / cnt)
+                    if np.any(np.abs(m) > 64.0 * sd):
+                        d = np.where(ok.any(1), m, 0.0)
             if d is not None:
                 self.set_offsets(d)
             else:
@@ -824,7 +831,11 @@ class HotPathEngine:
             out = self._pinned.array("out", (n, self.n_outputs), np.float32)
         else:
             out = np.empty((n, self.n_outputs), np.float32)
-        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        if want_nan_mask and data.size >= (1 << 18):   # (page-locked next to page-locked samples / rows: see run_pipelined)
+            mask = self._pinned.array("mask", (n, self.C_in), np.uint8)
+            mask[:] = 0
+        else:
+            mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
         if tap:
             pre = np.empty((n, self.C, self.W), np.float32)
             self.lib.check(self.lib.lib.nmx_process_batch_tap(
@@ -902,7 +913,11 @@ class HotPathEngine:
             runs = np.array([[0, 0, self.n_outputs]], dtype=np.int64)
         runs = np.ascontiguousarray(runs, dtype=np.int64).reshape(-1, 3)
         out = self._pinned.array("out", (n, self.n_outputs), np.float32)
-        mask = np.zeros((n, self.C_in), np.uint8) if want_nan_mask else None
+        # (page-locked like `out`: a copy into PAGEABLE memory is synchronous for the calling thread -- the library's host
+        # loop stood at the mask of chunk k - 1 until that chunk was complete, and the samples of chunk k + 1 waited with it)
+        mask = self._pinned.array("mask", (n, self.C_in), np.uint8) if want_nan_mask else None
+        if mask is not None:
+            mask[:] = 0
         own = ctr is None
         if own:
             ctr = self.pipeline_counters()

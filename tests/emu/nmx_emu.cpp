@@ -120,7 +120,7 @@ static void be_launch_burst_thr(const NmxBurstThrArgs& A, int n_items, int, size
   std::vector<float> sm(lds / 4 + 16);
   for (int it = 0; it < n_items; ++it) nmx_burst_thr_item<1>(A, it / A.n_bands, it % A.n_bands, sm.data());
 }
-static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short*, be_stream_t) {
+static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned short*, float*, be_stream_t) {
   for (int it = 0; it < n_items; ++it) nmx_burst_fill_item_emu(A, it / A.n_bands, it % A.n_bands);
 }
 static void be_launch_burst_stat(const NmxBurstStatArgs& A, int n_items, size_t lds, be_stream_t) {
