@@ -519,8 +519,8 @@ static void be_launch_burst_fill(const NmxBurstThrArgs& A, int n_items, unsigned
   be_init_once();
   int n2 = 2048;
   while (n2 < A.W + (A.n_windows - 1) * A.overlap) n2 <<= 1;
-  static int split = -1;
-  if (split < 0) { const char* v = getenv("NMX_FILL_SPLIT"); split = !(v && v[0] == '0'); }
+  const char* v_split = getenv("NMX_FILL_SPLIT");   // (read per launch -- once per fresh stream: the tests run both forms in one process)
+  const bool split = !(v_split && v_split[0] == '0');
   const size_t lds_walk = nmx_burst_fill_walk_lds(n2, A.n_windows);
   if (split && lds_walk <= 48 * 1024) {   // (a hop count whose slot pairs do not fit: the one-launch form)
     hipLaunchKernelGGL(nmx_kern_burst_fill_sort, dim3(n_items), dim3(NMX_FILL_NT), nmx_burst_fill_sort_lds(n2), s, A, n2, slots, sorted);

@@ -208,9 +208,9 @@ class Stream:
             rows[:, len(keys)] = times
             for k, idx in enumerate(tgt_rows):
                 rows[:, len(keys) + 1 + k] = np.asarray(data[idx])[last]
-            df = pd.DataFrame(rows, columns=keys + ["time"] + tgt_names)
+            df = pd.DataFrame(rows, columns=self._column_index(keys + ["time"] + tgt_names))
         else:
-            df = pd.DataFrame(rows, columns=keys)
+            df = pd.DataFrame(rows, columns=self._column_index(keys))
             df["time"] = times
             for idx, name in zip(tgt_rows, tgt_names):
                 df[name] = np.asarray(data[idx], dtype=np.float64)[last]
@@ -235,6 +235,17 @@ class Stream:
         if writer is not None and delete_ind_batch_files_after_stream:
             writer.delete_ind_files()
         return df if return_df else {}
+
+    def _column_index(self, names: list):
+        """The column Index of the result table, built once per set of names: hashing ~8000 strings into a new Index is
+        0.5 ms of every run (an Index is immutable: the frames of consecutive runs share it)."""
+        import pandas as pd
+
+        cached = getattr(self, "_col_index", None)
+        if cached is None or cached[0] != names:   # (the same string objects run after run: compared by identity first)
+            cached = (names, pd.Index(names))
+            self._col_index = cached
+        return cached[1]
 
     @staticmethod
     def _side_files(out_dir="", experiment_name: str = "sub"):

@@ -668,7 +668,7 @@ def test_alternative_code_paths_agree(gpu_lib, monkeypatch):
     # channel-pair / one-channel kernels, the one-channel notch, the generic sharp-wave / time-oscillatory / threshold-walk kernels, the schedules, a
     # chunk boundary every 9 hops
     for knobs in ({"NMX_BANK_W64C": "0"}, {"NMX_BANK_W64E": "0"}, {"NMX_BANK_W64C": "0", "NMX_BANK_W64E": "0"}, {"NMX_SW_DENSE": "0"}, {"NMX_CAR_FAST": "0"}, {"NMX_OVERLAP": "0"},
-                  {"NMX_OVERLAP": "2"}, {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_TIMEOSC_W1000": "0"},
+                  {"NMX_OVERLAP": "2"}, {"NMX_THR_LIST_GLOBAL": "1"}, {"NMX_THR_FILL": "0"}, {"NMX_FILL_SPLIT": "0"}, {"NMX_TIMEOSC_W1000": "0"},
                   {"NMX_TOW_PERSISTENT": "0"}, {"NMX_CHUNK_WINDOWS": "9"}, {"NMX_WAVES_PER_WG": "1"}, {"NMX_WAVES_PER_WG": "3"},
                   {"NMX_NOTCH_RESIDUAL": "0"}, {"NMX_NOTCH_RESIDUAL": "0", "NMX_BANK_W64E": "0"}):
         for knob, val in knobs.items():
@@ -795,6 +795,10 @@ def test_threshold_walk_one_wave_equals_workgroup_kernel(gpu_lib, monkeypatch, s
     np.testing.assert_array_equal(run(False, [n_hops]), want)            # fill walk + workgroup kernel
     np.testing.assert_array_equal(run(True, [n_hops], fill=False), want)
     np.testing.assert_array_equal(run(True, [n_hops]), want)             # the default: fill walk, then the one-wave walk
+    monkeypatch.setenv("NMX_FILL_SPLIT", "0")                              # the fill as ONE launch (sort and walk in one workgroup)
+    np.testing.assert_array_equal(run(True, [n_hops]), want)
+    np.testing.assert_array_equal(run(False, [n_hops]), want)
+    monkeypatch.delenv("NMX_FILL_SPLIT")
     np.testing.assert_array_equal(run(True, [5, 1, n_hops - 6]), want)   # a fill walk of 5 hops, continued by the others
     monkeypatch.setenv("NMX_CHUNK_WINDOWS", "1024")
     np.testing.assert_array_equal(run(True, [n_hops]), want)             # one chunk: the fill walk ends where the ring is full
