@@ -1,6 +1,14 @@
-import cProfile, pstats, sys, time
+"""cProfile of Stream.run on 256 ch x 120 s float64: a FRESH Stream object on a warm process, then the same object again
+(where the host-side milliseconds around the library call go)."""
+import cProfile
+import pstats
+import sys
+import time
+from pathlib import Path
+
 import numpy as np
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import py_neuromodulation_amd as nm
 C, T = 256, 120000
 rng = np.random.default_rng(0)
