@@ -122,6 +122,12 @@ class Stream:
                                       "accelerated hot path (SURVEY.md section 2)")
         if save_msgpack is None:
             save_msgpack = not delete_ind_batch_files_after_stream
+        # what the reference's run leaves on the object (stream/stream.py:213-219) -- its examples read `stream.out_dir` and
+        # `stream.experiment_name` afterwards (examples/plot_0_first_demo.py: nm.FeatureReader(feature_dir=stream.out_dir, ...))
+        self.is_stream_lsl, self.stream_lsl_name = is_stream_lsl, stream_lsl_name
+        self.save_csv, self.save_interval, self.return_df = save_csv, save_interval, return_df
+        self.out_dir = Path.cwd() if not out_dir else Path(out_dir)
+        self.experiment_name = experiment_name
         import pandas as pd
 
         if data is not None:
@@ -215,6 +221,7 @@ class Stream:
             for idx, name in zip(tgt_rows, tgt_names):
                 df[name] = np.asarray(data[idx], dtype=np.float64)[last]
         self.is_running = False
+        self.batch_count = len(df)   # (stream/stream.py:229,317: hops processed)
         # ---- output files, names and layouts of the reference (stream/stream.py:229,319-343,426-453)
         writer = None
         if save_msgpack:

@@ -98,6 +98,19 @@ def main(swap: bool, stream: bool = False) -> int:
             import py_neuromodulation_amd as amd
 
             nm.Stream = nms.Stream = amd.Stream
+            # user features: registered with BOTH registries -- the reference's sets the flag on its live settings objects
+            # (the caller's `settings` may exist already), the engine's is where the fused Stream looks the class up
+            ref_add, ref_remove = nm.add_custom_feature, nm.remove_custom_feature
+
+            def add_custom_feature(name, cls):
+                ref_add(name, cls)
+                amd.add_custom_feature(name, cls)
+
+            def remove_custom_feature(name):
+                ref_remove(name)
+                amd.remove_custom_feature(name)
+
+            nm.add_custom_feature, nm.remove_custom_feature = add_custom_feature, remove_custom_feature
     plugins = []
     record = os.environ.get("NMX_REFTEST_RECORD")
     if record:
@@ -137,6 +150,31 @@ def main(swap: bool, stream: bool = False) -> int:
             return df
 
         cls.run = run
+    if "--examples" in sys.argv:
+        # the reference's example scripts that need nothing this image lacks, executed IN PLACE (runpy) in the same modes:
+        # plot_6_real_time_demo.py (the one-window call shape, `stream.data_processor.process(window)`) and
+        # plot_2_example_add_feature.py (a user feature through `nm.add_custom_feature` and `Stream.run`)
+        import pickle
+        import runpy
+
+        import matplotlib
+
+        matplotlib.use("Agg")
+        os.chdir("/tmp")
+        tables = {}
+        for name in ("plot_6_real_time_demo.py", "plot_2_example_add_feature.py"):
+            np.random.seed(20)
+            ns = runpy.run_path(str(Path(ref_shim.REFERENCE_ROOT) / "examples" / name), run_name="__main__")
+            for k, v in ns.items():
+                if isinstance(v, pd.DataFrame) and len(v.columns) > 3:
+                    tables[f"{name}:{k}"] = (list(v.columns), v.to_numpy(dtype=float, copy=True))
+            st = ns.get("stream")
+            print(f"example {name}: ran to its end, Stream = {type(st).__module__}.{type(st).__name__}, "
+                  f"tables {[k for k in tables if k.startswith(name)]}")
+        if record:
+            with open(record, "wb") as f:
+                pickle.dump(tables, f)
+        return 0
     tests = Path(ref_shim.REFERENCE_ROOT) / "tests"
     args = [str(tests / f) for f in IN_SCOPE] + ["-q", "-p", "no:cacheprovider", "-o", "addopts=", "--rootdir", str(tests),
                                                   "-W", "ignore", "--tb=line", "-c", "/dev/null"]

@@ -709,6 +709,10 @@ def case_stream_output_files(lib, tmp_path):
                 delete_ind_batch_files_after_stream=False)
     out = tmp_path / "sub7"
     assert sorted(p.name for p in out.iterdir()) == [str(n) for n in g["file_names"]]
+    # what the reference's run leaves on the object (stream/stream.py:213-219): its examples go on from there
+    # (examples/plot_0_first_demo.py: nm.FeatureReader(feature_dir=stream.out_dir, feature_file=stream.experiment_name))
+    assert (st.out_dir, st.experiment_name, st.save_csv, st.save_interval, st.return_df) == (tmp_path, "sub7", True, 10, True)
+    assert st.batch_count == len(df) and st.is_stream_lsl is False
     cols = [str(c) for c in g["df_columns"]]
     assert list(df.columns) == cols and [str(t) for t in df.dtypes] == [str(t) for t in g["df_dtypes"]]
     want = g["df_values"]

@@ -47,3 +47,16 @@ def test_reference_own_tests_pass_with_swapped_plugins():
     # the reference's DataFrame / files out)
     stream_failed, stream_passed = _reference_suite("--stream")
     assert set(stream_failed) <= set(plain_failed) and stream_passed >= plain_passed, (stream_failed, stream_passed)
+
+
+@pytest.mark.skipif(not Path("/root/reference/examples").is_dir(), reason="the reference is only present in the build container")
+def test_reference_examples_run_in_place_with_the_fused_stream():
+    """The reference's example scripts that need nothing this image lacks -- examples/plot_6_real_time_demo.py (the
+    one-window call, `stream.data_processor.process(window)`) and examples/plot_2_example_add_feature.py (a user feature
+    registered through `nm.add_custom_feature`, then `Stream.run`) -- executed in place with `nm.Stream` = the engine's."""
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "run_reference_tests.py"), "--stream", "--examples"],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for name in ("plot_6_real_time_demo.py", "plot_2_example_add_feature.py"):
+        assert f"example {name}: ran to its end, Stream = py_neuromodulation_amd.stream.Stream" in r.stdout, r.stdout[-2000:]
+    assert "plot_2_example_add_feature.py:feature_df" in r.stdout
