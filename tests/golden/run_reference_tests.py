@@ -171,10 +171,26 @@ def main(swap: bool, stream: bool = False) -> int:
             st = ns.get("stream")
             print(f"example {name}: ran to its end, Stream = {type(st).__module__}.{type(st).__name__}, "
                   f"tables {[k for k in tables if k.startswith(name)]}")
+        # ... and the reference's own reader (analysis/feature_reader.py: FEATURES.csv, SIDECAR.json, SETTINGS.yaml,
+        # channels.csv) on what a run of `nm.Stream` -- whichever class that is in this mode -- leaves on disk
+        import shutil
+        import tempfile
+
+        out = tempfile.mkdtemp(prefix="nmx_reader_")
+        np.random.seed(3)
+        st = nm.Stream(sfreq=1000, data=np.random.random((4, 6000)), settings=nm.NMSettings.get_fast_compute(),
+                       sampling_rate_features_hz=10)
+        df = st.run(out_dir=out, experiment_name="probe", save_csv=True)
+        rd = nm.FeatureReader(feature_dir=st.out_dir, feature_file=st.experiment_name)
+        same = (list(rd.feature_arr.columns) == list(df.columns)
+                and np.allclose(rd.feature_arr.to_numpy(dtype=float), df.to_numpy(dtype=float), rtol=1e-12, equal_nan=True))
+        print(f"FeatureReader on the files of {type(st).__module__}.Stream.run: table {rd.feature_arr.shape} identical = {same}, "
+              f"sfreq {rd.sfreq}, channels {list(rd.ch_names)}")
+        shutil.rmtree(out, ignore_errors=True)
         if record:
             with open(record, "wb") as f:
                 pickle.dump(tables, f)
-        return 0
+        return 0 if same else 1
     tests = Path(ref_shim.REFERENCE_ROOT) / "tests"
     args = [str(tests / f) for f in IN_SCOPE] + ["-q", "-p", "no:cacheprovider", "-o", "addopts=", "--rootdir", str(tests),
                                                   "-W", "ignore", "--tb=line", "-c", "/dev/null"]

@@ -60,3 +60,5 @@ def test_reference_examples_run_in_place_with_the_fused_stream():
     for name in ("plot_6_real_time_demo.py", "plot_2_example_add_feature.py"):
         assert f"example {name}: ran to its end, Stream = py_neuromodulation_amd.stream.Stream" in r.stdout, r.stdout[-2000:]
     assert "plot_2_example_add_feature.py:feature_df" in r.stdout
+    # the reference's own FeatureReader loads what the fused Stream wrote (FEATURES.csv, SIDECAR.json, SETTINGS.yaml, channels.csv)
+    assert "FeatureReader on the files of py_neuromodulation_amd.stream.Stream.run: table (51, 17) identical = True" in r.stdout
