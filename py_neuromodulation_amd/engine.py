@@ -257,6 +257,22 @@ import atexit  # noqa: E402
 atexit.register(_free_all_staging)
 
 
+_scratch_tls = None
+
+
+def _offset_scratch(rows: int, cols: int) -> np.ndarray:
+    """A C-ordered float64 [rows, cols] scratch array of the calling thread (`HotPathEngine._host_offsets`)."""
+    global _scratch_tls
+    if _scratch_tls is None:
+        import threading
+
+        _scratch_tls = threading.local()
+    buf = getattr(_scratch_tls, "buf", None)
+    if buf is None or buf.size < rows * cols:
+        buf = _scratch_tls.buf = np.empty(max(rows * cols, 1 << 16), np.float64)
+    return buf[:rows * cols].reshape(rows, cols)
+
+
 class _Pinned:
     """Page-locked staging arrays (nmx_host_alloc), grown on demand and reused across calls."""
 
@@ -701,12 +717,18 @@ class HotPathEngine:
         if self._dc is None:
             d = None
             if data.dtype == np.float64 and self.carries_offsets and True:
-                seg = np.ascontiguousarray(data[:, :min(data.shape[1], 256)], dtype=np.float64)   # (C order: NumPy's sums follow the memory layout, the constants must not)
+                # (C order: NumPy's sums follow the memory layout, the constants must not.  The copy lives in a scratch array
+                # of this thread and the deviations are formed in place: every half-megabyte temporary is an mmap / munmap pair,
+                # and on a host with hundreds of cores and a process with dozens of threads those were 2 ms of a fresh stream)
+                w = min(data.shape[1], 256)
+                seg = _offset_scratch(data.shape[0], w)
+                np.copyto(seg, data[:, :w])
                 ok = np.isfinite(seg)
-                if ok.all():   # (the same sums over the same C-ordered values: the same constants, a third of the time)
-                    m = seg.sum(1) / seg.shape[1]
-                    dev = seg - m[:, None]
-                    sd = np.sqrt((dev * dev).sum(1) / seg.shape[1])
+                if ok.all():   # (the same sums over the same C-ordered values as below: the same constants)
+                    m = seg.sum(1) / w
+                    seg -= m[:, None]
+                    np.multiply(seg, seg, out=seg)
+                    sd = np.sqrt(seg.sum(1) / w)
                     if np.any(np.abs(m) > 64.0 * sd):
                         d = m
                 else:

@@ -243,16 +243,23 @@ class Stream:
             writer.delete_ind_files()
         return df if return_df else {}
 
+    _col_indexes: list = []   # (names, Index) of the last few result tables, shared by every Stream of the process
+    _after_texts: list = []   # (settings token, SETTINGS.yaml text, channels.csv text) of the last few runs
+
     def _column_index(self, names: list):
         """The column Index of the result table, built once per set of names: hashing ~8000 strings into a new Index is
-        0.5 ms of every run (an Index is immutable: the frames of consecutive runs share it)."""
+        0.5 ms of every run (an Index is immutable: the frames of consecutive runs -- of this Stream or of a fresh one with
+        the same settings -- share it)."""
         import pandas as pd
 
-        cached = getattr(self, "_col_index", None)
-        if cached is None or cached[0] != names:   # (the same string objects run after run: compared by identity first)
-            cached = (names, pd.Index(names))
-            self._col_index = cached
-        return cached[1]
+        cache = Stream._col_indexes
+        for entry in cache:
+            if entry[0] == names:   # (mostly the same string objects: compared by identity first)
+                return entry[1]
+        entry = (list(names), pd.Index(names))
+        cache.insert(0, entry)
+        del cache[4:]
+        return entry[1]
 
     @staticmethod
     def _side_files(out_dir="", experiment_name: str = "sub"):
@@ -269,10 +276,14 @@ class Stream:
                    "sfreq": float(self.settings.sampling_rate_features_hz), "sess_right": self.sess_right}
         fw.save_sidecar(sidecar, out_dir, experiment_name)
         # the serialised settings / channel table of the previous run are re-used while both are unchanged
+        # (process-wide: a fresh Stream with the settings of the one before -- the reference builds one per run -- does not
+        # serialise them again; the YAML dump is 3 - 5 ms of pure Python on this thread, holding the GIL the main thread
+        # needs to start its pipeline)
         token = settings_token if settings_token is not None else self._settings_token()
-        cache = getattr(self, "_after_text", None)
-        if cache is None or cache[0] != token:
+        cache = next((c for c in Stream._after_texts if c[0] == token), None)
+        if cache is None:
             cache = (token, self.settings.to_yaml_text(), fw.channels_csv_text(self.channels))
-            self._after_text = cache
+            Stream._after_texts.insert(0, cache)
+            del Stream._after_texts[4:]
         self.settings.save(out_dir or Path.cwd(), experiment_name, text=cache[1])
         fw.save_channels(self.channels, out_dir, experiment_name, text=cache[2])

@@ -19,6 +19,8 @@ st = nm.Stream(sfreq=1000, data=data)
 pr = cProfile.Profile(); pr.enable(); t0=time.perf_counter(); st.run(save_csv=False); t1=time.perf_counter(); pr.disable()
 print("fresh run", t1-t0)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).print_callees("run_pipelined")
+pstats.Stats(pr).print_callees("process_batch_f64")
 pr = cProfile.Profile(); pr.enable(); t0=time.perf_counter(); st.run(save_csv=False); t1=time.perf_counter(); pr.disable()
 print("same object again", t1-t0)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
