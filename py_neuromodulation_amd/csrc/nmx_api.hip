@@ -2,6 +2,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC nmx_api.hip -o ../libnmx.so
 // There is no CPU path in this library: every entry point that computes launches kernels.
 #include <chrono>
+#include <map>
+#include <unordered_map>
 #include <thread>
 #include <hip/hip_runtime.h>
 
@@ -334,22 +336,71 @@ static int be_sync_watch(be_stream_t st, const std::string* kernels, int n_lists
   }
 }
 static void be_sync_quiet(be_stream_t st) { if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError(); }   // (error paths: the first message stays)
-static be_stream_t be_stream_create() {
+// Streams of destroyed plans are recycled (per device, by priority class): hipStreamCreate is a hardware-queue creation of
+// 3.7 ms and hipStreamDestroy 2.5 ms on this runtime (tools/hip_call_costs.py) -- a plan owns seven, so a fresh Stream per
+// run (the reference's pattern) paid tens of milliseconds for what the device-memory pool already saves on hipMalloc.
+// Only IDLE streams are kept (hipStreamQuery == success: whoever destroys a stream has synchronised it, or it never ran
+// anything); at most NMX_STREAM_POOL (32, 0: off) per class and device.
+struct NmxStreamPool {
+  std::mutex mu;
+  std::vector<hipStream_t> idle[2];                       // [0] default priority, [1] highest
+  std::unordered_map<hipStream_t, int> cls;                // streams handed out by this pool -> class
+};
+static NmxStreamPool& be_stream_pool(int dev) {
+  static std::mutex mu;
+  static std::map<int, NmxStreamPool*> pools;
+  std::lock_guard<std::mutex> lk(mu);
+  NmxStreamPool*& p = pools[dev];
+  if (!p) p = new NmxStreamPool();
+  return *p;
+}
+static int be_stream_pool_cap() {
+  static int cap = -1;
+  if (cap < 0) { const char* v = getenv("NMX_STREAM_POOL"); cap = v ? std::max(0, atoi(v)) : 32; }
+  return cap;
+}
+static be_stream_t be_stream_make(int klass) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  NmxStreamPool& P = be_stream_pool(dev);
   hipStream_t s = nullptr;
-  BE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (!P.idle[klass].empty()) { s = P.idle[klass].back(); P.idle[klass].pop_back(); P.cls[s] = klass; return s; }
+  }
+  if (klass == 1) {
+    int lo = 0, hi = 0;
+    if (!(hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+          hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)) {
+      s = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (!s) BE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (s) { std::lock_guard<std::mutex> lk(P.mu); P.cls[s] = klass; }
   return s;
 }
-static void be_stream_destroy(be_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+static be_stream_t be_stream_create() { return be_stream_make(0); }
+static void be_stream_destroy(be_stream_t s) {
+  if (!s) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  NmxStreamPool& P = be_stream_pool(dev);
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.cls.find(s);
+    if (it != P.cls.end()) {
+      const int klass = it->second;
+      P.cls.erase(it);
+      if ((int)P.idle[klass].size() < be_stream_pool_cap() && hipStreamQuery(s) == hipSuccess) { P.idle[klass].push_back(s); return; }
+      (void)hipGetLastError();   // (a busy or failed stream is not kept)
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
 // side stream for the latency-bound bursts chain: highest priority so its few waves are issued
 // ahead of the throughput kernels it overlaps with
-static be_stream_t be_stream_create_high() {
-  int lo = 0, hi = 0;
-  hipStream_t s = nullptr;
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) == hipSuccess)
-    return s;
-  return be_stream_create();
-}
+static be_stream_t be_stream_create_high() { return be_stream_make(1); }
 typedef hipEvent_t be_event_t;
 static void be_event_create(be_event_t& e) { BE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
 static void be_event_destroy(be_event_t& e) { if (e) (void)hipEventDestroy(e); }
