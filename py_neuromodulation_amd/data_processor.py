@@ -123,6 +123,11 @@ class DataProcessor:
                  staging_slot: int = 0) -> None:
         self.settings = NMSettings.load(settings)
         self.channels = chmod.load_channels(channels)
+        # (what a twin for another window length is built from: `process` under the reference's own loop, below)
+        self._ctor = dict(sfreq=sfreq, line_noise=line_noise, verbose=verbose, device=device, lib=lib,
+                          resample_features_at_new_rate=resample_features_at_new_rate, staging_slot=staging_slot)
+        self._twin_ok = channel_subset is None and not dry_run and not local_inputs
+        self._by_len, self._active = None, None
         self.sfreq_features = self.settings.sampling_rate_features_hz
         self._sfreq_raw_orig = sfreq
         self.sfreq_raw = sfreq // 1
@@ -278,10 +283,37 @@ class DataProcessor:
         self.cnt_samples = 0
         self.settings_token = None
 
+    # -- stream/data_processor.py:313-351: what the reference's Stream calls after its loop ---------------------------------
+    def save_sidecar(self, out_dir, prefix: str = "", additional_args: dict | None = None) -> None:
+        from . import file_writer as fw
+
+        sidecar = {"original_fs": self._sfreq_raw_orig, "final_fs": self.sfreq_raw, "sfreq": self.sfreq_features}
+        if additional_args is not None:
+            sidecar = sidecar | additional_args
+        fw.save_sidecar(sidecar, out_dir, prefix)
+
+    def save_settings(self, out_dir, prefix: str = "") -> None:
+        self.settings.save(out_dir, prefix)
+
+    def save_channels(self, out_dir, prefix: str) -> None:
+        from . import file_writer as fw
+
+        fw.save_channels(self.channels, out_dir, prefix)
+
+    def save_features(self, feature_arr, out_dir="", prefix: str = "") -> None:
+        from . import file_writer as fw
+
+        fw.save_features(feature_arr, out_dir, prefix)
+
     def reset(self) -> None:
         """Forget everything carried across hops (burst history, Kalman filters, raw and feature normaliser
         histories): the state of a freshly constructed processor."""
         self.engine.reset_state()
+        if self._by_len is not None:   # (the twins of other window lengths take their state from whoever ran last)
+            for p in self._by_len.values():
+                if p is not self:
+                    p.engine.reset_state()
+            self._active[0] = self
         if self.device_normalizer is not None:
             self.device_normalizer.reset()
         if self._user is not None:
@@ -370,7 +402,41 @@ class DataProcessor:
         d.update(zip(tmpl[2], row.tolist()))
         return d
 
+    def _for_length(self, n_samples: int) -> "DataProcessor":
+        """The processor for windows of ``n_samples`` (a sampling rate that is not a whole number of samples per segment:
+        the reference's generator cuts two lengths, stream/generator.py:41-53, and its DataProcessor takes whatever
+        arrives).  One plan per length; what carries over from hop to hop (burst history, Kalman filters, raw-normaliser
+        history) is handed from plan to plan when the length changes, and ONE feature normaliser and one set of user
+        features serve them all -- the hop-by-hop form of what `Stream.run` does for its ragged runs."""
+        if self._by_len is None:
+            self._by_len, self._active = {self.engine.W_in: self}, [self]
+        p = self._by_len.get(n_samples)
+        if p is None:
+            if not self._twin_ok:
+                raise ValueError(f"expected windows of {self.engine.W_in} samples, got {n_samples}")
+            p = DataProcessor(settings=self.settings, channels=self.channels, window=n_samples, **self._ctor)
+            if self._norm_in_engine:
+                p.device_normalizer = self.device_normalizer
+                p.engine.attach_normalizer(self.device_normalizer)
+            p.feature_normalizer = self.feature_normalizer
+            p._user = self._user
+            p._by_len, p._active = self._by_len, self._active
+            self._by_len[n_samples] = p
+        cur = self._active[0]
+        if cur is not p:
+            state = cur.engine.export_state()
+            if state:
+                p.engine.import_state(state)
+            p.cnt_samples = cur.cnt_samples
+            self._active[0] = p
+        return p
+
     def process(self, data: np.ndarray) -> dict:
+        n_samples = np.shape(data)[-1]
+        if n_samples != self.engine.W_in or (self._active is not None and self._active[0] is not self):
+            p = self._for_length(n_samples)
+            if p is not self:
+                return p.process(data)
         start_time = time()
         if self._user is not None:
             data = np.asarray(data)

@@ -5,6 +5,7 @@ here; on a GPU box the same swap runs on libnmx.so).
 
     python tests/golden/run_reference_tests.py            # classes swapped (the reference's own Stream / DataProcessor loop)
     python tests/golden/run_reference_tests.py --stream   # + `nm.Stream` itself = the engine's fused Stream
+    python tests/golden/run_reference_tests.py --processor   # the reference's Stream loop over the engine's DataProcessor
     python tests/golden/run_reference_tests.py --plain    # the unmodified reference under the same shim: the baseline
 
 What the shim supplies instead of the packages this image lacks: MNE's filter design / resampling as restated in
@@ -93,6 +94,15 @@ def main(swap: bool, stream: bool = False) -> int:
             setattr(nmp, c, getattr(amd_p, c))
         nmflt.NotchFilter = amd_p.NotchFilter
         nmflt.MNEFilter = amd_f.MNEFilter
+        if "--processor" in sys.argv:
+            # the per-hop orchestrator seam: the reference's own Stream (generator, loop, DataFrame, files) calls
+            # `DataProcessor(...)`, `.process(window)` once per hop and `.save_sidecar / _settings / _channels` afterwards
+            import py_neuromodulation.stream as nms
+            import py_neuromodulation.stream.data_processor as nmdp
+            import py_neuromodulation.stream.stream as nmss
+            import py_neuromodulation_amd as amd
+
+            nms.DataProcessor = nmss.DataProcessor = nmdp.DataProcessor = amd.DataProcessor
         if stream:   # the tests construct `nm.Stream(...)` with the reference's pydantic settings and call `.run(...)`
             import py_neuromodulation.stream as nms
             import py_neuromodulation_amd as amd

@@ -2762,3 +2762,58 @@ def case_standalone_resampler_float64(lib):
         assert np.isnan(y[1]).all() and not np.isnan(y[0]).any()
         same = Resampler(1000.0, 1000.0)
         assert same.process(data) is data
+
+
+def case_processor_hop_by_hop_with_two_window_lengths(lib):
+    """`DataProcessor.process(window)` under a loop that hands it whatever the generator cuts (the reference's own
+    `Stream.run`, stream/stream.py:280-311, at 1111.111 Hz: windows of 1111 and 1112 samples) == `Stream.run` of the same
+    recording (one plan per length, hops in order): the burst history and Kalman filters travel between the plans at every
+    change of length, one feature normaliser serves them all.  Without the normaliser bit for bit; with the default
+    z-score to the composition tolerance (scan over a batch vs one hop at a time).  Plus the methods the reference's
+    Stream calls on its processor after the loop (stream/data_processor.py:313-351)."""
+    import json
+    import tempfile
+    from pathlib import Path
+
+    from py_neuromodulation_amd import DataProcessor, NMSettings, Stream
+    from py_neuromodulation_amd import channels as chmod
+    from py_neuromodulation_amd.generator import window_schedule
+
+    sfreq = 1111.111
+    rng = np.random.default_rng(314)
+    T = int(7.5 * sfreq)
+    t = np.arange(T) / sfreq
+    amp = 1.0 + 0.7 * np.sin(2 * np.pi * 0.4 * t)
+    data = np.stack([amp * np.sin(2 * np.pi * 17 * t), amp * np.sin(2 * np.pi * 25 * t + 1), np.sin(2 * np.pi * 70 * t)]) * 30 \
+        + rng.standard_normal((3, T)) * 4 + np.array([[0.0], [900.0], [-40.0]])
+    ch = chmod.get_default_channels_from_data(data)
+    for norm in (False, True):
+        s = NMSettings.get_fast_compute()
+        s.features.bursts = s.features.raw_hjorth = s.features.bandpass_filter = True
+        s.bandpass_filter_settings.kalman_filter = True
+        s.postprocessing.feature_normalization = norm
+        s = s.validate()
+        starts, lens, _ = window_schedule(T, sfreq, s.sampling_rate_features_hz, s.segment_length_features_ms)
+        assert len(set(lens.tolist())) == 2 and len(starts) > 40
+        df = Stream(sfreq=sfreq, channels=ch, settings=s, lib=lib, line_noise=50).run(data, save_csv=False)
+        dp = DataProcessor(sfreq=sfreq, settings=s, channels=ch, line_noise=50, lib=lib, verbose=False)
+        rows = [dp.process(data[:, a:a + n]) for a, n in zip(starts, lens)]
+        assert list(rows[0]) == list(df.columns[:-1]) and len(dp._by_len) == 2
+        got = np.array([list(r.values()) for r in rows])
+        want = df.to_numpy(dtype=np.float64)[:, :-1]
+        if not norm:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+        dp.reset()                                                     # a second pass from a fresh state: the same rows
+        again = np.array([list(dp.process(data[:, a:a + n]).values()) for a, n in zip(starts[:12], lens[:12])])
+        np.testing.assert_array_equal(again, got[:12])
+    with tempfile.TemporaryDirectory() as tmp:
+        dp.save_sidecar(tmp, "sub", {"sess_right": None})
+        dp.save_settings(tmp, "sub")
+        dp.save_channels(tmp, "sub")
+        dp.save_features(df, tmp, "sub")
+        side = json.loads((Path(tmp) / "sub" / "sub_SIDECAR.json").read_text())
+        assert side == {"original_fs": sfreq, "final_fs": sfreq // 1, "sfreq": s.sampling_rate_features_hz, "sess_right": None}
+        assert sorted(p.name for p in (Path(tmp) / "sub").iterdir()) == ["sub_SETTINGS.yaml", "sub_SIDECAR.json", "sub_channels.csv"]
+        assert (Path(tmp) / "sub_FEATURES.csv").exists()

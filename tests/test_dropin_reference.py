@@ -47,6 +47,10 @@ def test_reference_own_tests_pass_with_swapped_plugins():
     # the reference's DataFrame / files out)
     stream_failed, stream_passed = _reference_suite("--stream")
     assert set(stream_failed) <= set(plain_failed) and stream_passed >= plain_passed, (stream_failed, stream_passed)
+    # ... and with the reference's own Stream loop over the engine's DataProcessor (`.process(window)` once per hop, windows
+    # of two lengths at 1111.111 Hz, `.save_sidecar / _settings / _channels` after the loop)
+    proc_failed, proc_passed = _reference_suite("--processor")
+    assert set(proc_failed) <= set(plain_failed) and proc_passed >= plain_passed, (proc_failed, proc_passed)
 
 
 @pytest.mark.skipif(not Path("/root/reference/examples").is_dir(), reason="the reference is only present in the build container")

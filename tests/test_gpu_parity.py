@@ -1050,3 +1050,7 @@ def test_standalone_rereferencer_float64(gpu_lib):
 
 def test_standalone_resampler_float64(gpu_lib):
     pc.case_standalone_resampler_float64(gpu_lib)
+
+
+def test_processor_hop_by_hop_with_two_window_lengths(gpu_lib):
+    pc.case_processor_hop_by_hop_with_two_window_lengths(gpu_lib)

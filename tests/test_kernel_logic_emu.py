@@ -350,3 +350,7 @@ def test_standalone_rereferencer_float64(emu_lib):
 
 def test_standalone_resampler_float64(emu_lib):
     pc.case_standalone_resampler_float64(emu_lib)
+
+
+def test_processor_hop_by_hop_with_two_window_lengths(emu_lib):
+    pc.case_processor_hop_by_hop_with_two_window_lengths(emu_lib)
