@@ -108,6 +108,9 @@ def main(swap: bool, stream: bool = False) -> int:
             import py_neuromodulation_amd as amd
 
             nm.Stream = nms.Stream = amd.Stream
+        if stream or "--processor" in sys.argv:
+            import py_neuromodulation_amd as amd
+
             # user features: registered with BOTH registries -- the reference's sets the flag on its live settings objects
             # (the caller's `settings` may exist already), the engine's is where the fused Stream looks the class up
             ref_add, ref_remove = nm.add_custom_feature, nm.remove_custom_feature

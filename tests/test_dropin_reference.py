@@ -66,3 +66,9 @@ def test_reference_examples_run_in_place_with_the_fused_stream():
     assert "plot_2_example_add_feature.py:feature_df" in r.stdout
     # the reference's own FeatureReader loads what the fused Stream wrote (FEATURES.csv, SIDECAR.json, SETTINGS.yaml, channels.csv)
     assert "FeatureReader on the files of py_neuromodulation_amd.stream.Stream.run: table (51, 17) identical = True" in r.stdout
+    # the same scripts with the reference's own Stream over the engine's DataProcessor
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "run_reference_tests.py"), "--processor", "--examples"],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": ran to its end, Stream = py_neuromodulation.stream.stream.Stream") == 2, r.stdout[-2000:]
+    assert "identical = True" in r.stdout
